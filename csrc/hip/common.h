@@ -1,0 +1,57 @@
+// Common device helpers for the gfx950 (MI355X / CDNA4) kernels.
+// Wavefront = 64 lanes everywhere in this tree; nothing here is portable to other targets.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DTF_API extern "C" __attribute__((visibility("default")))
+#define DTF_WAVE 64
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// hardware RNE convert (v_cvt_pk_bf16_f32); keeps NaN a NaN (MI355X_MICROARCH "Correctness boundaries")
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float bf2f(uint16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Philox4x32-10 counter RNG (dropout masks, samplers): stateless, graph-replay safe because the
+// counter is (element index, device-resident step counter).
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+    uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+    ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+    key.x += W0;
+    key.y += W1;
+  }
+  return ctr;
+}
+__device__ __forceinline__ float u32_to_unit(uint32_t x) { return (x >> 8) * (1.0f / 16777216.0f); }
+
+static inline int dtf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+#define DTF_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t _e = hipGetLastError();                       \
+    if (_e != hipSuccess) return (int)_e;                    \
+  } while (0)

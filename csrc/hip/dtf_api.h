@@ -1,0 +1,29 @@
+// C ABI of libdtf_hip.so (mirrored by distributed_tensorflow_amd/native.py).
+#pragma once
+#include "common.h"
+
+struct HeadParams;
+struct OptimParams;
+
+DTF_API int dtf_fc_fwd(const void* X, int x_is_f32, const float* W, float* out, int M, int N, int K, int splits,
+                       const float* bias, int relu, hipStream_t st);
+DTF_API int dtf_fc_bwd_data(const void* dY, const float* W, float* dX, int M, int N, int K, int splits, hipStream_t st);
+DTF_API int dtf_fc_dw(const void* X, int x_is_f32, const void* dY, float* dW, int M, int N, int K, int splits, hipStream_t st);
+DTF_API int dtf_conv_bias_relu_pool(const void* x, const float* Wt, const float* bias, void* out, void* argmax, int B,
+                                    int H, int W, int Cin, int Cout, int KH, int KW, hipStream_t st);
+DTF_API int dtf_conv_bwd_data_mask(const void* dY, const float* Wt, const void* mask, float* dX, int B, int H, int W,
+                                   int Cin, int Cout, int KH, int KW, hipStream_t st);
+DTF_API int dtf_conv_dw(const void* x, const void* dY, float* dW, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                        int splits, hipStream_t st);
+DTF_API int dtf_conv_bias_relu(const void* x, const void* Wp, const float* bias, void* out, int B, int H, int W, int Cin,
+                               int in_cstride, int Cout, int out_cstride, int KH, int KW, int stride, int pad_h, int pad_w,
+                               int Ho, int Wo, int relu, hipStream_t st);
+DTF_API int dtf_conv1_fwd(const float* images, const int* perm, const int* step_ptr, int spe, int B, const float* Wt,
+                          const float* bias, void* out, void* amax, hipStream_t st);
+DTF_API int dtf_conv1_dw(const float* images, const int* perm, const int* step_ptr, int spe, int B, const float* dpool1,
+                         const void* amax, float* dW, float* db, hipStream_t st);
+DTF_API int dtf_unpool(const float* dpool, const void* pooled, const void* amax, void* dY, float* db, int B, int Hp, int Wp,
+                       int C, hipStream_t st);
+DTF_API int dtf_head(const HeadParams* hp, int blocks, hipStream_t st);
+DTF_API int dtf_adam_tf(const OptimParams* p, hipStream_t st);
+DTF_API int dtf_sgd(const OptimParams* p, hipStream_t st);

@@ -1,0 +1,46 @@
+// Plain-old-data parameter blocks shared by the kernels, the step executor and the ctypes mirror
+// in distributed_tensorflow_amd/native.py (keep field order/types in sync with that file).
+#pragma once
+#include <stdint.h>
+
+struct HeadParams {
+  const float* slabs;     // [nslab][B][1024] raw fc1 partial sums (no bias)
+  int nslab;
+  long slab_stride;
+  const float* b_fc1;
+  const float* W_fc2;     // [1024][10]
+  const float* b_fc2;
+  const int* labels_all;  // int32 class ids of the whole split
+  const int* perm;        // or null (labels_all[b])
+  const int* step_ptr;
+  int spe;
+  int B;
+  float keep_prob;
+  float grad_scale;       // 1 / local batch
+  unsigned long long seed;
+  int double_softmax;
+  int training;
+  uint16_t* h_drop;       // bf16 [B][1024]           (training)
+  uint16_t* dh;           // bf16 [B][1024] d/d(fc1 pre-activation)   (training)
+  uint16_t* dz;           // bf16 [B][10]   dlogits   (training; feeds the fc2 dW GEMM)
+  float* db_fc2;          // [10]   atomics
+  float* db_fc1;          // [1024] atomics
+  float* metrics;         // [2]: loss sum, correct count (atomics)
+  int metrics_ring;       // >0: metrics += 2*(step % ring)
+  float* probs;           // optional fp32 [B][10]
+  int* pred;              // optional int32 [B]
+};
+
+struct OptimParams {
+  float* P;
+  float* G;
+  float* M;
+  float* V;
+  long n;          // elements (multiple of 4)
+  long zero_from;  // gradients at [zero_from, n) are reset to 0 (atomically accumulated segments)
+  float lr, beta1, beta2, eps, grad_scale;
+  int* step;             // device: number of updates applied so far
+  unsigned int* ticket;  // device: arrival counter (0 between launches)
+  float* metrics_ring;   // optional: slot (t % ring) zeroed for the next step's head kernel
+  int ring;
+};

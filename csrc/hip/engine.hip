@@ -1,0 +1,192 @@
+// Native step executor for the MNIST CNN: the whole train step — batch gather,
+// forward, fused loss head, backward, optimizer — is a fixed sequence of 12 kernels + 1 memset issued
+// from C++ on one HIP stream and (normally) replayed as a hipGraph, so the ~100 us step is not bound
+// by Python/launch overhead.  All per-step state that changes (step counter, batch offset, dropout
+// counter, metric slot) lives in device memory, which is what makes the captured graph replayable.
+//
+// The backward is split in two parts so a data-parallel driver can all-reduce the fc gradient bucket
+// (98 % of the bytes) on a communication stream while the conv backward still runs:
+//   part 1: conv1 fwd -> conv2 fwd -> fc1 (split-K) -> head -> fc2 dW -> fc1 dW        [bucket A ready]
+//   part 2: fc1 bwd-data -> unpool2(+db2) -> conv2 bwd-data -> conv2 dW -> conv1 dW/db  [bucket B ready]
+//   apply : multi-tensor TF-Adam over the flat arena (also zeroes the atomically accumulated grads)
+#include "dtf_api.h"
+#include "dtf_structs.h"
+
+struct MnistEngine {
+  int B, maxB, spe, world, double_softmax, fc1_splits, bwd_splits, dw2_splits, head_blocks, ring;
+  float lr, beta1, beta2, eps, keep_prob;
+  unsigned long long seed;
+  const float* images;
+  const int* labels;
+  const int* perm;
+  float *P, *G, *M, *V;
+  long n_arena;
+  long off_Wfc1, off_bfc1, off_Wfc2, off_bfc2, off_Wc2, off_bc2, off_Wc1, off_bc1;
+  int* step;
+  unsigned int* ticket;
+  float* metrics_ring;
+  void *pool1, *amax1, *pool2, *amax2;
+  float* slabs;
+  void *h_drop, *dh, *dz;
+  float* dpool2;
+  void* dy2;
+  float* dpool1;
+};
+
+#define DTF_TRY(x)            \
+  do {                        \
+    int _r = (x);             \
+    if (_r != 0) return _r;   \
+  } while (0)
+
+static int forward_to_slabs(const MnistEngine* e, const float* images, const int* perm, const int* step, int n,
+                            int splits, bool need_argmax, hipStream_t st) {
+  DTF_TRY(dtf_conv1_fwd(images, perm, step, e->spe, n, e->P + e->off_Wc1, e->P + e->off_bc1, e->pool1,
+                        need_argmax ? e->amax1 : nullptr, st));
+  DTF_TRY(dtf_conv_bias_relu_pool(e->pool1, e->P + e->off_Wc2, e->P + e->off_bc2, e->pool2,
+                                  need_argmax ? e->amax2 : nullptr, n, 14, 14, 32, 64, 5, 5, st));
+  DTF_TRY(dtf_fc_fwd(e->pool2, 0, e->P + e->off_Wfc1, e->slabs, n, 1024, 3136, splits, nullptr, 0, st));
+  return 0;
+}
+
+static int effective_splits(int K, int splits) {
+  const int ksteps = (K + 31) / 32;
+  const int kchunk = ((ksteps + splits - 1) / splits) * 32;
+  return (K + kchunk - 1) / kchunk;
+}
+
+DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e, int parts, hipStream_t st) {
+  const int B = e->B;
+  if (B <= 0 || B > e->maxB) return -22;
+  if (parts & 1) {
+    DTF_TRY(forward_to_slabs(e, e->images, e->perm, e->step, B, e->fc1_splits, true, st));
+    HeadParams hp{};
+    hp.slabs = e->slabs;
+    hp.nslab = effective_splits(3136, e->fc1_splits);
+    hp.slab_stride = (long)B * 1024;
+    hp.b_fc1 = e->P + e->off_bfc1;
+    hp.W_fc2 = e->P + e->off_Wfc2;
+    hp.b_fc2 = e->P + e->off_bfc2;
+    hp.labels_all = e->labels;
+    hp.perm = e->perm;
+    hp.step_ptr = e->step;
+    hp.spe = e->spe;
+    hp.B = B;
+    hp.keep_prob = e->keep_prob;
+    hp.grad_scale = 1.0f / (float)B;
+    hp.seed = e->seed;
+    hp.double_softmax = e->double_softmax;
+    hp.training = 1;
+    hp.h_drop = (uint16_t*)e->h_drop;
+    hp.dh = (uint16_t*)e->dh;
+    hp.dz = (uint16_t*)e->dz;
+    hp.db_fc2 = e->G + e->off_bfc2;
+    hp.db_fc1 = e->G + e->off_bfc1;
+    hp.metrics = e->metrics_ring;
+    hp.metrics_ring = e->ring;
+    DTF_TRY(dtf_head(&hp, e->head_blocks, st));
+    // fc2 dW[1024][10] = h_drop^T * dz      (stored, not accumulated)
+    DTF_TRY(dtf_fc_dw(e->h_drop, 0, e->dz, e->G + e->off_Wfc2, 1024, 10, B, 1, st));
+    // fc1 dW[3136][1024] = pool2^T * dh     (stored: 12.8 MB, the one gradient that is never re-zeroed)
+    DTF_TRY(dtf_fc_dw(e->pool2, 0, e->dh, e->G + e->off_Wfc1, 3136, 1024, B, 1, st));
+  }
+  if (parts & 2) {
+    const int bs = effective_splits(1024, e->bwd_splits);
+    if (bs > 1) {
+      hipError_t err = hipMemsetAsync(e->dpool2, 0, (size_t)B * 3136 * sizeof(float), st);
+      if (err != hipSuccess) return (int)err;
+    }
+    DTF_TRY(dtf_fc_bwd_data(e->dh, e->P + e->off_Wfc1, e->dpool2, B, 3136, 1024, e->bwd_splits, st));
+    DTF_TRY(dtf_unpool(e->dpool2, e->pool2, e->amax2, e->dy2, e->G + e->off_bc2, B, 7, 7, 64, st));
+    DTF_TRY(dtf_conv_bwd_data_mask(e->dy2, e->P + e->off_Wc2, e->pool1, e->dpool1, B, 14, 14, 32, 64, 5, 5, st));
+    DTF_TRY(dtf_conv_dw(e->pool1, e->dy2, e->G + e->off_Wc2, B, 14, 14, 32, 64, 5, 5, e->dw2_splits, st));
+    DTF_TRY(dtf_conv1_dw(e->images, e->perm, e->step, e->spe, B, e->dpool1, e->amax1, e->G + e->off_Wc1,
+                         e->G + e->off_bc1, st));
+  }
+  return 0;
+}
+
+DTF_API int dtf_mnist_apply(const MnistEngine* e, hipStream_t st) {
+  OptimParams op{};
+  op.P = e->P; op.G = e->G; op.M = e->M; op.V = e->V;
+  op.n = e->n_arena;
+  op.zero_from = e->off_bfc1;  // everything after W_fc1 is accumulated with atomics
+  op.lr = e->lr; op.beta1 = e->beta1; op.beta2 = e->beta2; op.eps = e->eps;
+  op.grad_scale = 1.0f / (float)(e->world > 0 ? e->world : 1);
+  op.step = e->step;
+  op.ticket = e->ticket;
+  op.metrics_ring = e->metrics_ring;
+  op.ring = e->ring;
+  return dtf_adam_tf(&op, st);
+}
+
+// Inference / evaluation over n samples (contiguous or via `index`), chunked by the workspace size.
+// metrics[2] (loss sum, correct count) must be zeroed by the caller; probs / pred are optional.
+DTF_API int dtf_mnist_eval(const MnistEngine* e, const float* images, const int* labels, int n, float* metrics,
+                           float* probs, int* pred, hipStream_t st) {
+  if (n <= 0) return -22;
+  for (int off = 0; off < n; off += e->maxB) {
+    const int c = (n - off) < e->maxB ? (n - off) : e->maxB;
+    DTF_TRY(forward_to_slabs(e, images + (long)off * 784, nullptr, nullptr, c, 1, false, st));
+    HeadParams hp{};
+    hp.slabs = e->slabs;
+    hp.nslab = 1;
+    hp.slab_stride = (long)c * 1024;
+    hp.b_fc1 = e->P + e->off_bfc1;
+    hp.W_fc2 = e->P + e->off_Wfc2;
+    hp.b_fc2 = e->P + e->off_bfc2;
+    hp.labels_all = labels + off;
+    hp.B = c;
+    hp.spe = 1;
+    hp.keep_prob = 1.0f;
+    hp.grad_scale = 0.f;
+    hp.double_softmax = e->double_softmax;
+    hp.training = 0;
+    hp.metrics = metrics;
+    hp.metrics_ring = 0;
+    hp.probs = probs ? probs + (long)off * 10 : nullptr;
+    hp.pred = pred ? pred + off : nullptr;
+    const int blocks = c < 1024 ? c : 1024;
+    DTF_TRY(dtf_head(&hp, blocks, st));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ hipGraph helpers
+// Capture whatever is enqueued on `st` between begin/end (our launchers, torch ops, RCCL calls)
+// and replay it with one host call.  Relaxed mode: other threads (checkpoint saver) may keep
+// issuing HIP calls while the capture is open.
+struct DtfGraph {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+
+DTF_API int dtf_graph_begin(hipStream_t st) { return (int)hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed); }
+
+DTF_API int dtf_graph_end(hipStream_t st, void** out) {
+  DtfGraph* g = new DtfGraph{};
+  hipError_t e = hipStreamEndCapture(st, &g->graph);
+  if (e != hipSuccess) { delete g; return (int)e; }
+  e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) { hipGraphDestroy(g->graph); delete g; return (int)e; }
+  *out = g;
+  return 0;
+}
+
+DTF_API int dtf_graph_launch(void* h, hipStream_t st) { return (int)hipGraphLaunch(((DtfGraph*)h)->exec, st); }
+
+DTF_API int dtf_graph_num_nodes(void* h) {
+  size_t n = 0;
+  if (hipGraphGetNodes(((DtfGraph*)h)->graph, nullptr, &n) != hipSuccess) return -1;
+  return (int)n;
+}
+
+DTF_API void dtf_graph_free(void* h) {
+  DtfGraph* g = (DtfGraph*)h;
+  if (!g) return;
+  hipGraphExecDestroy(g->exec);
+  hipGraphDestroy(g->graph);
+  delete g;
+}
+
+DTF_API int dtf_version() { return 1; }

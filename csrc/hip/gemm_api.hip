@@ -1,0 +1,125 @@
+// C ABI launchers for the MFMA GEMM / implicit-GEMM instantiations (see gemm_core.h).
+// Every launcher validates the shapes/alignments its kernel assumes and returns a non-zero code
+// instead of launching when they do not hold (a faulting kernel can reset the whole GPU host).
+#include "gemm_core.h"
+
+namespace {
+constexpr int ERR_SHAPE = -22;
+
+inline GemmParams base_params(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb,
+                              long ldc, int splits) {
+  GemmParams p{};
+  p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  const int ksteps = dtf_cdiv(K, kBK);
+  p.kchunk = dtf_cdiv(ksteps, splits) * kBK;
+  p.slab_stride = (long)M * ldc;
+  return p;
+}
+inline int eff_splits(const GemmParams& p) { return dtf_cdiv(p.K, p.kchunk); }
+}  // namespace
+
+// out[z][M][N] (fp32 slabs) = X[M][K] (bf16|fp32, row-major) * W[K][N] (fp32, TF [in,out] layout)
+// splits == 1: bias/relu (optional) are applied; splits > 1: raw partial sums per slab.
+DTF_API int dtf_fc_fwd(const void* X, int x_is_f32, const float* W, float* out, int M, int N, int K, int splits,
+                       const float* bias, int relu, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 8 || N % 2 || splits < 1) return ERR_SHAPE;
+  GemmParams p = base_params(X, W, out, M, N, K, K, N, N, splits);
+  const int s = eff_splits(p);
+  p.bias = (s == 1) ? bias : nullptr;
+  p.relu = (s == 1) ? relu : 0;
+  if (x_is_f32)
+    return dtf_launch_gemm<128, 64, 4, 1, LoadRowK<float, 128, 256, true>, LoadColK<float, 64, 256, false>, EpStoreF32>(p, s, st);
+  return dtf_launch_gemm<128, 64, 4, 1, LoadRowK<uint16_t, 128, 256, true>, LoadColK<float, 64, 256, false>, EpStoreF32>(p, s, st);
+}
+
+// dX[M][N] (fp32) (+)= dY[M][K] (bf16) * W[N][K]^T with W fp32 [N][K] (TF [in,out] layout seen from the input side).
+// splits > 1 accumulates with fp32 atomics into a pre-zeroed dX.
+DTF_API int dtf_fc_bwd_data(const void* dY, const float* W, float* dX, int M, int N, int K, int splits, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 8 || splits < 1) return ERR_SHAPE;
+  GemmParams p = base_params(dY, W, dX, M, N, K, K, K, N, splits);
+  const int s = eff_splits(p);
+  if (s == 1)
+    return dtf_launch_gemm<128, 64, 4, 1, LoadRowK<uint16_t, 128, 256, true>, LoadRowK<float, 64, 256, false>, EpStoreF32>(p, 1, st);
+  return dtf_launch_gemm<128, 64, 4, 1, LoadRowK<uint16_t, 128, 256, true>, LoadRowK<float, 64, 256, false>, EpAtomicF32>(p, s, st);
+}
+
+// dW[M][N] (fp32) = X[K][M]^T * dY[K][N]   (both bf16 row-major [batch][features]; K = batch)
+// splits > 1 accumulates atomically into a pre-zeroed dW.
+DTF_API int dtf_fc_dw(const void* X, int x_is_f32, const void* dY, float* dW, int M, int N, int K, int splits, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0 || M % 2 || N % 2 || splits < 1) return ERR_SHAPE;
+  GemmParams p = base_params(X, dY, dW, M, N, K, M, N, N, splits);
+  const int s = eff_splits(p);
+  if (x_is_f32) {
+    if (s == 1)
+      return dtf_launch_gemm<128, 64, 4, 1, LoadColK<float, 128, 256, true>, LoadColK<uint16_t, 64, 256, false>, EpStoreF32>(p, 1, st);
+    return dtf_launch_gemm<128, 64, 4, 1, LoadColK<float, 128, 256, true>, LoadColK<uint16_t, 64, 256, false>, EpAtomicF32>(p, s, st);
+  }
+  if (s == 1)
+    return dtf_launch_gemm<128, 64, 4, 1, LoadColK<uint16_t, 128, 256, true>, LoadColK<uint16_t, 64, 256, false>, EpStoreF32>(p, 1, st);
+  return dtf_launch_gemm<128, 64, 4, 1, LoadColK<uint16_t, 128, 256, true>, LoadColK<uint16_t, 64, 256, false>, EpAtomicF32>(p, s, st);
+}
+
+static inline int fill_geom(GemmParams& p, int H, int W, int Cin, int cstride, int Ho, int Wo, int KH, int KW,
+                            int stride, int pad_h, int pad_w) {
+  p.g.H = H; p.g.W = W; p.g.Cin = Cin; p.g.cstride = cstride; p.g.Ho = Ho; p.g.Wo = Wo;
+  p.g.KH = KH; p.g.KW = KW; p.g.stride = stride; p.g.pad_h = pad_h; p.g.pad_w = pad_w;
+  if (Cin % 8 || cstride % 8 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return ERR_SHAPE;
+  return 0;
+}
+
+// Fused conv (stride 1) + bias + ReLU + 2x2/2 max-pool.  x: bf16 NHWC [B,H,W,Cin]; Wt: fp32 HWIO
+// [KH*KW*Cin][Cout]; out: bf16 [B,H/2,W/2,Cout]; argmax: uint8 same shape (may be null).
+DTF_API int dtf_conv_bias_relu_pool(const void* x, const float* Wt, const float* bias, void* out, void* argmax,
+                                    int B, int H, int W, int Cin, int Cout, int KH, int KW, hipStream_t st) {
+  if (B <= 0 || H % 2 || W % 2 || Cout % 2) return ERR_SHAPE;
+  const int M = B * H * W, K = KH * KW * Cin;
+  GemmParams p = base_params(x, Wt, out, M, Cout, K, 0, Cout, Cout, 1);
+  if (fill_geom(p, H, W, Cin, Cin, H, W, KH, KW, 1, (KH - 1) / 2, (KW - 1) / 2)) return ERR_SHAPE;
+  p.bias = bias;
+  p.aux_out = argmax;
+  return dtf_launch_gemm<64, 64, 2, 2, LoadConvA<64, 256, 1>, LoadColK<float, 64, 256, false>, EpBiasReluPool>(p, 1, st);
+}
+
+// Conv backward-data (stride 1, SAME) fused with the ReLU mask of the producing layer's pooled output:
+//   dX[b,h,w,ci] = (mask[b,h,w,ci] > 0) * sum_{tap,co} dY[b,h+dy'-p,w+dx'-p,co] * W[flip(tap)][ci][co]
+// dY: bf16 NHWC [B,H,W,Cout] (dense); Wt fp32 HWIO; mask: bf16 [B,H,W,Cin]; dX: fp32 [B,H,W,Cin].
+DTF_API int dtf_conv_bwd_data_mask(const void* dY, const float* Wt, const void* mask, float* dX, int B, int H, int W,
+                                   int Cin, int Cout, int KH, int KW, hipStream_t st) {
+  if (B <= 0 || Cout % 8 || mask == nullptr) return ERR_SHAPE;
+  const int M = B * H * W, K = KH * KW * Cout;
+  GemmParams p = base_params(dY, Wt, dX, M, Cin, K, 0, 0, Cin, 1);
+  if (fill_geom(p, H, W, Cout, Cout, H, W, KH, KW, 1, (KH - 1) / 2, (KW - 1) / 2)) return ERR_SHAPE;
+  p.aux_in = mask;
+  return dtf_launch_gemm<64, 32, 2, 1, LoadConvA<64, 128, 0>, LoadConvWBwd<32, 128>, EpMaskMulF32>(p, 1, st);
+}
+
+// Conv filter gradient: dW[tap][ci][co] (fp32 HWIO, pre-zeroed, atomics) += sum_pos X[pos+tap][ci] * dY[pos][co]
+// x: bf16 NHWC [B,H,W,Cin]; dY: bf16 NHWC [B,H,W,Cout] (stride 1, SAME).
+DTF_API int dtf_conv_dw(const void* x, const void* dY, float* dW, int B, int H, int W, int Cin, int Cout, int KH,
+                        int KW, int splits, hipStream_t st) {
+  if (B <= 0 || Cin % 2 || Cout % 2 || splits < 1) return ERR_SHAPE;
+  const int M = KH * KW * Cin, K = B * H * W;
+  GemmParams p = base_params(x, dY, dW, M, Cout, K, 0, Cout, Cout, splits);
+  if (fill_geom(p, H, W, Cin, Cin, H, W, KH, KW, 1, (KH - 1) / 2, (KW - 1) / 2)) return ERR_SHAPE;
+  return dtf_launch_gemm<128, 64, 4, 1, LoadConvDwA<128, 256>, LoadColK<uint16_t, 64, 256, false>, EpAtomicF32>(p, eff_splits(p), st);
+}
+
+// General inference conv for the Inception-v3 backbone: x bf16 NHWC (channel stride in_cstride, so the
+// input may be a channel slice of a concat buffer), Wp: bf16 packed [Cout][KH*KW*Cin] (BN folded),
+// bias fp32 [Cout]; out bf16 written at channel stride out_cstride (a slice of the concat buffer).
+DTF_API int dtf_conv_bias_relu(const void* x, const void* Wp, const float* bias, void* out, int B, int H, int W,
+                               int Cin, int in_cstride, int Cout, int out_cstride, int KH, int KW, int stride,
+                               int pad_h, int pad_w, int Ho, int Wo, int relu, hipStream_t st) {
+  if (B <= 0 || Cout <= 0) return ERR_SHAPE;
+  const int M = B * Ho * Wo, K = KH * KW * Cin;
+  GemmParams p = base_params(x, Wp, out, M, Cout, K, 0, K, out_cstride, 1);
+  if (fill_geom(p, H, W, Cin, in_cstride, Ho, Wo, KH, KW, stride, pad_h, pad_w)) return ERR_SHAPE;
+  p.bias = bias;
+  p.relu = relu;
+  if (Cout <= 32)
+    return dtf_launch_gemm<128, 32, 4, 1, LoadConvA<128, 256, 0>, LoadRowK<uint16_t, 32, 256, false>, EpBiasReluBf16>(p, 1, st);
+  if (M <= 256 * 64)
+    return dtf_launch_gemm<64, 64, 2, 2, LoadConvA<64, 256, 0>, LoadRowK<uint16_t, 64, 256, false>, EpBiasReluBf16>(p, 1, st);
+  return dtf_launch_gemm<128, 64, 4, 1, LoadConvA<128, 256, 0>, LoadRowK<uint16_t, 64, 256, false>, EpBiasReluBf16>(p, 1, st);
+}

@@ -1,0 +1,479 @@
+// MFMA (v_mfma_f32_32x32x16_bf16) GEMM / implicit-GEMM core for gfx950.
+//
+//   C[M,N] (+)= A[M,K] * B[N,K]^T      fp32 accumulate, bf16 MFMA operands
+//
+// One templated kernel; the operand *loaders* decide where a [rows x 32] K-slab comes from
+// (row-major, column-major with an in-register transpose, NHWC conv gather, conv-weight views)
+// and the *epilogues* decide what happens to the 32x32 accumulator fragments (split-K slabs,
+// fp32 atomics, bias+ReLU bf16 store into a concat slice, bias+ReLU+2x2 max-pool, masking).
+// fp32 sources are converted to bf16 while staging, so the fp32 master weights are read
+// directly and no bf16 shadow copy of the parameters has to be maintained by the optimizer.
+//
+// Tiling: workgroup = WM x WN waves (64 lanes each); each wave owns TM x TN MFMA tiles of 32x32.
+// LDS tiles are [rows][32 k] bf16 with an 80-byte row stride: 16-byte aligned for ds_read_b128 and
+// conflict-free for the 16-lane groups of that instruction (20 dwords/row -> rows hit distinct
+// 4-bank slots mod 64).  Register prefetch: the global loads of K-slab t+1 are in flight while the
+// MFMAs of slab t run.
+//
+// Fragment maps (cdna_hip_programming.md §3): lane l, r=l&31, h=l>>5:
+//   A frag = A[row r][k = 8h..8h+7], B frag = B[k = 8h..8h+7][col r],
+//   C/D reg i -> row (i&3) + 8*(i>>2) + 4h, col r.
+#pragma once
+#include "common.h"
+
+constexpr int kBK = 32;         // K elements per staged slab
+constexpr int kLdsStride = 40;  // bf16 elements per LDS row (32 + 8 pad = 80 bytes)
+
+struct ConvGeom {
+  int H, W, Cin, cstride;  // gathered NHWC tensor: spatial dims, channels taken per tap, channel stride
+  int Ho, Wo, KH, KW, stride, pad_h, pad_w;
+};
+
+struct GemmParams {
+  const void* A;
+  const void* B;
+  void* C;
+  int M, N, K;
+  long lda, ldb, ldc;
+  int kchunk;        // K elements per blockIdx.z slice (multiple of 32)
+  long slab_stride;  // elements between split-K slabs
+  const float* bias;
+  int relu;
+  const void* aux_in;
+  void* aux_out;
+  ConvGeom g;
+};
+
+// ------------------------------------------------------------------ element loads
+template <typename T>
+struct Ld8;
+template <>
+struct Ld8<uint16_t> {  // bf16 bits
+  static __device__ __forceinline__ uint4 ld(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+};
+template <>
+struct Ld8<float> {
+  static __device__ __forceinline__ uint4 ld(const float* p) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0];
+    const float4 b = reinterpret_cast<const float4*>(p)[1];
+    return make_uint4(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w), pack_bf2(b.x, b.y), pack_bf2(b.z, b.w));
+  }
+};
+template <typename T>
+struct Ld2;  // two adjacent elements -> two bf16 bit patterns
+template <>
+struct Ld2<uint16_t> {
+  static __device__ __forceinline__ void ld(const uint16_t* p, uint32_t& e0, uint32_t& e1) {
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(p);
+    e0 = v & 0xffffu;
+    e1 = v >> 16;
+  }
+};
+template <>
+struct Ld2<float> {
+  static __device__ __forceinline__ void ld(const float* p, uint32_t& e0, uint32_t& e1) {
+    const float2 v = *reinterpret_cast<const float2*>(p);
+    e0 = f2bf(v.x);
+    e1 = f2bf(v.y);
+  }
+};
+
+// ------------------------------------------------------------------ loaders
+// Every loader: init(p, r0, tid) / load(k0, kend, tid) -> registers / store(lds, tid) -> LDS [R][40].
+
+// src[row*ld + k]   (k contiguous); needs ld % 8 == 0 (bf16) or % 4 == 0 (fp32), K % 8 == 0
+template <typename T, int R, int NT, bool IS_A>
+struct LoadRowK {
+  static constexpr int NCHUNK = R * 4;
+  static constexpr int PER = (NCHUNK + NT - 1) / NT;
+  uint4 regs[PER];
+  const T* src;
+  long ld;
+  int rows, r0;
+  __device__ __forceinline__ void init(const GemmParams& p, int r0_, int) {
+    src = reinterpret_cast<const T*>(IS_A ? p.A : p.B);
+    ld = IS_A ? p.lda : p.ldb;
+    rows = IS_A ? p.M : p.N;
+    r0 = r0_;
+  }
+  __device__ __forceinline__ void load(int k0, int kend, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + NT * i;
+      const int row = c >> 2, k = k0 + (c & 3) * 8;
+      const bool ok = (NCHUNK % NT == 0 || c < NCHUNK) && (r0 + row) < rows && k < kend;
+      regs[i] = ok ? Ld8<T>::ld(src + (long)(r0 + row) * ld + k) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  __device__ __forceinline__ void store(uint16_t* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + NT * i;
+      if (NCHUNK % NT == 0 || c < NCHUNK)
+        *reinterpret_cast<uint4*>(lds + (c >> 2) * kLdsStride + (c & 3) * 8) = regs[i];
+    }
+  }
+};
+
+// src[k*ld + row]   (row contiguous): transposed in registers while staging.  rows, ld even.
+template <typename T, int R, int NT, bool IS_A>
+struct LoadColK {
+  static constexpr int NTASK = (R / 2) * 4;
+  static constexpr int PER = (NTASK + NT - 1) / NT;
+  uint32_t lo[PER][4], hi[PER][4];
+  const T* src;
+  long ld;
+  int rows, r0;
+  __device__ __forceinline__ void init(const GemmParams& p, int r0_, int) {
+    src = reinterpret_cast<const T*>(IS_A ? p.A : p.B);
+    ld = IS_A ? p.lda : p.ldb;
+    rows = IS_A ? p.M : p.N;
+    r0 = r0_;
+  }
+  __device__ __forceinline__ void load(int k0, int kend, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int t = tid + NT * i;
+      const int rp = t % (R / 2), kc = t / (R / 2);
+      const int row = r0 + 2 * rp;
+      const bool okr = (NTASK % NT == 0 || t < NTASK) && row < rows;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { lo[i][q] = 0; hi[i][q] = 0; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + kc * 8 + j;
+        uint32_t e0 = 0, e1 = 0;
+        if (okr && k < kend) Ld2<T>::ld(src + (long)k * ld + row, e0, e1);
+        lo[i][j >> 1] |= e0 << ((j & 1) * 16);
+        hi[i][j >> 1] |= e1 << ((j & 1) * 16);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(uint16_t* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int t = tid + NT * i;
+      if (NTASK % NT == 0 || t < NTASK) {
+        const int rp = t % (R / 2), kc = t / (R / 2);
+        *reinterpret_cast<uint4*>(lds + (2 * rp) * kLdsStride + kc * 8) = make_uint4(lo[i][0], lo[i][1], lo[i][2], lo[i][3]);
+        *reinterpret_cast<uint4*>(lds + (2 * rp + 1) * kLdsStride + kc * 8) = make_uint4(hi[i][0], hi[i][1], hi[i][2], hi[i][3]);
+      }
+    }
+  }
+};
+
+// Implicit-GEMM activation gather: row m = output position, k = (tap, channel) of a bf16 NHWC tensor.
+// ORDER 0: m = (b, ho, wo).  ORDER 1: m = 4*window + sub over 2x2 pooling windows, so the four
+// members of a window land in one lane's consecutive accumulator registers (fused max-pool).
+template <int R, int NT, int ORDER>
+struct LoadConvA {
+  static_assert(NT % 4 == 0, "NT");
+  static constexpr int NCHUNK = R * 4;
+  static constexpr int PER = (NCHUNK + NT - 1) / NT;
+  uint4 regs[PER];
+  const uint16_t* src;
+  int img[PER], hi0[PER], wi0[PER];
+  bool okr[PER];
+  ConvGeom g;
+  __device__ __forceinline__ void init(const GemmParams& p, int m0, int tid) {
+    src = reinterpret_cast<const uint16_t*>(p.A);
+    g = p.g;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + NT * i;
+      const int m = m0 + (c >> 2);
+      okr[i] = (NCHUNK % NT == 0 || c < NCHUNK) && m < p.M;
+      int b, ho, wo;
+      if (ORDER == 0) {
+        wo = m % g.Wo;
+        const int t = m / g.Wo;
+        ho = t % g.Ho;
+        b = t / g.Ho;
+      } else {
+        const int win = m >> 2, sub = m & 3;
+        const int Wp = g.Wo >> 1, Hp = g.Ho >> 1;
+        const int px = win % Wp, t = win / Wp;
+        const int py = t % Hp;
+        b = t / Hp;
+        ho = 2 * py + (sub >> 1);
+        wo = 2 * px + (sub & 1);
+      }
+      img[i] = b;
+      hi0[i] = ho * g.stride - g.pad_h;
+      wi0[i] = wo * g.stride - g.pad_w;
+    }
+  }
+  __device__ __forceinline__ void load(int k0, int kend, int tid) {
+    const int kk = k0 + (tid & 3) * 8;
+    const int tap = kk / g.Cin, ci = kk - tap * g.Cin;
+    const int dy = tap / g.KW, dx = tap - dy * g.KW;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int hi = hi0[i] + dy, wi = wi0[i] + dx;
+      const bool ok = okr[i] && kk < kend && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+      regs[i] = ok ? *reinterpret_cast<const uint4*>(src + ((long)(img[i] * g.H + hi) * g.W + wi) * g.cstride + ci)
+                   : make_uint4(0, 0, 0, 0);
+    }
+  }
+  __device__ __forceinline__ void store(uint16_t* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + NT * i;
+      if (NCHUNK % NT == 0 || c < NCHUNK)
+        *reinterpret_cast<uint4*>(lds + (c >> 2) * kLdsStride + (c & 3) * 8) = regs[i];
+    }
+  }
+};
+
+// Backward-data weight view of an fp32 HWIO filter W[tap][n=cin][kc=cout]:
+//   B[n][k = (tap', cout)] = W[(KH*KW-1) - tap'][n][cout]      (taps flipped, k contiguous)
+// g.Cin holds the channels per tap of the gathered tensor (= cout of the forward conv).
+template <int R, int NT>
+struct LoadConvWBwd {
+  static constexpr int NCHUNK = R * 4;
+  static constexpr int PER = (NCHUNK + NT - 1) / NT;
+  uint4 regs[PER];
+  const float* src;
+  int rows, r0, kc_per_tap, ntaps;
+  __device__ __forceinline__ void init(const GemmParams& p, int r0_, int) {
+    src = reinterpret_cast<const float*>(p.B);
+    rows = p.N;
+    r0 = r0_;
+    kc_per_tap = p.g.Cin;
+    ntaps = p.g.KH * p.g.KW;
+  }
+  __device__ __forceinline__ void load(int k0, int kend, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + NT * i;
+      const int row = c >> 2, kk = k0 + (c & 3) * 8;
+      const int tapp = kk / kc_per_tap, co = kk - tapp * kc_per_tap;
+      const int tap = ntaps - 1 - tapp;
+      const bool ok = (NCHUNK % NT == 0 || c < NCHUNK) && (r0 + row) < rows && kk < kend;
+      regs[i] = ok ? Ld8<float>::ld(src + ((long)tap * rows + (r0 + row)) * kc_per_tap + co) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  __device__ __forceinline__ void store(uint16_t* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + NT * i;
+      if (NCHUNK % NT == 0 || c < NCHUNK)
+        *reinterpret_cast<uint4*>(lds + (c >> 2) * kLdsStride + (c & 3) * 8) = regs[i];
+    }
+  }
+};
+
+// Filter-gradient activation gather (transposing): row r = (tap, cin), k = output position (b,y,x):
+//   A[r][k] = X[b, y*stride + dy - pad, x*stride + dx - pad, cin]     (bf16 NHWC, Cin even)
+template <int R, int NT>
+struct LoadConvDwA {
+  static constexpr int NTASK = (R / 2) * 4;
+  static constexpr int PER = (NTASK + NT - 1) / NT;
+  uint32_t lo[PER][4], hi[PER][4];
+  const uint16_t* src;
+  int dy[PER], dx[PER], ci[PER];
+  bool okr[PER];
+  ConvGeom g;
+  int npos;
+  __device__ __forceinline__ void init(const GemmParams& p, int r0, int tid) {
+    src = reinterpret_cast<const uint16_t*>(p.A);
+    g = p.g;
+    npos = g.Ho * g.Wo;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int t = tid + NT * i;
+      const int r = r0 + 2 * (t % (R / 2));
+      okr[i] = (NTASK % NT == 0 || t < NTASK) && r < p.M;
+      const int tap = r / g.Cin;
+      ci[i] = r - tap * g.Cin;
+      dy[i] = tap / g.KW - g.pad_h;
+      dx[i] = tap % g.KW - g.pad_w;
+    }
+  }
+  __device__ __forceinline__ void load(int k0, int kend, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int t = tid + NT * i;
+      const int kc = t / (R / 2);
+      int pos = k0 + kc * 8;
+      int b = pos / npos, rem = pos - b * npos;
+      int y = rem / g.Wo, x = rem - y * g.Wo;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { lo[i][q] = 0; hi[i][q] = 0; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int hi_ = y * g.stride + dy[i], wi_ = x * g.stride + dx[i];
+        uint32_t e0 = 0, e1 = 0;
+        if (okr[i] && (pos + j) < kend && (unsigned)hi_ < (unsigned)g.H && (unsigned)wi_ < (unsigned)g.W)
+          Ld2<uint16_t>::ld(src + ((long)(b * g.H + hi_) * g.W + wi_) * g.cstride + ci[i], e0, e1);
+        lo[i][j >> 1] |= e0 << ((j & 1) * 16);
+        hi[i][j >> 1] |= e1 << ((j & 1) * 16);
+        if (++x == g.Wo) { x = 0; if (++y == g.Ho) { y = 0; ++b; } }
+      }
+    }
+  }
+  __device__ __forceinline__ void store(uint16_t* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int t = tid + NT * i;
+      if (NTASK % NT == 0 || t < NTASK) {
+        const int rp = t % (R / 2), kc = t / (R / 2);
+        *reinterpret_cast<uint4*>(lds + (2 * rp) * kLdsStride + kc * 8) = make_uint4(lo[i][0], lo[i][1], lo[i][2], lo[i][3]);
+        *reinterpret_cast<uint4*>(lds + (2 * rp + 1) * kLdsStride + kc * 8) = make_uint4(hi[i][0], hi[i][1], hi[i][2], hi[i][3]);
+      }
+    }
+  }
+};
+
+// ------------------------------------------------------------------ epilogues
+// run(p, acc, mbase, nbase, lane, z): acc[TM][TN] of f32x16; rows/cols per the C/D map above.
+#define DTF_EP_FOREACH(body)                                                        \
+  _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) {                              \
+    const int row = mbase + tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);     \
+    const int col = nbase + tn * 32 + (lane & 31);                                  \
+    const float v = acc[tm][tn][i];                                                 \
+    body                                                                            \
+  }
+
+struct EpStoreF32 {  // C[z][m][n] = acc (+bias) (relu)
+  template <int TM, int TN>
+  static __device__ __forceinline__ void run(const GemmParams& p, f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int z) {
+    float* C = reinterpret_cast<float*>(p.C) + (long)z * p.slab_stride;
+    DTF_EP_FOREACH(if (row < p.M && col < p.N) {
+      float o = v + (p.bias ? p.bias[col] : 0.f);
+      if (p.relu) o = fmaxf(o, 0.f);
+      C[(long)row * p.ldc + col] = o;
+    })
+  }
+};
+
+struct EpAtomicF32 {  // C[m][n] += acc   (split-K / cross-workgroup accumulation)
+  template <int TM, int TN>
+  static __device__ __forceinline__ void run(const GemmParams& p, f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int) {
+    float* C = reinterpret_cast<float*>(p.C);
+    DTF_EP_FOREACH(if (row < p.M && col < p.N) atomicAdd(&C[(long)row * p.ldc + col], v);)
+  }
+};
+
+struct EpBiasReluBf16 {  // out[m*ldc + n] = bf16(relu(acc + bias[n]))   (conv into a concat slice)
+  template <int TM, int TN>
+  static __device__ __forceinline__ void run(const GemmParams& p, f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int) {
+    uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
+    DTF_EP_FOREACH(if (row < p.M && col < p.N) {
+      float o = v + (p.bias ? p.bias[col] : 0.f);
+      if (p.relu) o = fmaxf(o, 0.f);
+      C[(long)row * p.ldc + col] = f2bf(o);
+    })
+  }
+};
+
+struct EpMaskMulF32 {  // C = acc * (mask_bf16 > 0): conv bwd-data through the ReLU of the pooled input
+  template <int TM, int TN>
+  static __device__ __forceinline__ void run(const GemmParams& p, f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int) {
+    float* C = reinterpret_cast<float*>(p.C);
+    const uint16_t* mask = reinterpret_cast<const uint16_t*>(p.aux_in);
+    DTF_EP_FOREACH(if (row < p.M && col < p.N) {
+      const long o = (long)row * p.ldc + col;
+      const uint16_t mk = mask[o];
+      C[o] = ((mk & 0x7fffu) != 0 && (mk & 0x8000u) == 0) ? v : 0.f;
+    })
+  }
+};
+
+// bias + ReLU + 2x2/2 max-pool over rows in pool-window order (LoadConvA ORDER 1).
+// out: bf16 [M/4][N] (== NHWC pooled), aux_out: uint8 argmax (0..3 = 2*sy+sx) for the backward.
+struct EpBiasReluPool {
+  template <int TM, int TN>
+  static __device__ __forceinline__ void run(const GemmParams& p, f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int) {
+    uint16_t* out = reinterpret_cast<uint16_t*>(p.C);
+    uint8_t* amax = reinterpret_cast<uint8_t*>(p.aux_out);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int col = nbase + tn * 32 + (lane & 31);
+        const float bv = (col < p.N && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int row = mbase + tm * 32 + 8 * gq + 4 * (lane >> 5);
+          float best = acc[tm][tn][4 * gq];
+          int arg = 0;
+#pragma unroll
+          for (int j = 1; j < 4; ++j) {
+            const float v = acc[tm][tn][4 * gq + j];
+            if (v > best) { best = v; arg = j; }
+          }
+          if (row < p.M && col < p.N) {
+            const long o = (long)(row >> 2) * p.ldc + col;
+            out[o] = f2bf(fmaxf(best + bv, 0.f));
+            if (amax) amax[o] = (uint8_t)arg;
+          }
+        }
+      }
+  }
+};
+
+// ------------------------------------------------------------------ the kernel
+template <int BM, int BN, int WM, int WN, class AL, class BL, class EP>
+__global__ __launch_bounds__(64 * WM * WN) void dtf_gemm_kernel(const GemmParams p) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static_assert(TM >= 1 && TN >= 1 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile");
+  __shared__ __attribute__((aligned(16))) uint16_t As[BM * kLdsStride];
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[BN * kLdsStride];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
+  const int kbeg = z * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  AL al;
+  BL bl;
+  al.init(p, m0, tid);
+  bl.init(p, n0, tid);
+  al.load(kbeg, kend, tid);
+  bl.load(kbeg, kend, tid);
+  const int r = lane & 31, h = lane >> 5;
+  for (int k = kbeg; k < kend; k += kBK) {
+    __syncthreads();
+    al.store(As, tid);
+    bl.store(Bs, tid);
+    __syncthreads();
+    if (k + kBK < kend) {
+      al.load(k + kBK, kend, tid);
+      bl.load(k + kBK, kend, tid);
+    }
+#pragma unroll
+    for (int kk = 0; kk < kBK; kk += 16) {
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+        af[a] = *reinterpret_cast<const bf16x8*>(&As[(wm * (BM / WM) + a * 32 + r) * kLdsStride + kk + 8 * h]);
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+        bfr[b] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * (BN / WN) + b * 32 + r) * kLdsStride + kk + 8 * h]);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+  }
+  EP::template run<TM, TN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, z);
+}
+
+template <int BM, int BN, int WM, int WN, class AL, class BL, class EP>
+static inline int dtf_launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
+  dim3 grid(dtf_cdiv(p.M, BM), dtf_cdiv(p.N, BN), splits);
+  hipLaunchKernelGGL((dtf_gemm_kernel<BM, BN, WM, WN, AL, BL, EP>), grid, dim3(64 * WM * WN), 0, st, p);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,380 @@
+// MNIST-CNN specific kernels (everything that is not GEMM-shaped):
+//   conv1 forward  : direct 5x5 conv (Cin=1, K=25 is MFMA-hostile) + bias + ReLU + 2x2 max-pool, with the
+//                    mini-batch gathered by index straight out of the HBM-resident dataset
+//   conv1 backward : filter/bias gradient through the pool argmax (no data gradient needed)
+//   unpool2        : max-pool/ReLU backward that expands the fc1 data gradient into the dense bf16 dY
+//                    consumed by the conv2 backward implicit GEMMs, fused with the conv2 bias gradient
+//   head           : fc1 split-K combine + bias + ReLU + Philox dropout + fc2 + softmax + (double)
+//                    softmax cross-entropy + accuracy + dlogits + fc2/fc1 bias grads + fc1 pre-act grad
+// Reference semantics: demo1/train.py:57-141.
+#include "common.h"
+#include "dtf_structs.h"
+
+namespace {
+constexpr int ERR_SHAPE = -22;
+constexpr int HID = 1024;
+constexpr int NC = 10;
+}  // namespace
+
+// index of the sample feeding batch row b of the current step
+__device__ __forceinline__ int sample_index(const int* perm, const int* step_ptr, int spe, int B, int b) {
+  if (perm == nullptr) return b;
+  const int step = step_ptr ? *step_ptr : 0;
+  return perm[(long)(step % spe) * B + b];
+}
+
+// ------------------------------------------------------------------ conv1 forward
+// grid (B, 4): blockIdx.y = group of 8 output channels (wave-uniform -> weights come through scalar loads).
+// x: fp32 [N,784]; Wt: fp32 [25][32] (HWIO, I=1); out: bf16 [B,14,14,32]; amax: uint8 [B,14,14,32].
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ images, const int* __restrict__ perm,
+                                                        const int* __restrict__ step_ptr, int spe, int B,
+                                                        const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                        uint16_t* __restrict__ out, uint8_t* __restrict__ amax) {
+  __shared__ float img[32 * 32];  // rows/cols -2..29 (SAME padding halo)
+  const int b = blockIdx.x, cg = blockIdx.y, tid = threadIdx.x;
+  const long n = sample_index(perm, step_ptr, spe, B, b);
+  const float* src = images + n * 784;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = tid + 256 * i, r = e >> 5, c = e & 31;
+    const int y = r - 2, x = c - 2;
+    img[e] = ((unsigned)y < 28u && (unsigned)x < 28u) ? src[y * 28 + x] : 0.f;
+  }
+  __syncthreads();
+  if (tid >= 196) return;
+  const int py = tid / 14, px = tid - py * 14;
+  float patch[6][6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) patch[r][c] = img[(2 * py + r) * 32 + 2 * px + c];
+  float acc[4][8];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[s][j] = 0.f;
+  const float* w = Wt + cg * 8;
+#pragma unroll
+  for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) {
+      float wv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wv[j] = w[(dy * 5 + dx) * 32 + j];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float v = patch[(s >> 1) + dy][(s & 1) + dx];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[s][j] = fmaf(v, wv[j], acc[s][j]);
+      }
+    }
+  uint32_t ov[4];
+  uint32_t av[2] = {0, 0};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float best = acc[0][j];
+    int arg = 0;
+#pragma unroll
+    for (int s = 1; s < 4; ++s)
+      if (acc[s][j] > best) { best = acc[s][j]; arg = s; }
+    const float o = fmaxf(best + bias[cg * 8 + j], 0.f);
+    const uint32_t bits = f2bf(o);
+    if (j & 1) ov[j >> 1] |= bits << 16; else ov[j >> 1] = bits;
+    av[j >> 2] |= (uint32_t)arg << ((j & 3) * 8);
+  }
+  const long o = ((long)b * 196 + tid) * 32 + cg * 8;
+  *reinterpret_cast<uint4*>(out + o) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+  if (amax) *reinterpret_cast<uint2*>(amax + o) = make_uint2(av[0], av[1]);
+}
+
+DTF_API int dtf_conv1_fwd(const float* images, const int* perm, const int* step_ptr, int spe, int B, const float* Wt,
+                          const float* bias, void* out, void* amax, hipStream_t st) {
+  if (B <= 0 || (perm && spe <= 0)) return ERR_SHAPE;
+  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(B, 4), dim3(256), 0, st, images, perm, step_ptr, spe, B, Wt, bias,
+                     (uint16_t*)out, (uint8_t*)amax);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------ conv1 backward (filter + bias grads)
+// dpool1: fp32 [B,14,14,32] gradient wrt the pooled+ReLU'd conv1 output (already ReLU-masked);
+// amax: pool argmax.  dW[25][32], db[32] accumulated with atomics (pre-zeroed).
+__global__ __launch_bounds__(256) void conv1_dw_kernel(const float* __restrict__ images, const int* __restrict__ perm,
+                                                       const int* __restrict__ step_ptr, int spe, int B,
+                                                       const float* __restrict__ dpool1, const uint8_t* __restrict__ amax,
+                                                       float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float img[32 * 32];
+  __shared__ float red[8 * 26 * 32];
+  const int tid = threadIdx.x, c = tid & 31, pg = tid >> 5;
+  float acc[26];
+#pragma unroll
+  for (int t = 0; t < 26; ++t) acc[t] = 0.f;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const long n = sample_index(perm, step_ptr, spe, B, b);
+    const float* src = images + n * 784;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i, r = e >> 5, cc = e & 31;
+      const int y = r - 2, x = cc - 2;
+      img[e] = ((unsigned)y < 28u && (unsigned)x < 28u) ? src[y * 28 + x] : 0.f;
+    }
+    __syncthreads();
+    for (int p = pg; p < 196; p += 8) {
+      const long o = ((long)b * 196 + p) * 32 + c;
+      const float g = dpool1[o];
+      const int a = amax[o];
+      const int py = p / 14, px = p - py * 14;
+      const int r0 = 2 * py + (a >> 1), c0 = 2 * px + (a & 1);
+#pragma unroll
+      for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) acc[dy * 5 + dx] = fmaf(img[(r0 + dy) * 32 + c0 + dx], g, acc[dy * 5 + dx]);
+      acc[25] += g;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 26; ++t) red[(pg * 26 + t) * 32 + c] = acc[t];
+  __syncthreads();
+  for (int e = tid; e < 26 * 32; e += 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += red[q * 26 * 32 + e];
+    if (e < 25 * 32) atomicAdd(&dW[e], s); else atomicAdd(&db[e - 25 * 32], s);
+  }
+}
+
+DTF_API int dtf_conv1_dw(const float* images, const int* perm, const int* step_ptr, int spe, int B, const float* dpool1,
+                         const void* amax, float* dW, float* db, hipStream_t st) {
+  if (B <= 0 || (perm && spe <= 0)) return ERR_SHAPE;
+  const int grid = B < 256 ? B : 256;
+  hipLaunchKernelGGL(conv1_dw_kernel, dim3(grid), dim3(256), 0, st, images, perm, step_ptr, spe, B, dpool1,
+                     (const uint8_t*)amax, dW, db);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------ unpool2 (+ conv2 bias grad)
+// dpool: fp32 [W][C] (W = B*Hp*Wp windows), pooled: bf16 [W][C] forward output (ReLU mask), amax: uint8 [W][C].
+// dY: bf16 dense [B, 2Hp, 2Wp, C]; db[C] += sum of the masked gradient.   C % 8 == 0, C <= 256.
+__global__ __launch_bounds__(256) void unpool_kernel(const float* __restrict__ dpool, const uint16_t* __restrict__ pooled,
+                                                     const uint8_t* __restrict__ amax, uint16_t* __restrict__ dY,
+                                                     float* __restrict__ db, int nwin, int Hp, int Wp, int C) {
+  __shared__ float dbs[256];
+  const int tid = threadIdx.x;
+  dbs[tid] = 0.f;
+  __syncthreads();
+  const int c8n = C >> 3;
+  const long gi = (long)blockIdx.x * 256 + tid;
+  const long win = gi / c8n;
+  const int c0 = (int)(gi - win * c8n) * 8;
+  if (win < nwin) {
+    const long o = win * C + c0;
+    const float4 g0 = *reinterpret_cast<const float4*>(dpool + o);
+    const float4 g1 = *reinterpret_cast<const float4*>(dpool + o + 4);
+    const uint4 pv = *reinterpret_cast<const uint4*>(pooled + o);
+    const uint2 av = *reinterpret_cast<const uint2*>(amax + o);
+    float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const uint32_t pw[4] = {pv.x, pv.y, pv.z, pv.w};
+    int a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t bits = (pw[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+      const bool pos = (bits & 0x7fffu) != 0 && (bits & 0x8000u) == 0;
+      g[j] = pos ? g[j] : 0.f;
+      a[j] = ((j < 4 ? av.x : av.y) >> ((j & 3) * 8)) & 0xff;
+      if (db) atomicAdd(&dbs[c0 + j], g[j]);
+    }
+    const int px = (int)(win % Wp);
+    const long t = win / Wp;
+    const int py = (int)(t % Hp);
+    const long b = t / Hp;
+    const int W2 = 2 * Wp;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      uint32_t ov[4];
+#pragma unroll
+      for (int j = 0; j < 8; j += 2)
+        ov[j >> 1] = pack_bf2(a[j] == s ? g[j] : 0.f, a[j + 1] == s ? g[j + 1] : 0.f);
+      const long d = ((b * 2 * Hp + 2 * py + (s >> 1)) * W2 + 2 * px + (s & 1)) * C + c0;
+      *reinterpret_cast<uint4*>(dY + d) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+    }
+  }
+  if (db) {
+    __syncthreads();
+    if (tid < C) atomicAdd(&db[tid], dbs[tid]);
+  }
+}
+
+DTF_API int dtf_unpool(const float* dpool, const void* pooled, const void* amax, void* dY, float* db, int B, int Hp,
+                       int Wp, int C, hipStream_t st) {
+  if (B <= 0 || C % 8 || C > 256) return ERR_SHAPE;
+  const long nwin = (long)B * Hp * Wp;
+  const long nthreads = nwin * (C / 8);
+  hipLaunchKernelGGL(unpool_kernel, dim3(dtf_cdiv(nthreads, 256)), dim3(256), 0, st, dpool, (const uint16_t*)pooled,
+                     (const uint8_t*)amax, (uint16_t*)dY, db, (int)nwin, Hp, Wp, C);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------ head
+
+__global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
+  __shared__ float red[2][4][NC];
+  __shared__ float db1s[HID];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = tid * 4;
+  float w2[4][NC];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < NC; ++j) w2[q][j] = p.W_fc2[(k + q) * NC + j];
+  const float4 b1 = *reinterpret_cast<const float4*>(p.b_fc1 + k);
+  float b2[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) b2[j] = p.b_fc2[j];
+  const int step = p.step_ptr ? *p.step_ptr : 0;
+  float accb1[4] = {0.f, 0.f, 0.f, 0.f};
+  float accb2[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) accb2[j] = 0.f;
+  float loss_sum = 0.f, correct = 0.f;
+  const float inv_keep = 1.f / p.keep_prob;
+  int it = 0;
+  for (int row = blockIdx.x; row < p.B; row += gridDim.x, ++it) {
+    float4 h = b1;
+    for (int s = 0; s < p.nslab; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(p.slabs + (long)s * p.slab_stride + (long)row * HID + k);
+      h.x += v.x; h.y += v.y; h.z += v.z; h.w += v.w;
+    }
+    float hv[4] = {fmaxf(h.x, 0.f), fmaxf(h.y, 0.f), fmaxf(h.z, 0.f), fmaxf(h.w, 0.f)};
+    bool keep[4] = {true, true, true, true};
+    if (p.training && p.keep_prob < 1.f) {
+      const uint4 r = philox4x32_10(make_uint4((uint32_t)(row * 256 + tid), (uint32_t)step, 0x6d6e6973u, 0u),
+                                    make_uint2((uint32_t)p.seed, (uint32_t)(p.seed >> 32)));
+      const uint32_t rv[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        keep[q] = u32_to_unit(rv[q]) < p.keep_prob;
+        hv[q] = keep[q] ? hv[q] * inv_keep : 0.f;
+      }
+    }
+    // the fc2 GEMV consumes the same bf16-rounded activations the backward GEMMs will see
+    uint32_t hb[2] = {pack_bf2(hv[0], hv[1]), pack_bf2(hv[2], hv[3])};
+    float hr[4] = {bf2f(hb[0] & 0xffffu), bf2f(hb[0] >> 16), bf2f(hb[1] & 0xffffu), bf2f(hb[1] >> 16)};
+    float part[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s = fmaf(hr[q], w2[q][j], s);
+      part[j] = wave_sum(s);
+    }
+    const int buf = it & 1;
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j) red[buf][wave][j] = part[j];
+    }
+    __syncthreads();
+    float z[NC], zmax = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      z[j] = red[buf][0][j] + red[buf][1][j] + red[buf][2][j] + red[buf][3][j] + b2[j];
+      zmax = fmaxf(zmax, z[j]);
+    }
+    float pr[NC], psum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) { pr[j] = __expf(z[j] - zmax); psum += pr[j]; }
+    const float pinv = 1.f / psum;
+    int arg = 0;
+    float pbest = -1.f;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      pr[j] *= pinv;
+      if (pr[j] > pbest) { pbest = pr[j]; arg = j; }
+    }
+    const int y = p.labels_all[sample_index(p.perm, p.step_ptr, p.spe, p.B, row)];
+    float dzv[NC];
+    float loss;
+    if (p.double_softmax) {
+      // loss = -log softmax(p)[y]   (demo1/train.py:123,127: softmax applied twice)
+      float q[NC], qsum = 0.f;
+#pragma unroll
+      for (int j = 0; j < NC; ++j) { q[j] = __expf(pr[j] - 1.f); qsum += q[j]; }  // p <= 1: stable shift
+      const float qinv = 1.f / qsum;
+      float gp[NC], dot = 0.f, qy = 0.f;
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        q[j] *= qinv;
+        if (j == y) qy = q[j];
+        gp[j] = (q[j] - (j == y ? 1.f : 0.f)) * p.grad_scale;
+        dot = fmaf(gp[j], pr[j], dot);
+      }
+      loss = -__logf(qy);
+#pragma unroll
+      for (int j = 0; j < NC; ++j) dzv[j] = pr[j] * (gp[j] - dot);
+    } else {
+      float py_ = 0.f;
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        if (j == y) py_ = pr[j];
+        dzv[j] = (pr[j] - (j == y ? 1.f : 0.f)) * p.grad_scale;
+      }
+      loss = -__logf(fmaxf(py_, 1e-30f));
+    }
+    if (tid == 0) {
+      loss_sum += loss;
+      correct += (arg == y) ? 1.f : 0.f;
+      if (p.pred) p.pred[row] = arg;
+    }
+    if (p.probs) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j)
+        if (tid == j) p.probs[(long)row * NC + j] = pr[j];
+    }
+    if (p.training) {
+      *reinterpret_cast<uint2*>(p.h_drop + (long)row * HID + k) = make_uint2(hb[0], hb[1]);
+      float dhv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) s = fmaf(dzv[j], w2[q][j], s);
+        dhv[q] = (keep[q] && hv[q] > 0.f) ? s * inv_keep : 0.f;
+        accb1[q] += dhv[q];
+      }
+      *reinterpret_cast<uint2*>(p.dh + (long)row * HID + k) = make_uint2(pack_bf2(dhv[0], dhv[1]), pack_bf2(dhv[2], dhv[3]));
+#pragma unroll
+      for (int j = 0; j < NC; ++j)
+        if (tid == j) p.dz[(long)row * NC + j] = f2bf(dzv[j]);
+#pragma unroll
+      for (int j = 0; j < NC; ++j) accb2[j] += dzv[j];
+    }
+  }
+  if (tid == 0) {
+    float* m = p.metrics + (p.metrics_ring > 0 ? 2 * (step % p.metrics_ring) : 0);
+    atomicAdd(&m[0], loss_sum);
+    atomicAdd(&m[1], correct);
+  }
+  if (p.training) {
+    if (tid == 0) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j) atomicAdd(&p.db_fc2[j], accb2[j]);
+    }
+    // contiguous 256-B atomics per wave instruction (lane-strided float4 adds are ~4x more memory requests)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) db1s[k + q] = accb1[q];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) atomicAdd(&p.db_fc1[i * 256 + tid], db1s[i * 256 + tid]);
+  }
+}
+
+DTF_API int dtf_head(const HeadParams* hp, int blocks, hipStream_t st) {
+  if (hp->B <= 0 || hp->nslab < 1 || blocks < 1 || hp->keep_prob <= 0.f) return ERR_SHAPE;
+  if (hp->training && (!hp->h_drop || !hp->dh || !hp->dz || !hp->db_fc1 || !hp->db_fc2)) return ERR_SHAPE;
+  if (blocks > hp->B) blocks = hp->B;
+  hipLaunchKernelGGL(head_kernel, dim3(blocks), dim3(256), 0, st, *hp);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}

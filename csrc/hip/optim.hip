@@ -1,0 +1,85 @@
+// Multi-tensor optimizers over the flat parameter arena (components C6/C7, kernel K14/K18).
+// One launch updates every parameter: fp32 master weights, Adam slots and gradients live in four
+// parallel flat arrays, so "8 x ApplyAdam" (demo1/train.py:132) is a single memory-bound stream.
+//
+// TF-1.x Adam:  lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  m,v EMA;  p -= lr_t*m/(sqrt(v)+eps)  (eps outside the
+// bias correction).  The 1-based step t lives in device memory and is advanced by the last workgroup to
+// finish (arrival ticket), so a captured hipGraph can be replayed without any host-side argument patch.
+#include "common.h"
+#include "dtf_structs.h"
+
+
+__device__ __forceinline__ void finish_step(const OptimParams& p, int t) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int prev = atomicAdd(p.ticket, 1u);
+    if (prev == gridDim.x - 1) {  // every workgroup has read *step and finished its updates
+      *p.ticket = 0u;
+      *p.step = t;
+      if (p.metrics_ring && p.ring > 0) {
+        p.metrics_ring[2 * (t % p.ring)] = 0.f;
+        p.metrics_ring[2 * (t % p.ring) + 1] = 0.f;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_tf_kernel(const OptimParams p) {
+  const int t = *p.step + 1;
+  const double b1p = pow((double)p.beta1, (double)t), b2p = pow((double)p.beta2, (double)t);
+  const float lr_t = (float)((double)p.lr * sqrt(1.0 - b2p) / (1.0 - b1p));
+  const float b1 = p.beta1, b2 = p.beta2, ob1 = 1.f - p.beta1, ob2 = 1.f - p.beta2;
+  const long n4 = p.n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 g = reinterpret_cast<const float4*>(p.G)[i];
+    float4 m = reinterpret_cast<const float4*>(p.M)[i];
+    float4 v = reinterpret_cast<const float4*>(p.V)[i];
+    float4 w = reinterpret_cast<const float4*>(p.P)[i];
+    g.x *= p.grad_scale; g.y *= p.grad_scale; g.z *= p.grad_scale; g.w *= p.grad_scale;
+    m.x = b1 * m.x + ob1 * g.x; m.y = b1 * m.y + ob1 * g.y; m.z = b1 * m.z + ob1 * g.z; m.w = b1 * m.w + ob1 * g.w;
+    v.x = b2 * v.x + ob2 * g.x * g.x; v.y = b2 * v.y + ob2 * g.y * g.y;
+    v.z = b2 * v.z + ob2 * g.z * g.z; v.w = b2 * v.w + ob2 * g.w * g.w;
+    w.x -= lr_t * m.x / (sqrtf(v.x) + p.eps); w.y -= lr_t * m.y / (sqrtf(v.y) + p.eps);
+    w.z -= lr_t * m.z / (sqrtf(v.z) + p.eps); w.w -= lr_t * m.w / (sqrtf(v.w) + p.eps);
+    reinterpret_cast<float4*>(p.M)[i] = m;
+    reinterpret_cast<float4*>(p.V)[i] = v;
+    reinterpret_cast<float4*>(p.P)[i] = w;
+    if (i * 4 >= p.zero_from) reinterpret_cast<float4*>(p.G)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  finish_step(p, t);
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(const OptimParams p) {
+  const int t = *p.step + 1;
+  const float a = p.lr * p.grad_scale;
+  const long n4 = p.n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 g = reinterpret_cast<const float4*>(p.G)[i];
+    float4 w = reinterpret_cast<const float4*>(p.P)[i];
+    w.x -= a * g.x; w.y -= a * g.y; w.z -= a * g.z; w.w -= a * g.w;
+    reinterpret_cast<float4*>(p.P)[i] = w;
+    if (i * 4 >= p.zero_from) reinterpret_cast<float4*>(p.G)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  finish_step(p, t);
+}
+
+static int optim_grid(long n) {
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;  // memory-bound: cap and grid-stride (guide §6 G11)
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+DTF_API int dtf_adam_tf(const OptimParams* p, hipStream_t st) {
+  if (p->n <= 0 || p->n % 4 || p->zero_from % 4 || !p->step || !p->ticket) return -22;
+  hipLaunchKernelGGL(adam_tf_kernel, dim3(optim_grid(p->n)), dim3(256), 0, st, *p);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+DTF_API int dtf_sgd(const OptimParams* p, hipStream_t st) {
+  if (p->n <= 0 || p->n % 4 || p->zero_from % 4 || !p->step || !p->ticket) return -22;
+  hipLaunchKernelGGL(sgd_kernel, dim3(optim_grid(p->n)), dim3(256), 0, st, *p);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}

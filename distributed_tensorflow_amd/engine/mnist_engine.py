@@ -1,0 +1,381 @@
+"""MNIST CNN training engines.
+
+``NativeMnistEngine`` — the MI355X hot path.  It owns a flat fp32 parameter arena
+(``P``/``G``/``M``/``V``: weights, gradients, Adam slots; TF layouts, arena order =
+gradient-readiness order), the bf16 activation workspaces and a private HIP stream, and
+drives the C++ step executor (``csrc/hip/engine.hip``): 12 kernels + 1 memset per train
+step, replayed as a hipGraph.  Batches are gathered on-device from an HBM-resident
+dataset through a device permutation; loss/accuracy land in a device ring buffer that is
+read back only at logging points (the reference syncs every step, quirk Q5).
+
+``EagerMnistEngine`` — the same interface on plain PyTorch ops (``models.mnist_cnn``):
+CPU plumbing config (BASELINE config 1), the correctness oracle, and the measured
+"PyTorch-ROCm eager" baseline.
+
+Reference: ``demo1/train.py:49-165`` (model, loss, Adam 1e-4, keep_prob 0.7, eval).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import OrderedDict
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import native
+from ..data.mnist import DeviceDataset
+from ..models import mnist_cnn
+from ..optim.adam_tf import adam_tf_flat_
+
+ARENA_ALIGN = 64  # elements (256 B): keeps every segment float4 / cache-line aligned
+
+
+def arena_layout() -> Tuple["OrderedDict[str, Tuple[int, int, tuple]]", int]:
+    """name -> (offset, numel, shape); total padded element count."""
+    off = 0
+    out: "OrderedDict[str, Tuple[int, int, tuple]]" = OrderedDict()
+    for name, (_tf, shape, _k) in mnist_cnn.PARAM_SPECS.items():
+        n = mnist_cnn.numel(shape)
+        out[name] = (off, n, shape)
+        off += (n + ARENA_ALIGN - 1) // ARENA_ALIGN * ARENA_ALIGN
+    return out, off
+
+
+class _EngineBase:
+    double_softmax: bool
+    batch_size: int
+
+    def param_views(self) -> "OrderedDict[str, torch.Tensor]":
+        raise NotImplementedError
+
+    def export_numpy(self) -> Dict[str, np.ndarray]:
+        return {k: v.detach().float().cpu().numpy().copy() for k, v in self.param_views().items()}
+
+
+class NativeMnistEngine(_EngineBase):
+    RING = 1024
+
+    def __init__(self, dataset: Optional[DeviceDataset], *, batch_size: int = 100, lr: float = 1e-4,
+                 keep_prob: float = 0.7, double_softmax: bool = True, seed: Optional[int] = None,
+                 world: int = 1, eval_chunk: int = 5000, use_graph: bool = True,
+                 fc1_splits: int = 14, bwd_splits: int = 4, dw2_splits: int = 32, head_blocks: int = 0,
+                 beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, device="cuda"):
+        if not torch.cuda.is_available():
+            raise native.NativeError("NativeMnistEngine needs a GPU (MI355X); use EagerMnistEngine on CPU")
+        self.lib = native.hip()
+        self.device = torch.device(device)
+        self.dataset = dataset
+        self.batch_size = batch_size
+        self.double_softmax = double_softmax
+        self.world = world
+        self.use_graph = use_graph
+        self.maxB = max(batch_size, eval_chunk)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.layout, self.n_arena = arena_layout()
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.P = torch.zeros(self.n_arena, **f32)
+        self.G = torch.zeros(self.n_arena, **f32)
+        self.M = torch.zeros(self.n_arena, **f32)
+        self.V = torch.zeros(self.n_arena, **f32)
+        self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.metrics_ring = torch.zeros(self.RING * 2, **f32)
+        self.eval_metrics = torch.zeros(2, **f32)
+        mb = self.maxB
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        u8 = dict(dtype=torch.uint8, device=dev)
+        self.ws = {
+            "pool1": torch.zeros(mb * 196 * 32, **bf), "amax1": torch.zeros(mb * 196 * 32, **u8),
+            "pool2": torch.zeros(mb * 49 * 64, **bf), "amax2": torch.zeros(mb * 49 * 64, **u8),
+            "slabs": torch.zeros(max(fc1_splits * batch_size, mb) * 1024, **f32),
+            "h_drop": torch.zeros(batch_size * 1024, **bf), "dh": torch.zeros(batch_size * 1024, **bf),
+            "dz": torch.zeros(batch_size * 16, **bf),
+            "dpool2": torch.zeros(batch_size * 3136, **f32), "dy2": torch.zeros(batch_size * 196 * 64, **bf),
+            "dpool1": torch.zeros(batch_size * 196 * 32, **f32),
+        }
+        self.seed = int(seed if seed is not None else np.random.SeedSequence().entropy % (2 ** 62))
+        self.spe = dataset.steps_per_epoch(batch_size) if dataset is not None else 1
+        self._steps_done = 0  # host mirror of the device step counter
+        s = native.MnistEngineStruct()
+        s.B, s.maxB, s.spe, s.world = batch_size, self.maxB, self.spe, world
+        s.double_softmax = int(double_softmax)
+        s.fc1_splits, s.bwd_splits, s.dw2_splits = fc1_splits, bwd_splits, dw2_splits
+        s.head_blocks = head_blocks if head_blocks > 0 else max(1, (batch_size + 1) // 2)
+        s.ring = self.RING
+        s.lr, s.beta1, s.beta2, s.eps, s.keep_prob = lr, beta1, beta2, eps, keep_prob
+        s.seed = self.seed
+        if dataset is not None:
+            s.images, s.labels, s.perm = dataset.images.data_ptr(), dataset.labels.data_ptr(), dataset.perm.data_ptr()
+        s.P, s.G, s.M, s.V = (t.data_ptr() for t in (self.P, self.G, self.M, self.V))
+        s.n_arena = self.n_arena
+        for field, name in (("off_Wfc1", "W_fc1"), ("off_bfc1", "b_fc1"), ("off_Wfc2", "W_fc2"), ("off_bfc2", "b_fc2"),
+                            ("off_Wc2", "W_conv2"), ("off_bc2", "b_conv2"), ("off_Wc1", "W_conv1"), ("off_bc1", "b_conv1")):
+            setattr(s, field, self.layout[name][0])
+        s.step, s.ticket, s.metrics_ring = self.step_t.data_ptr(), self.ticket.data_ptr(), self.metrics_ring.data_ptr()
+        for k in ("pool1", "amax1", "pool2", "amax2", "slabs", "h_drop", "dh", "dz", "dpool2", "dy2", "dpool1"):
+            setattr(s, k, self.ws[k].data_ptr())
+        self.cfg = s
+        self._graph = None
+        self.init_params(seed)
+
+    # ------------------------------------------------------------------ parameters / state
+    def param_views(self, arena: Optional[torch.Tensor] = None) -> "OrderedDict[str, torch.Tensor]":
+        a = self.P if arena is None else arena
+        return OrderedDict((k, a[o:o + n].view(shape)) for k, (o, n, shape) in self.layout.items())
+
+    def init_params(self, seed: Optional[int] = None) -> None:
+        self.load_params(mnist_cnn.init_params(seed))
+
+    def load_params(self, params: Dict[str, torch.Tensor]) -> None:
+        with torch.cuda.stream(self.stream):
+            for k, v in self.param_views().items():
+                v.copy_(torch.as_tensor(params[k]).to(self.device, torch.float32).reshape(v.shape))
+        self.stream.synchronize()
+
+    def bucket_bounds(self) -> Tuple[Tuple[int, int], Tuple[int, int]]:
+        """Gradient buckets in readiness order: A = fc layers (after part 1), B = conv layers (after part 2)."""
+        split = self.layout["W_conv2"][0]
+        return (0, split), (split, self.n_arena)
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        self.stream.synchronize()
+        return {"P": self.P.clone(), "M": self.M.clone(), "V": self.V.clone(), "step": self.step_t.clone()}
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        with torch.cuda.stream(self.stream):
+            self.P.copy_(sd["P"].to(self.device))
+            self.M.copy_(sd["M"].to(self.device))
+            self.V.copy_(sd["V"].to(self.device))
+            self.step_t.copy_(sd["step"].to(self.device).to(torch.int32))
+        self.stream.synchronize()
+        self._steps_done = int(self.step_t.item())
+
+    @property
+    def global_step(self) -> int:
+        return self._steps_done
+
+    def set_lr(self, lr: float) -> None:
+        self.cfg.lr = lr
+        self._drop_graph()
+
+    def set_world(self, world: int) -> None:
+        self.world = world
+        self.cfg.world = world
+        self._drop_graph()
+
+    def _drop_graph(self) -> None:
+        if self._graph is not None:
+            self.lib.dtf_graph_free(self._graph)
+            self._graph = None
+
+    # ------------------------------------------------------------------ stepping
+    def _maybe_reshuffle(self) -> None:
+        if self.dataset is not None and self._steps_done > 0 and self._steps_done % self.spe == 0:
+            with torch.cuda.stream(self.stream):
+                self.dataset.reshuffle()
+
+    def fwd_bwd(self, parts: int = 3) -> None:
+        native.check(self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), parts, self.stream.cuda_stream), "mnist fwd/bwd")
+
+    def apply(self) -> None:
+        native.check(self.lib.dtf_mnist_apply(C.byref(self.cfg), self.stream.cuda_stream), "mnist apply")
+        self._steps_done += 1
+
+    def _capture(self) -> None:
+        st = self.stream.cuda_stream
+        self.stream.synchronize()
+        native.check(self.lib.dtf_graph_begin(st), "graph begin")
+        rc1 = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 3, st)
+        rc2 = self.lib.dtf_mnist_apply(C.byref(self.cfg), st)
+        h = C.c_void_p()
+        rc3 = self.lib.dtf_graph_end(st, C.byref(h))
+        native.check(rc1 or rc2 or rc3, "graph capture")
+        self._graph = h
+
+    def train_step(self) -> None:
+        """One full step (single-GPU: fwd+bwd+Adam as one hipGraph replay)."""
+        self._maybe_reshuffle()
+        if self.use_graph:
+            if self._graph is None:
+                self._capture()
+            native.check(self.lib.dtf_graph_launch(self._graph, self.stream.cuda_stream), "graph launch")
+            self._steps_done += 1
+        else:
+            self.fwd_bwd(3)
+            self.apply()
+
+    def graph_nodes(self) -> int:
+        return -1 if self._graph is None else self.lib.dtf_graph_num_nodes(self._graph)
+
+    # ------------------------------------------------------------------ metrics / eval
+    def read_metrics(self, first_step: int, last_step: int) -> Tuple[np.ndarray, np.ndarray]:
+        """(loss mean, accuracy) per step for device steps [first_step, last_step) (<= RING steps back)."""
+        self.stream.synchronize()
+        ring = self.metrics_ring.view(self.RING, 2).cpu().numpy()
+        idx = np.arange(first_step, last_step) % self.RING
+        return ring[idx, 0] / self.batch_size, ring[idx, 1] / self.batch_size
+
+    def evaluate(self, images: torch.Tensor, labels: torch.Tensor) -> Tuple[float, float]:
+        """Mean loss and accuracy over a device-resident split (fp32 [N,784], int32 [N]); chunked on device."""
+        n = images.shape[0]
+        with torch.cuda.stream(self.stream):
+            self.eval_metrics.zero_()
+            native.check(self.lib.dtf_mnist_eval(C.byref(self.cfg), images.data_ptr(), labels.data_ptr(), n,
+                                                 self.eval_metrics.data_ptr(), 0, 0, self.stream.cuda_stream), "mnist eval")
+        self.stream.synchronize()
+        m = self.eval_metrics.cpu().numpy()
+        return float(m[0]) / n, float(m[1]) / n
+
+    def predict(self, images: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """softmax probabilities [N,10] and argmax [N] for fp32 [N,784] device images."""
+        images = images.to(self.device, torch.float32).contiguous()
+        n = images.shape[0]
+        probs = torch.empty(n, 10, dtype=torch.float32, device=self.device)
+        pred = torch.empty(n, dtype=torch.int32, device=self.device)
+        labels = torch.zeros(n, dtype=torch.int32, device=self.device)
+        with torch.cuda.stream(self.stream):
+            self.eval_metrics.zero_()
+            native.check(self.lib.dtf_mnist_eval(C.byref(self.cfg), images.data_ptr(), labels.data_ptr(), n,
+                                                 self.eval_metrics.data_ptr(), probs.data_ptr(), pred.data_ptr(),
+                                                 self.stream.cuda_stream), "mnist predict")
+        self.stream.synchronize()
+        return probs, pred
+
+    def __del__(self):
+        try:
+            self._drop_graph()
+        except Exception:
+            pass
+
+
+class EagerMnistEngine(_EngineBase):
+    """Same interface on PyTorch ops (CPU or GPU)."""
+
+    RING = 1024
+
+    def __init__(self, dataset, *, batch_size: int = 100, lr: float = 1e-4, keep_prob: float = 0.7,
+                 double_softmax: bool = True, seed: Optional[int] = None, world: int = 1, device="cpu",
+                 beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, **_unused):
+        self.device = torch.device(device)
+        self.dataset = dataset
+        self.batch_size, self.lr, self.keep_prob = batch_size, lr, keep_prob
+        self.double_softmax, self.world = double_softmax, world
+        self.b1, self.b2, self.eps = beta1, beta2, eps
+        self.layout, self.n_arena = arena_layout()
+        self.P = torch.zeros(self.n_arena, device=self.device)
+        self.G = torch.zeros_like(self.P)
+        self.M = torch.zeros_like(self.P)
+        self.V = torch.zeros_like(self.P)
+        self._steps_done = 0
+        self.spe = dataset.steps_per_epoch(batch_size) if dataset is not None else 1
+        self._ring = np.zeros((self.RING, 2), np.float64)
+        self._gen = torch.Generator(device="cpu")
+        self._gen.manual_seed(seed if seed is not None else int(np.random.SeedSequence().entropy % (2 ** 31)))
+        self.load_params(mnist_cnn.init_params(seed))
+
+    def param_views(self, arena=None):
+        a = self.P if arena is None else arena
+        return OrderedDict((k, a[o:o + n].view(shape)) for k, (o, n, shape) in self.layout.items())
+
+    def load_params(self, params):
+        for k, v in self.param_views().items():
+            v.copy_(torch.as_tensor(params[k]).to(self.device, torch.float32).reshape(v.shape))
+
+    def init_params(self, seed=None):
+        self.load_params(mnist_cnn.init_params(seed))
+
+    def bucket_bounds(self):
+        split = self.layout["W_conv2"][0]
+        return (0, split), (split, self.n_arena)
+
+    def state_dict(self):
+        return {"P": self.P.clone(), "M": self.M.clone(), "V": self.V.clone(),
+                "step": torch.tensor([self._steps_done], dtype=torch.int32)}
+
+    def load_state_dict(self, sd):
+        self.P.copy_(sd["P"].to(self.device))
+        self.M.copy_(sd["M"].to(self.device))
+        self.V.copy_(sd["V"].to(self.device))
+        self._steps_done = int(sd["step"].reshape(-1)[0])
+
+    @property
+    def global_step(self) -> int:
+        return self._steps_done
+
+    def set_lr(self, lr):
+        self.lr = lr
+
+    def set_world(self, world):
+        self.world = world
+
+    def _batch(self):
+        if self._steps_done > 0 and self._steps_done % self.spe == 0:
+            self.dataset.reshuffle()
+        idx = self.dataset.batch_indices(self._steps_done % self.spe, self.batch_size)
+        return self.dataset.gather(idx)
+
+    def fwd_bwd(self, parts: int = 3, batch=None) -> None:
+        if not parts & 1:
+            return  # the eager backward is monolithic: everything happens in part 1
+        x, y = self._batch() if batch is None else batch
+        leaf = self.P.detach().clone().requires_grad_(True)
+        views = self.param_views(leaf)
+        mask = None
+        if self.keep_prob < 1.0:
+            mask = (torch.rand(x.shape[0], 1024, generator=self._gen) < self.keep_prob).float().to(self.device)
+        logits = mnist_cnn.forward_logits(views, x, keep_prob=self.keep_prob, dropout_mask=mask, training=True)
+        loss, pred = mnist_cnn.softmax_xent(logits, y.long(), double_softmax=self.double_softmax)
+        (g,) = torch.autograd.grad(loss, leaf)
+        self.G.copy_(g)
+        slot = self._steps_done % self.RING
+        self._ring[slot, 0] = float(loss) * x.shape[0]
+        self._ring[slot, 1] = float((pred.argmax(1) == y.long()).sum())
+
+    def apply(self) -> None:
+        adam_tf_flat_(self.P, self.G, self.M, self.V, self._steps_done + 1, self.lr, self.b1, self.b2, self.eps,
+                      grad_scale=1.0 / max(1, self.world))
+        self.G.zero_()
+        self._steps_done += 1
+
+    def train_step(self) -> None:
+        self.fwd_bwd(3)
+        self.apply()
+
+    def read_metrics(self, first_step, last_step):
+        idx = np.arange(first_step, last_step) % self.RING
+        return self._ring[idx, 0] / self.batch_size, self._ring[idx, 1] / self.batch_size
+
+    @torch.no_grad()
+    def evaluate(self, images, labels, chunk: int = 5000):
+        n = images.shape[0]
+        loss_sum, correct = 0.0, 0.0
+        views = self.param_views()
+        for s in range(0, n, chunk):
+            x, y = images[s:s + chunk].to(self.device), labels[s:s + chunk].to(self.device).long()
+            logits = mnist_cnn.forward_logits(views, x)
+            loss, pred = mnist_cnn.softmax_xent(logits, y, double_softmax=self.double_softmax)
+            loss_sum += float(loss) * x.shape[0]
+            correct += float((pred.argmax(1) == y).sum())
+        return loss_sum / n, correct / n
+
+    @torch.no_grad()
+    def predict(self, images):
+        logits = mnist_cnn.forward_logits(self.param_views(), images.to(self.device, torch.float32))
+        p = torch.softmax(logits, 1)
+        return p, p.argmax(1).to(torch.int32)
+
+
+def make_engine(kind: str, dataset, **kw):
+    """``auto`` -> native on a GPU, eager otherwise."""
+    if kind == "auto":
+        kind = "native" if torch.cuda.is_available() else "eager"
+    if kind == "native":
+        return NativeMnistEngine(dataset, **kw)
+    if kind == "eager":
+        kw.pop("use_graph", None)
+        kw.pop("eval_chunk", None)
+        return EagerMnistEngine(dataset, **kw)
+    raise ValueError("unknown engine %r" % kind)

@@ -1,0 +1,190 @@
+"""ctypes bindings to the in-tree native libraries.
+
+* ``hip()``  -> ``_lib/libdtf_hip.so``  (gfx950 kernels + step executor; needs a GPU to *run*, loads anywhere ROCm is installed)
+* ``host()`` -> ``_lib/libdtf_host.so`` (CRC32C, tfevents writer, rendezvous store, checkpoint container)
+
+There is deliberately no silent fallback: if a library is missing it is built on the spot
+(hipcc cross-compiles without a GPU) and if that fails the import error is raised — on a GPU
+box the HIP path must be the one that runs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional
+
+_LIBDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
+_lock = threading.Lock()
+_hip: Optional[C.CDLL] = None
+_host: Optional[C.CDLL] = None
+
+c_void_p, c_int, c_long, c_float, c_uint64, c_int64, c_char_p = (
+    C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_int64, C.c_char_p)
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+# ----------------------------------------------------------------------------- struct mirrors (csrc/hip/dtf_structs.h)
+class HeadParams(C.Structure):
+    _fields_ = [
+        ("slabs", c_void_p), ("nslab", c_int), ("slab_stride", c_long),
+        ("b_fc1", c_void_p), ("W_fc2", c_void_p), ("b_fc2", c_void_p),
+        ("labels_all", c_void_p), ("perm", c_void_p), ("step_ptr", c_void_p),
+        ("spe", c_int), ("B", c_int), ("keep_prob", c_float), ("grad_scale", c_float),
+        ("seed", C.c_ulonglong), ("double_softmax", c_int), ("training", c_int),
+        ("h_drop", c_void_p), ("dh", c_void_p), ("dz", c_void_p),
+        ("db_fc2", c_void_p), ("db_fc1", c_void_p), ("metrics", c_void_p), ("metrics_ring", c_int),
+        ("probs", c_void_p), ("pred", c_void_p),
+    ]
+
+
+class OptimParams(C.Structure):
+    _fields_ = [
+        ("P", c_void_p), ("G", c_void_p), ("M", c_void_p), ("V", c_void_p),
+        ("n", c_long), ("zero_from", c_long),
+        ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("grad_scale", c_float),
+        ("step", c_void_p), ("ticket", c_void_p), ("metrics_ring", c_void_p), ("ring", c_int),
+    ]
+
+
+class MnistEngineStruct(C.Structure):  # csrc/hip/engine.hip: struct MnistEngine
+    _fields_ = [
+        ("B", c_int), ("maxB", c_int), ("spe", c_int), ("world", c_int), ("double_softmax", c_int),
+        ("fc1_splits", c_int), ("bwd_splits", c_int), ("dw2_splits", c_int), ("head_blocks", c_int), ("ring", c_int),
+        ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("keep_prob", c_float),
+        ("seed", C.c_ulonglong),
+        ("images", c_void_p), ("labels", c_void_p), ("perm", c_void_p),
+        ("P", c_void_p), ("G", c_void_p), ("M", c_void_p), ("V", c_void_p),
+        ("n_arena", c_long),
+        ("off_Wfc1", c_long), ("off_bfc1", c_long), ("off_Wfc2", c_long), ("off_bfc2", c_long),
+        ("off_Wc2", c_long), ("off_bc2", c_long), ("off_Wc1", c_long), ("off_bc1", c_long),
+        ("step", c_void_p), ("ticket", c_void_p), ("metrics_ring", c_void_p),
+        ("pool1", c_void_p), ("amax1", c_void_p), ("pool2", c_void_p), ("amax2", c_void_p),
+        ("slabs", c_void_p), ("h_drop", c_void_p), ("dh", c_void_p), ("dz", c_void_p),
+        ("dpool2", c_void_p), ("dy2", c_void_p), ("dpool1", c_void_p),
+    ]
+
+
+def _ensure_built(name: str) -> str:
+    path = os.path.join(_LIBDIR, name)
+    if not os.path.exists(path):
+        from . import build
+        (build.build_hip if "hip" in name else build.build_host)()
+    if not os.path.exists(path):
+        raise NativeError("native library %s is missing and could not be built" % path)
+    return path
+
+
+def _sig(lib, name, restype, argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = argtypes
+    return fn
+
+
+def hip() -> C.CDLL:
+    global _hip
+    with _lock:
+        if _hip is not None:
+            return _hip
+        lib = C.CDLL(_ensure_built("libdtf_hip.so"))
+        P, I, L, F = c_void_p, c_int, c_long, c_float
+        _sig(lib, "dtf_version", I, [])
+        _sig(lib, "dtf_fc_fwd", I, [P, I, P, P, I, I, I, I, P, I, P])
+        _sig(lib, "dtf_fc_bwd_data", I, [P, P, P, I, I, I, I, P])
+        _sig(lib, "dtf_fc_dw", I, [P, I, P, P, I, I, I, I, P])
+        _sig(lib, "dtf_conv_bias_relu_pool", I, [P, P, P, P, P, I, I, I, I, I, I, I, P])
+        _sig(lib, "dtf_conv_bwd_data_mask", I, [P, P, P, P, I, I, I, I, I, I, I, P])
+        _sig(lib, "dtf_conv_dw", I, [P, P, P, I, I, I, I, I, I, I, I, P])
+        _sig(lib, "dtf_conv_bias_relu", I, [P, P, P, P] + [I] * 15 + [P])
+        _sig(lib, "dtf_conv1_fwd", I, [P, P, P, I, I, P, P, P, P, P])
+        _sig(lib, "dtf_conv1_dw", I, [P, P, P, I, I, P, P, P, P, P])
+        _sig(lib, "dtf_unpool", I, [P, P, P, P, P, I, I, I, I, P])
+        _sig(lib, "dtf_head", I, [C.POINTER(HeadParams), I, P])
+        _sig(lib, "dtf_adam_tf", I, [C.POINTER(OptimParams), P])
+        _sig(lib, "dtf_sgd", I, [C.POINTER(OptimParams), P])
+        _sig(lib, "dtf_mnist_fwd_bwd", I, [C.POINTER(MnistEngineStruct), I, P])
+        _sig(lib, "dtf_mnist_apply", I, [C.POINTER(MnistEngineStruct), P])
+        _sig(lib, "dtf_mnist_eval", I, [C.POINTER(MnistEngineStruct), P, P, I, P, P, P, P])
+        _sig(lib, "dtf_graph_begin", I, [P])
+        _sig(lib, "dtf_graph_end", I, [P, C.POINTER(c_void_p)])
+        _sig(lib, "dtf_graph_launch", I, [P, P])
+        _sig(lib, "dtf_graph_num_nodes", I, [P])
+        _sig(lib, "dtf_graph_free", None, [P])
+        for extra in _HIP_EXTRA_SIGS:
+            if hasattr(lib, extra[0]):
+                _sig(lib, *extra)
+        _hip = lib
+        return lib
+
+
+# signatures of optional kernels (Inception pools / image ops / stats / retrain head) registered by
+# the modules that own them so this file does not have to know every op
+_HIP_EXTRA_SIGS = []
+
+
+def register_hip_sig(name, restype, argtypes) -> None:
+    _HIP_EXTRA_SIGS.append((name, restype, argtypes))
+    if _hip is not None and hasattr(_hip, name):
+        _sig(_hip, name, restype, argtypes)
+
+
+def host() -> C.CDLL:
+    global _host
+    with _lock:
+        if _host is not None:
+            return _host
+        lib = C.CDLL(_ensure_built("libdtf_host.so"))
+        P, I = c_void_p, c_int
+        _sig(lib, "dtf_crc32c", C.c_uint32, [P, c_uint64])
+        _sig(lib, "dtf_masked_crc32c", C.c_uint32, [P, c_uint64])
+        _sig(lib, "dtf_events_open", P, [c_char_p])
+        _sig(lib, "dtf_events_begin", None, [P, c_int64, C.c_double])
+        _sig(lib, "dtf_events_scalar", None, [P, c_char_p, c_float])
+        _sig(lib, "dtf_events_histogram", None, [P, c_char_p] + [C.c_double] * 5 + [I, P, P])
+        _sig(lib, "dtf_events_end", None, [P])
+        _sig(lib, "dtf_events_graph", None, [P, P, c_uint64])
+        _sig(lib, "dtf_events_flush", None, [P])
+        _sig(lib, "dtf_events_num_records", c_uint64, [P])
+        _sig(lib, "dtf_events_close", None, [P])
+        _sig(lib, "dtf_store_server_start", P, [I])
+        _sig(lib, "dtf_store_server_port", I, [P])
+        _sig(lib, "dtf_store_server_stop", None, [P])
+        _sig(lib, "dtf_store_connect", P, [c_char_p, I, I])
+        _sig(lib, "dtf_store_set", c_int64, [P, c_char_p, P, c_uint64])
+        _sig(lib, "dtf_store_get", c_int64, [P, c_char_p, P, c_uint64, c_int64])
+        _sig(lib, "dtf_store_add", c_int64, [P, c_char_p, c_int64])
+        _sig(lib, "dtf_store_check", c_int64, [P, c_char_p])
+        _sig(lib, "dtf_store_delete", c_int64, [P, c_char_p])
+        _sig(lib, "dtf_store_close", None, [P])
+        _sig(lib, "dtf_ckpt_begin", P, [c_char_p])
+        _sig(lib, "dtf_ckpt_add", I, [P, c_char_p, I, I, P, P, c_uint64])
+        _sig(lib, "dtf_ckpt_finish", I, [P])
+        _sig(lib, "dtf_ckpt_open", P, [c_char_p])
+        _sig(lib, "dtf_ckpt_count", I, [P])
+        _sig(lib, "dtf_ckpt_entry", I, [P, I, P, I, P, P, P, P])
+        _sig(lib, "dtf_ckpt_read", I, [P, I, P])
+        _sig(lib, "dtf_ckpt_close", None, [P])
+        _sig(lib, "dtf_parse_floats", c_int64, [c_char_p, c_uint64, P, c_uint64])
+        _sig(lib, "dtf_format_floats", c_int64, [P, c_uint64, P, c_uint64])
+        _host = lib
+        return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise NativeError("%s failed with code %d%s" % (
+            what, rc, " (shape/alignment precondition violated)" if rc == -22 else ""))
+
+
+def ptr(t) -> int:
+    """Device/host address of a torch tensor (0 for None)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

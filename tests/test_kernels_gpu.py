@@ -1,0 +1,216 @@
+"""Numerics of every HIP kernel vs a plain PyTorch fp32 reference of the same op (GPU only).
+
+bf16 MFMA operands: references round the same operands to bf16 and accumulate in fp32, so the
+tolerances only have to absorb accumulation-order differences.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def r(t):
+    return t.to(torch.bfloat16).float()
+
+
+def relerr(a, b):
+    return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-12))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from distributed_tensorflow_amd.ops import hip_ops
+    return hip_ops
+
+
+def dev():
+    return torch.device("cuda")
+
+
+@pytest.mark.parametrize("M,splits", [(100, 14), (100, 1), (1, 2), (333, 3)])
+def test_fc_forward(ops, M, splits):
+    torch.manual_seed(0)
+    x = bf(torch.randn(M, 3136, device=dev()))
+    w = torch.randn(3136, 1024, device=dev()) * 0.05
+    slabs = ops.fc_forward(x, w, splits=splits)
+    got = slabs.sum(0)
+    ref = x.float() @ r(w)
+    assert relerr(got, ref) < 2e-3
+
+
+def test_fc_forward_f32_bias_relu(ops):
+    torch.manual_seed(1)
+    x = torch.randn(64, 2048, device=dev())
+    w = torch.randn(2048, 6, device=dev()) * 0.05
+    b = torch.randn(6, device=dev())
+    got = ops.fc_forward(x, w, bias=b, relu=True)[0]
+    ref = torch.relu(r(x) @ r(w) + b)
+    assert relerr(got, ref) < 2e-3
+
+
+@pytest.mark.parametrize("splits", [1, 4])
+def test_fc_backward_data(ops, splits):
+    torch.manual_seed(2)
+    dy = bf(torch.randn(100, 1024, device=dev()))
+    w = torch.randn(3136, 1024, device=dev()) * 0.05
+    got = ops.fc_backward_data(dy, w, splits=splits)
+    ref = dy.float() @ r(w).t()
+    assert relerr(got, ref) < 2e-3
+
+
+@pytest.mark.parametrize("M,N,Kb", [(3136, 1024, 100), (1024, 10, 100), (64, 6, 7), (2048, 6, 100)])
+def test_fc_backward_weight(ops, M, N, Kb):
+    torch.manual_seed(3)
+    x = bf(torch.randn(Kb, M, device=dev()))
+    dy = bf(torch.randn(Kb, N, device=dev()))
+    got = ops.fc_backward_weight(x, dy)
+    ref = x.float().t() @ dy.float()
+    assert relerr(got, ref) < 2e-3
+
+
+def _conv1_ref(x, w, b):
+    c = F.conv2d(x.view(-1, 1, 28, 28), w.permute(3, 2, 0, 1), b, padding=2)
+    return c
+
+
+def test_conv1_forward(ops):
+    torch.manual_seed(4)
+    imgs = torch.rand(300, 784, device=dev())
+    idx = torch.randperm(300, device=dev())[:100].to(torch.int32)
+    w = torch.randn(5, 5, 1, 32, device=dev()) * 0.1
+    b = torch.randn(32, device=dev()) * 0.1
+    out, amax = ops.conv1_forward(imgs, w.view(25, 32).contiguous(), b, index=idx)
+    c = _conv1_ref(imgs[idx.long()], w, b)
+    ref = F.max_pool2d(torch.relu(c), 2).permute(0, 2, 3, 1)
+    assert relerr(out, ref) < 1e-2  # bf16 output rounding
+    # argmax points at a maximal element of each window
+    cw = c.permute(0, 2, 3, 1).reshape(100, 14, 2, 14, 2, 32).permute(0, 1, 3, 5, 2, 4).reshape(100, 14, 14, 32, 4)
+    picked = torch.gather(cw, 4, amax.long().unsqueeze(-1)).squeeze(-1)
+    assert torch.allclose(picked, cw.max(-1).values, atol=1e-5)
+
+
+def test_conv1_forward_no_index(ops):
+    torch.manual_seed(5)
+    imgs = torch.rand(7, 784, device=dev())
+    w = torch.randn(5, 5, 1, 32, device=dev()) * 0.1
+    b = torch.zeros(32, device=dev())
+    out, _ = ops.conv1_forward(imgs, w.view(25, 32).contiguous(), b)
+    ref = F.max_pool2d(torch.relu(_conv1_ref(imgs, w, b)), 2).permute(0, 2, 3, 1)
+    assert relerr(out, ref) < 1e-2
+
+
+@pytest.mark.parametrize("B", [100, 3])
+def test_conv2_forward_pool(ops, B):
+    torch.manual_seed(6)
+    x = bf(torch.rand(B, 14, 14, 32, device=dev()))
+    w = torch.randn(5, 5, 32, 64, device=dev()) * 0.05
+    b = torch.randn(64, device=dev()) * 0.1
+    out, amax = ops.conv_bias_relu_pool(x, w.view(800, 64).contiguous(), b, 5, 5)
+    c = F.conv2d(x.float().permute(0, 3, 1, 2), r(w).permute(3, 2, 0, 1), b, padding=2)
+    ref = F.max_pool2d(torch.relu(c), 2).permute(0, 2, 3, 1)
+    assert relerr(out, ref) < 1e-2
+    cw = c.permute(0, 2, 3, 1).reshape(B, 7, 2, 7, 2, 64).permute(0, 1, 3, 5, 2, 4).reshape(B, 7, 7, 64, 4)
+    picked = torch.gather(cw, 4, amax.long().unsqueeze(-1)).squeeze(-1)
+    assert float((picked - cw.max(-1).values).abs().max()) < 2e-2
+
+
+def test_unpool(ops):
+    torch.manual_seed(7)
+    B = 10
+    dpool = torch.randn(B, 7, 7, 64, device=dev())
+    pooled = bf(torch.relu(torch.randn(B, 7, 7, 64, device=dev())))
+    amax = torch.randint(0, 4, (B, 7, 7, 64), device=dev(), dtype=torch.uint8)
+    dy, db = ops.unpool(dpool, pooled, amax)
+    g = dpool * (pooled.float() > 0)
+    ref = torch.zeros(B, 7, 2, 7, 2, 64, device=dev())
+    for s in range(4):
+        ref[:, :, s >> 1, :, s & 1, :] = g * (amax == s)
+    ref = ref.reshape(B, 14, 14, 64)
+    assert relerr(dy, ref) < 1e-2
+    assert relerr(db, g.sum((0, 1, 2))) < 1e-4
+
+
+def test_conv_backward_data_mask(ops):
+    torch.manual_seed(8)
+    B = 20
+    dy = bf(torch.randn(B, 14, 14, 64, device=dev()))
+    w = torch.randn(5, 5, 32, 64, device=dev()) * 0.05
+    mask = bf(torch.relu(torch.randn(B, 14, 14, 32, device=dev())))
+    got = ops.conv_backward_data_mask(dy, w.view(800, 64).contiguous(), mask, 5, 5)
+    x = torch.zeros(B, 32, 14, 14, device=dev(), requires_grad=True)
+    y = F.conv2d(x, r(w).permute(3, 2, 0, 1), padding=2)
+    (gx,) = torch.autograd.grad(y, x, dy.float().permute(0, 3, 1, 2))
+    ref = gx.permute(0, 2, 3, 1) * (mask.float() > 0)
+    assert relerr(got, ref) < 2e-3
+
+
+@pytest.mark.parametrize("B,splits", [(100, 32), (5, 1)])
+def test_conv_backward_weight(ops, B, splits):
+    torch.manual_seed(9)
+    x = bf(torch.rand(B, 14, 14, 32, device=dev()))
+    dy = bf(torch.randn(B, 14, 14, 64, device=dev()))
+    got = ops.conv_backward_weight(x, dy, 5, 5, splits=splits)
+    wt = torch.zeros(64, 32, 5, 5, device=dev(), requires_grad=True)
+    y = F.conv2d(x.float().permute(0, 3, 1, 2), wt, padding=2)
+    (gw,) = torch.autograd.grad(y, wt, dy.float().permute(0, 3, 1, 2))
+    ref = gw.permute(2, 3, 1, 0)
+    assert relerr(got, ref) < 2e-3
+
+
+def test_conv1_backward_weight(ops):
+    torch.manual_seed(10)
+    B = 50
+    imgs = torch.rand(B, 784, device=dev())
+    w = torch.randn(5, 5, 1, 32, device=dev()) * 0.1
+    b = torch.randn(32, device=dev()) * 0.1
+    out, amax = ops.conv1_forward(imgs, w.view(25, 32).contiguous(), b)
+    dpool = torch.randn(B, 14, 14, 32, device=dev()) * (out.float() > 0)
+    dW, db = ops.conv1_backward_weight(imgs, dpool.contiguous(), amax)
+    wt = w.clone().requires_grad_(True)
+    bt = b.clone().requires_grad_(True)
+    ref_out = F.max_pool2d(torch.relu(_conv1_ref(imgs, wt, bt)), 2).permute(0, 2, 3, 1)
+    gw, gb = torch.autograd.grad(ref_out, (wt, bt), dpool)
+    assert relerr(dW.view(5, 5, 1, 32), gw) < 1e-3
+    assert relerr(db, gb) < 1e-3
+
+
+def test_adam_tf(ops):
+    from distributed_tensorflow_amd.optim.adam_tf import adam_tf_flat_
+    torch.manual_seed(11)
+    n = 4096 * 3 + 64
+    P = torch.randn(n, device=dev())
+    M = torch.zeros(n, device=dev())
+    V = torch.zeros(n, device=dev())
+    step = torch.zeros(1, dtype=torch.int32, device=dev())
+    ticket = torch.zeros(1, dtype=torch.int32, device=dev())
+    Pr, Mr, Vr = P.clone(), M.clone(), V.clone()
+    for t in range(1, 4):
+        G = torch.randn(n, device=dev())
+        Gk = G.clone()
+        ops.adam_tf_(P, Gk, M, V, step, ticket, lr=1e-3, grad_scale=0.5, zero_from=1024)
+        adam_tf_flat_(Pr, G, Mr, Vr, t, 1e-3, grad_scale=0.5)
+        torch.cuda.synchronize()
+        assert int(step.item()) == t and int(ticket.item()) == 0
+        assert float(Gk[1024:].abs().max()) == 0.0 and torch.equal(Gk[:1024], G[:1024])
+        assert torch.allclose(P, Pr, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(V, Vr, rtol=1e-5, atol=1e-9)
+
+
+def test_sgd(ops):
+    torch.manual_seed(12)
+    n = 2048 * 5 + 12
+    P = torch.randn(n, device=dev())
+    G = torch.randn(n, device=dev())
+    ref = P - 0.01 * G
+    step = torch.zeros(1, dtype=torch.int32, device=dev())
+    ticket = torch.zeros(1, dtype=torch.int32, device=dev())
+    ops.sgd_(P, G, step, ticket, lr=0.01)
+    torch.cuda.synchronize()
+    assert torch.allclose(P, ref, rtol=1e-6, atol=1e-7) and float(G.abs().max()) == 0.0 and int(step.item()) == 1
