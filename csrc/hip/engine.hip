@@ -49,9 +49,9 @@ static int forward_to_slabs(const MnistEngine* e, const float* images, const int
   return 0;
 }
 
-static int effective_splits(int K, int splits) {
-  const int ksteps = (K + 31) / 32;
-  const int kchunk = ((ksteps + splits - 1) / splits) * 32;
+static int effective_splits(int K, int splits, int BK = 64) {  // mirrors base_params() in gemm_api.hip
+  const int ksteps = (K + BK - 1) / BK;
+  const int kchunk = ((ksteps + splits - 1) / splits) * BK;
   return (K + kchunk - 1) / kchunk;
 }
 

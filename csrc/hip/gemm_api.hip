@@ -7,12 +7,12 @@ namespace {
 constexpr int ERR_SHAPE = -22;
 
 inline GemmParams base_params(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb,
-                              long ldc, int splits) {
+                              long ldc, int splits, int BK) {
   GemmParams p{};
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-  const int ksteps = dtf_cdiv(K, kBK);
-  p.kchunk = dtf_cdiv(ksteps, splits) * kBK;
+  const int ksteps = dtf_cdiv(K, BK);
+  p.kchunk = dtf_cdiv(ksteps, splits) * BK;
   p.slab_stride = (long)M * ldc;
   return p;
 }
@@ -24,40 +24,40 @@ inline int eff_splits(const GemmParams& p) { return dtf_cdiv(p.K, p.kchunk); }
 DTF_API int dtf_fc_fwd(const void* X, int x_is_f32, const float* W, float* out, int M, int N, int K, int splits,
                        const float* bias, int relu, hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0 || K % 8 || N % 2 || splits < 1) return ERR_SHAPE;
-  GemmParams p = base_params(X, W, out, M, N, K, K, N, N, splits);
+  GemmParams p = base_params(X, W, out, M, N, K, K, N, N, splits, 64);
   const int s = eff_splits(p);
   p.bias = (s == 1) ? bias : nullptr;
   p.relu = (s == 1) ? relu : 0;
   if (x_is_f32)
-    return dtf_launch_gemm<128, 64, 4, 1, LoadRowK<float, 128, 256, true>, LoadColK<float, 64, 256, false>, EpStoreF32>(p, s, st);
-  return dtf_launch_gemm<128, 64, 4, 1, LoadRowK<uint16_t, 128, 256, true>, LoadColK<float, 64, 256, false>, EpStoreF32>(p, s, st);
+    return dtf_launch_gemm<128, 64, 64, 4, 1, LoadRowK<float, 128, 256, 64, true>, LoadColK<float, 64, 256, 64, false>, EpStoreF32>(p, s, st);
+  return dtf_launch_gemm<128, 64, 64, 4, 1, LoadRowK<uint16_t, 128, 256, 64, true>, LoadColK<float, 64, 256, 64, false>, EpStoreF32>(p, s, st);
 }
 
 // dX[M][N] (fp32) (+)= dY[M][K] (bf16) * W[N][K]^T with W fp32 [N][K] (TF [in,out] layout seen from the input side).
 // splits > 1 accumulates with fp32 atomics into a pre-zeroed dX.
 DTF_API int dtf_fc_bwd_data(const void* dY, const float* W, float* dX, int M, int N, int K, int splits, hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0 || K % 8 || splits < 1) return ERR_SHAPE;
-  GemmParams p = base_params(dY, W, dX, M, N, K, K, K, N, splits);
+  GemmParams p = base_params(dY, W, dX, M, N, K, K, K, N, splits, 64);
   const int s = eff_splits(p);
   if (s == 1)
-    return dtf_launch_gemm<128, 64, 4, 1, LoadRowK<uint16_t, 128, 256, true>, LoadRowK<float, 64, 256, false>, EpStoreF32>(p, 1, st);
-  return dtf_launch_gemm<128, 64, 4, 1, LoadRowK<uint16_t, 128, 256, true>, LoadRowK<float, 64, 256, false>, EpAtomicF32>(p, s, st);
+    return dtf_launch_gemm<128, 64, 64, 4, 1, LoadRowK<uint16_t, 128, 256, 64, true>, LoadRowK<float, 64, 256, 64, false>, EpStoreF32>(p, 1, st);
+  return dtf_launch_gemm<128, 64, 64, 4, 1, LoadRowK<uint16_t, 128, 256, 64, true>, LoadRowK<float, 64, 256, 64, false>, EpAtomicF32>(p, s, st);
 }
 
 // dW[M][N] (fp32) = X[K][M]^T * dY[K][N]   (both bf16 row-major [batch][features]; K = batch)
 // splits > 1 accumulates atomically into a pre-zeroed dW.
 DTF_API int dtf_fc_dw(const void* X, int x_is_f32, const void* dY, float* dW, int M, int N, int K, int splits, hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0 || M % 2 || N % 2 || splits < 1) return ERR_SHAPE;
-  GemmParams p = base_params(X, dY, dW, M, N, K, M, N, N, splits);
+  GemmParams p = base_params(X, dY, dW, M, N, K, M, N, N, splits, 128);
   const int s = eff_splits(p);
   if (x_is_f32) {
     if (s == 1)
-      return dtf_launch_gemm<128, 64, 4, 1, LoadColK<float, 128, 256, true>, LoadColK<uint16_t, 64, 256, false>, EpStoreF32>(p, 1, st);
-    return dtf_launch_gemm<128, 64, 4, 1, LoadColK<float, 128, 256, true>, LoadColK<uint16_t, 64, 256, false>, EpAtomicF32>(p, s, st);
+      return dtf_launch_gemm<128, 64, 128, 4, 1, LoadColK<float, 128, 256, 128, true>, LoadColK<uint16_t, 64, 256, 128, false>, EpStoreF32>(p, 1, st);
+    return dtf_launch_gemm<128, 64, 128, 4, 1, LoadColK<float, 128, 256, 128, true>, LoadColK<uint16_t, 64, 256, 128, false>, EpAtomicF32>(p, s, st);
   }
   if (s == 1)
-    return dtf_launch_gemm<128, 64, 4, 1, LoadColK<uint16_t, 128, 256, true>, LoadColK<uint16_t, 64, 256, false>, EpStoreF32>(p, 1, st);
-  return dtf_launch_gemm<128, 64, 4, 1, LoadColK<uint16_t, 128, 256, true>, LoadColK<uint16_t, 64, 256, false>, EpAtomicF32>(p, s, st);
+    return dtf_launch_gemm<128, 64, 128, 4, 1, LoadColK<uint16_t, 128, 256, 128, true>, LoadColK<uint16_t, 64, 256, 128, false>, EpStoreF32>(p, 1, st);
+  return dtf_launch_gemm<128, 64, 128, 4, 1, LoadColK<uint16_t, 128, 256, 128, true>, LoadColK<uint16_t, 64, 256, 128, false>, EpAtomicF32>(p, s, st);
 }
 
 static inline int fill_geom(GemmParams& p, int H, int W, int Cin, int cstride, int Ho, int Wo, int KH, int KW,
@@ -74,11 +74,11 @@ DTF_API int dtf_conv_bias_relu_pool(const void* x, const float* Wt, const float*
                                     int B, int H, int W, int Cin, int Cout, int KH, int KW, hipStream_t st) {
   if (B <= 0 || H % 2 || W % 2 || Cout % 2) return ERR_SHAPE;
   const int M = B * H * W, K = KH * KW * Cin;
-  GemmParams p = base_params(x, Wt, out, M, Cout, K, 0, Cout, Cout, 1);
+  GemmParams p = base_params(x, Wt, out, M, Cout, K, 0, Cout, Cout, 1, 128);
   if (fill_geom(p, H, W, Cin, Cin, H, W, KH, KW, 1, (KH - 1) / 2, (KW - 1) / 2)) return ERR_SHAPE;
   p.bias = bias;
   p.aux_out = argmax;
-  return dtf_launch_gemm<64, 64, 2, 2, LoadConvA<64, 256, 1>, LoadColK<float, 64, 256, false>, EpBiasReluPool>(p, 1, st);
+  return dtf_launch_gemm<64, 64, 128, 2, 2, LoadConvA<64, 256, 128, 1>, LoadColK<float, 64, 256, 128, false>, EpBiasReluPool>(p, 1, st);
 }
 
 // Conv backward-data (stride 1, SAME) fused with the ReLU mask of the producing layer's pooled output:
@@ -88,10 +88,10 @@ DTF_API int dtf_conv_bwd_data_mask(const void* dY, const float* Wt, const void* 
                                    int Cin, int Cout, int KH, int KW, hipStream_t st) {
   if (B <= 0 || Cout % 8 || mask == nullptr) return ERR_SHAPE;
   const int M = B * H * W, K = KH * KW * Cout;
-  GemmParams p = base_params(dY, Wt, dX, M, Cin, K, 0, 0, Cin, 1);
+  GemmParams p = base_params(dY, Wt, dX, M, Cin, K, 0, 0, Cin, 1, 128);
   if (fill_geom(p, H, W, Cout, Cout, H, W, KH, KW, 1, (KH - 1) / 2, (KW - 1) / 2)) return ERR_SHAPE;
   p.aux_in = mask;
-  return dtf_launch_gemm<64, 32, 2, 1, LoadConvA<64, 128, 0>, LoadConvWBwd<32, 128>, EpMaskMulF32>(p, 1, st);
+  return dtf_launch_gemm<64, 32, 128, 2, 1, LoadConvA<64, 128, 128, 0>, LoadConvWBwd<32, 128, 128>, EpMaskMulF32>(p, 1, st);
 }
 
 // Conv filter gradient: dW[tap][ci][co] (fp32 HWIO, pre-zeroed, atomics) += sum_pos X[pos+tap][ci] * dY[pos][co]
@@ -100,9 +100,9 @@ DTF_API int dtf_conv_dw(const void* x, const void* dY, float* dW, int B, int H, 
                         int KW, int splits, hipStream_t st) {
   if (B <= 0 || Cin % 2 || Cout % 2 || splits < 1) return ERR_SHAPE;
   const int M = KH * KW * Cin, K = B * H * W;
-  GemmParams p = base_params(x, dY, dW, M, Cout, K, 0, Cout, Cout, splits);
+  GemmParams p = base_params(x, dY, dW, M, Cout, K, 0, Cout, Cout, splits, 64);
   if (fill_geom(p, H, W, Cin, Cin, H, W, KH, KW, 1, (KH - 1) / 2, (KW - 1) / 2)) return ERR_SHAPE;
-  return dtf_launch_gemm<128, 64, 4, 1, LoadConvDwA<128, 256>, LoadColK<uint16_t, 64, 256, false>, EpAtomicF32>(p, eff_splits(p), st);
+  return dtf_launch_gemm<128, 64, 64, 4, 1, LoadConvDwA<128, 256, 64>, LoadColK<uint16_t, 64, 256, 64, false>, EpAtomicF32>(p, eff_splits(p), st);
 }
 
 // General inference conv for the Inception-v3 backbone: x bf16 NHWC (channel stride in_cstride, so the
@@ -113,13 +113,13 @@ DTF_API int dtf_conv_bias_relu(const void* x, const void* Wp, const float* bias,
                                int pad_h, int pad_w, int Ho, int Wo, int relu, hipStream_t st) {
   if (B <= 0 || Cout <= 0) return ERR_SHAPE;
   const int M = B * Ho * Wo, K = KH * KW * Cin;
-  GemmParams p = base_params(x, Wp, out, M, Cout, K, 0, K, out_cstride, 1);
+  GemmParams p = base_params(x, Wp, out, M, Cout, K, 0, K, out_cstride, 1, 64);
   if (fill_geom(p, H, W, Cin, in_cstride, Ho, Wo, KH, KW, stride, pad_h, pad_w)) return ERR_SHAPE;
   p.bias = bias;
   p.relu = relu;
   if (Cout <= 32)
-    return dtf_launch_gemm<128, 32, 4, 1, LoadConvA<128, 256, 0>, LoadRowK<uint16_t, 32, 256, false>, EpBiasReluBf16>(p, 1, st);
+    return dtf_launch_gemm<128, 32, 64, 4, 1, LoadConvA<128, 256, 64, 0>, LoadRowK<uint16_t, 32, 256, 64, false>, EpBiasReluBf16>(p, 1, st);
   if (M <= 256 * 64)
-    return dtf_launch_gemm<64, 64, 2, 2, LoadConvA<64, 256, 0>, LoadRowK<uint16_t, 64, 256, false>, EpBiasReluBf16>(p, 1, st);
-  return dtf_launch_gemm<128, 64, 4, 1, LoadConvA<128, 256, 0>, LoadRowK<uint16_t, 64, 256, false>, EpBiasReluBf16>(p, 1, st);
+    return dtf_launch_gemm<64, 64, 64, 2, 2, LoadConvA<64, 256, 64, 0>, LoadRowK<uint16_t, 64, 256, 64, false>, EpBiasReluBf16>(p, 1, st);
+  return dtf_launch_gemm<128, 64, 64, 4, 1, LoadConvA<128, 256, 64, 0>, LoadRowK<uint16_t, 64, 256, 64, false>, EpBiasReluBf16>(p, 1, st);
 }

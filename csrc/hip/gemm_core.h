@@ -2,7 +2,7 @@
 //
 //   C[M,N] (+)= A[M,K] * B[N,K]^T      fp32 accumulate, bf16 MFMA operands
 //
-// One templated kernel; the operand *loaders* decide where a [rows x 32] K-slab comes from
+// One templated kernel; the operand *loaders* decide where a [rows x BK] K-slab comes from
 // (row-major, column-major with an in-register transpose, NHWC conv gather, conv-weight views)
 // and the *epilogues* decide what happens to the 32x32 accumulator fragments (split-K slabs,
 // fp32 atomics, bias+ReLU bf16 store into a concat slice, bias+ReLU+2x2 max-pool, masking).
@@ -10,19 +10,22 @@
 // directly and no bf16 shadow copy of the parameters has to be maintained by the optimizer.
 //
 // Tiling: workgroup = WM x WN waves (64 lanes each); each wave owns TM x TN MFMA tiles of 32x32.
-// LDS tiles are [rows][32 k] bf16 with an 80-byte row stride: 16-byte aligned for ds_read_b128 and
-// conflict-free for the 16-lane groups of that instruction (20 dwords/row -> rows hit distinct
-// 4-bank slots mod 64).  Register prefetch: the global loads of K-slab t+1 are in flight while the
-// MFMAs of slab t run.
+// LDS tiles are [rows][BK] bf16 with a (BK+8)*2-byte row stride: 16-byte aligned for ds_read_b128
+// and conflict-free for the 16-lane groups of that instruction (row stride = 4 dwords mod 64 for
+// BK = 128/256, 36 for BK = 64, 20 for BK = 32 -> rows hit distinct 4-bank slots).
+//
+// Latency structure (these GEMMs are small: one wave of workgroups, so kernel time == one
+// workgroup's dependent chain): every global load of a K-slab is issued back to back from clamped
+// addresses (no predicated loads: hipcc would branch around each and drain vmcnt per element,
+// cdna_hip_programming.md §5 trap (c)), raw data stays in registers while the MFMAs of the previous
+// slab run, and conversion/masking happens at LDS-store time.  BK is a template knob: a larger slab
+// means fewer barrier + round-trip episodes on the chain.
 //
 // Fragment maps (cdna_hip_programming.md §3): lane l, r=l&31, h=l>>5:
 //   A frag = A[row r][k = 8h..8h+7], B frag = B[k = 8h..8h+7][col r],
 //   C/D reg i -> row (i&3) + 8*(i>>2) + 4h, col r.
 #pragma once
 #include "common.h"
-
-constexpr int kBK = 32;         // K elements per staged slab
-constexpr int kLdsStride = 40;  // bf16 elements per LDS row (32 + 8 pad = 80 bytes)
 
 struct ConvGeom {
   int H, W, Cin, cstride;  // gathered NHWC tensor: spatial dims, channels taken per tap, channel stride
@@ -35,7 +38,7 @@ struct GemmParams {
   void* C;
   int M, N, K;
   long lda, ldb, ldc;
-  int kchunk;        // K elements per blockIdx.z slice (multiple of 32)
+  int kchunk;        // K elements per blockIdx.z slice (multiple of the kernel's BK)
   long slab_stride;  // elements between split-K slabs
   const float* bias;
   int relu;
@@ -44,65 +47,71 @@ struct GemmParams {
   ConvGeom g;
 };
 
-// ------------------------------------------------------------------ element loads
+// ------------------------------------------------------------------ raw element loads (convert later)
 template <typename T>
-struct Ld8;
+struct Raw8;  // 8 consecutive elements
 template <>
-struct Ld8<uint16_t> {  // bf16 bits
-  static __device__ __forceinline__ uint4 ld(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+struct Raw8<uint16_t> {  // bf16 bits
+  uint4 v;
+  __device__ __forceinline__ void ld(const uint16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ uint4 bf() const { return v; }
 };
 template <>
-struct Ld8<float> {
-  static __device__ __forceinline__ uint4 ld(const float* p) {
-    const float4 a = reinterpret_cast<const float4*>(p)[0];
-    const float4 b = reinterpret_cast<const float4*>(p)[1];
+struct Raw8<float> {
+  float4 a, b;
+  __device__ __forceinline__ void ld(const float* p) {
+    a = reinterpret_cast<const float4*>(p)[0];
+    b = reinterpret_cast<const float4*>(p)[1];
+  }
+  __device__ __forceinline__ uint4 bf() const {
     return make_uint4(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w), pack_bf2(b.x, b.y), pack_bf2(b.z, b.w));
   }
 };
 template <typename T>
-struct Ld2;  // two adjacent elements -> two bf16 bit patterns
+struct Raw2;  // two adjacent elements
 template <>
-struct Ld2<uint16_t> {
-  static __device__ __forceinline__ void ld(const uint16_t* p, uint32_t& e0, uint32_t& e1) {
-    const uint32_t v = *reinterpret_cast<const uint32_t*>(p);
-    e0 = v & 0xffffu;
-    e1 = v >> 16;
-  }
+struct Raw2<uint16_t> {
+  uint32_t v;
+  __device__ __forceinline__ void ld(const uint16_t* p) { v = *reinterpret_cast<const uint32_t*>(p); }
+  __device__ __forceinline__ uint32_t e0() const { return v & 0xffffu; }
+  __device__ __forceinline__ uint32_t e1() const { return v >> 16; }
 };
 template <>
-struct Ld2<float> {
-  static __device__ __forceinline__ void ld(const float* p, uint32_t& e0, uint32_t& e1) {
-    const float2 v = *reinterpret_cast<const float2*>(p);
-    e0 = f2bf(v.x);
-    e1 = f2bf(v.y);
-  }
+struct Raw2<float> {
+  float2 v;
+  __device__ __forceinline__ void ld(const float* p) { v = *reinterpret_cast<const float2*>(p); }
+  __device__ __forceinline__ uint32_t e0() const { return f2bf(v.x); }
+  __device__ __forceinline__ uint32_t e1() const { return f2bf(v.y); }
 };
 
 // ------------------------------------------------------------------ loaders
-// Every loader: init(p, r0, tid) / load(k0, kend, tid) -> registers / store(lds, tid) -> LDS [R][40].
+// Every loader: init(p, r0, tid) / load(k0, kend, tid) -> raw registers / store(lds, tid) -> LDS [R][BK+8].
+#define DTF_LDS_STRIDE (BK + 8)
 
 // src[row*ld + k]   (k contiguous); needs ld % 8 == 0 (bf16) or % 4 == 0 (fp32), K % 8 == 0
-template <typename T, int R, int NT, bool IS_A>
+template <typename T, int R, int NT, int BK, bool IS_A>
 struct LoadRowK {
-  static constexpr int NCHUNK = R * 4;
-  static constexpr int PER = (NCHUNK + NT - 1) / NT;
-  uint4 regs[PER];
+  static constexpr int CPR = BK / 8, NCHUNK = R * CPR, PER = (NCHUNK + NT - 1) / NT;
+  Raw8<T> regs[PER];
   const T* src;
   long ld;
-  int rows, r0;
+  int rows, r0, k0, kend;
   __device__ __forceinline__ void init(const GemmParams& p, int r0_, int) {
     src = reinterpret_cast<const T*>(IS_A ? p.A : p.B);
     ld = IS_A ? p.lda : p.ldb;
     rows = IS_A ? p.M : p.N;
     r0 = r0_;
   }
-  __device__ __forceinline__ void load(int k0, int kend, int tid) {
+  __device__ __forceinline__ bool ok(int c) const {
+    return (NCHUNK % NT == 0 || c < NCHUNK) && (r0 + c / CPR) < rows && (k0 + (c % CPR) * 8) < kend;
+  }
+  __device__ __forceinline__ void load(int k0_, int kend_, int tid) {
+    k0 = k0_;
+    kend = kend_;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int c = tid + NT * i;
-      const int row = c >> 2, k = k0 + (c & 3) * 8;
-      const bool ok = (NCHUNK % NT == 0 || c < NCHUNK) && (r0 + row) < rows && k < kend;
-      regs[i] = ok ? Ld8<T>::ld(src + (long)(r0 + row) * ld + k) : make_uint4(0, 0, 0, 0);
+      regs[i].ld(src + (ok(c) ? (long)(r0 + c / CPR) * ld + k0 + (c % CPR) * 8 : 0L));
     }
   }
   __device__ __forceinline__ void store(uint16_t* lds, int tid) const {
@@ -110,27 +119,28 @@ struct LoadRowK {
     for (int i = 0; i < PER; ++i) {
       const int c = tid + NT * i;
       if (NCHUNK % NT == 0 || c < NCHUNK)
-        *reinterpret_cast<uint4*>(lds + (c >> 2) * kLdsStride + (c & 3) * 8) = regs[i];
+        *reinterpret_cast<uint4*>(lds + (c / CPR) * DTF_LDS_STRIDE + (c % CPR) * 8) = ok(c) ? regs[i].bf() : make_uint4(0, 0, 0, 0);
     }
   }
 };
 
 // src[k*ld + row]   (row contiguous): transposed in registers while staging.  rows, ld even.
-template <typename T, int R, int NT, bool IS_A>
+template <typename T, int R, int NT, int BK, bool IS_A>
 struct LoadColK {
-  static constexpr int NTASK = (R / 2) * 4;
-  static constexpr int PER = (NTASK + NT - 1) / NT;
-  uint32_t lo[PER][4], hi[PER][4];
+  static constexpr int CPR = BK / 8, NTASK = (R / 2) * CPR, PER = (NTASK + NT - 1) / NT;
+  Raw2<T> regs[PER][8];
   const T* src;
   long ld;
-  int rows, r0;
+  int rows, r0, k0, kend;
   __device__ __forceinline__ void init(const GemmParams& p, int r0_, int) {
     src = reinterpret_cast<const T*>(IS_A ? p.A : p.B);
     ld = IS_A ? p.lda : p.ldb;
     rows = IS_A ? p.M : p.N;
     r0 = r0_;
   }
-  __device__ __forceinline__ void load(int k0, int kend, int tid) {
+  __device__ __forceinline__ void load(int k0_, int kend_, int tid) {
+    k0 = k0_;
+    kend = kend_;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int t = tid + NT * i;
@@ -138,14 +148,9 @@ struct LoadColK {
       const int row = r0 + 2 * rp;
       const bool okr = (NTASK % NT == 0 || t < NTASK) && row < rows;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { lo[i][q] = 0; hi[i][q] = 0; }
-#pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int k = k0 + kc * 8 + j;
-        uint32_t e0 = 0, e1 = 0;
-        if (okr && k < kend) Ld2<T>::ld(src + (long)k * ld + row, e0, e1);
-        lo[i][j >> 1] |= e0 << ((j & 1) * 16);
-        hi[i][j >> 1] |= e1 << ((j & 1) * 16);
+        regs[i][j].ld(src + ((okr && k < kend) ? (long)k * ld + row : 0L));
       }
     }
   }
@@ -155,8 +160,16 @@ struct LoadColK {
       const int t = tid + NT * i;
       if (NTASK % NT == 0 || t < NTASK) {
         const int rp = t % (R / 2), kc = t / (R / 2);
-        *reinterpret_cast<uint4*>(lds + (2 * rp) * kLdsStride + kc * 8) = make_uint4(lo[i][0], lo[i][1], lo[i][2], lo[i][3]);
-        *reinterpret_cast<uint4*>(lds + (2 * rp + 1) * kLdsStride + kc * 8) = make_uint4(hi[i][0], hi[i][1], hi[i][2], hi[i][3]);
+        const bool okr = (r0 + 2 * rp) < rows;
+        uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool ok = okr && (k0 + kc * 8 + j) < kend;
+          lo[j >> 1] |= (ok ? regs[i][j].e0() : 0u) << ((j & 1) * 16);
+          hi[j >> 1] |= (ok ? regs[i][j].e1() : 0u) << ((j & 1) * 16);
+        }
+        *reinterpret_cast<uint4*>(lds + (2 * rp) * DTF_LDS_STRIDE + kc * 8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        *reinterpret_cast<uint4*>(lds + (2 * rp + 1) * DTF_LDS_STRIDE + kc * 8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
       }
     }
   }
@@ -165,12 +178,12 @@ struct LoadColK {
 // Implicit-GEMM activation gather: row m = output position, k = (tap, channel) of a bf16 NHWC tensor.
 // ORDER 0: m = (b, ho, wo).  ORDER 1: m = 4*window + sub over 2x2 pooling windows, so the four
 // members of a window land in one lane's consecutive accumulator registers (fused max-pool).
-template <int R, int NT, int ORDER>
+template <int R, int NT, int BK, int ORDER>
 struct LoadConvA {
-  static_assert(NT % 4 == 0, "NT");
-  static constexpr int NCHUNK = R * 4;
-  static constexpr int PER = (NCHUNK + NT - 1) / NT;
+  static constexpr int CPR = BK / 8, NCHUNK = R * CPR, PER = (NCHUNK + NT - 1) / NT;
+  static_assert(NT % CPR == 0, "every thread keeps one k-chunk column");
   uint4 regs[PER];
+  unsigned okbits;
   const uint16_t* src;
   int img[PER], hi0[PER], wi0[PER];
   bool okr[PER];
@@ -181,7 +194,7 @@ struct LoadConvA {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int c = tid + NT * i;
-      const int m = m0 + (c >> 2);
+      const int m = m0 + c / CPR;
       okr[i] = (NCHUNK % NT == 0 || c < NCHUNK) && m < p.M;
       int b, ho, wo;
       if (ORDER == 0) {
@@ -204,15 +217,16 @@ struct LoadConvA {
     }
   }
   __device__ __forceinline__ void load(int k0, int kend, int tid) {
-    const int kk = k0 + (tid & 3) * 8;
+    const int kk = k0 + (tid % CPR) * 8;
     const int tap = kk / g.Cin, ci = kk - tap * g.Cin;
     const int dy = tap / g.KW, dx = tap - dy * g.KW;
+    okbits = 0;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int hi = hi0[i] + dy, wi = wi0[i] + dx;
       const bool ok = okr[i] && kk < kend && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-      regs[i] = ok ? *reinterpret_cast<const uint4*>(src + ((long)(img[i] * g.H + hi) * g.W + wi) * g.cstride + ci)
-                   : make_uint4(0, 0, 0, 0);
+      okbits |= (ok ? 1u : 0u) << i;
+      regs[i] = *reinterpret_cast<const uint4*>(src + (ok ? ((long)(img[i] * g.H + hi) * g.W + wi) * g.cstride + ci : 0L));
     }
   }
   __device__ __forceinline__ void store(uint16_t* lds, int tid) const {
@@ -220,7 +234,8 @@ struct LoadConvA {
     for (int i = 0; i < PER; ++i) {
       const int c = tid + NT * i;
       if (NCHUNK % NT == 0 || c < NCHUNK)
-        *reinterpret_cast<uint4*>(lds + (c >> 2) * kLdsStride + (c & 3) * 8) = regs[i];
+        *reinterpret_cast<uint4*>(lds + (c / CPR) * DTF_LDS_STRIDE + (c % CPR) * 8) =
+            ((okbits >> i) & 1u) ? regs[i] : make_uint4(0, 0, 0, 0);
     }
   }
 };
@@ -228,13 +243,12 @@ struct LoadConvA {
 // Backward-data weight view of an fp32 HWIO filter W[tap][n=cin][kc=cout]:
 //   B[n][k = (tap', cout)] = W[(KH*KW-1) - tap'][n][cout]      (taps flipped, k contiguous)
 // g.Cin holds the channels per tap of the gathered tensor (= cout of the forward conv).
-template <int R, int NT>
+template <int R, int NT, int BK>
 struct LoadConvWBwd {
-  static constexpr int NCHUNK = R * 4;
-  static constexpr int PER = (NCHUNK + NT - 1) / NT;
-  uint4 regs[PER];
+  static constexpr int CPR = BK / 8, NCHUNK = R * CPR, PER = (NCHUNK + NT - 1) / NT;
+  Raw8<float> regs[PER];
   const float* src;
-  int rows, r0, kc_per_tap, ntaps;
+  int rows, r0, kc_per_tap, ntaps, k0, kend;
   __device__ __forceinline__ void init(const GemmParams& p, int r0_, int) {
     src = reinterpret_cast<const float*>(p.B);
     rows = p.N;
@@ -242,15 +256,19 @@ struct LoadConvWBwd {
     kc_per_tap = p.g.Cin;
     ntaps = p.g.KH * p.g.KW;
   }
-  __device__ __forceinline__ void load(int k0, int kend, int tid) {
+  __device__ __forceinline__ bool ok(int c) const {
+    return (NCHUNK % NT == 0 || c < NCHUNK) && (r0 + c / CPR) < rows && (k0 + (c % CPR) * 8) < kend;
+  }
+  __device__ __forceinline__ void load(int k0_, int kend_, int tid) {
+    k0 = k0_;
+    kend = kend_;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int c = tid + NT * i;
-      const int row = c >> 2, kk = k0 + (c & 3) * 8;
+      const int row = c / CPR, kk = k0 + (c % CPR) * 8;
       const int tapp = kk / kc_per_tap, co = kk - tapp * kc_per_tap;
       const int tap = ntaps - 1 - tapp;
-      const bool ok = (NCHUNK % NT == 0 || c < NCHUNK) && (r0 + row) < rows && kk < kend;
-      regs[i] = ok ? Ld8<float>::ld(src + ((long)tap * rows + (r0 + row)) * kc_per_tap + co) : make_uint4(0, 0, 0, 0);
+      regs[i].ld(src + (ok(c) ? ((long)tap * rows + (r0 + row)) * kc_per_tap + co : 0L));
     }
   }
   __device__ __forceinline__ void store(uint16_t* lds, int tid) const {
@@ -258,18 +276,18 @@ struct LoadConvWBwd {
     for (int i = 0; i < PER; ++i) {
       const int c = tid + NT * i;
       if (NCHUNK % NT == 0 || c < NCHUNK)
-        *reinterpret_cast<uint4*>(lds + (c >> 2) * kLdsStride + (c & 3) * 8) = regs[i];
+        *reinterpret_cast<uint4*>(lds + (c / CPR) * DTF_LDS_STRIDE + (c % CPR) * 8) = ok(c) ? regs[i].bf() : make_uint4(0, 0, 0, 0);
     }
   }
 };
 
 // Filter-gradient activation gather (transposing): row r = (tap, cin), k = output position (b,y,x):
 //   A[r][k] = X[b, y*stride + dy - pad, x*stride + dx - pad, cin]     (bf16 NHWC, Cin even)
-template <int R, int NT>
+template <int R, int NT, int BK>
 struct LoadConvDwA {
-  static constexpr int NTASK = (R / 2) * 4;
-  static constexpr int PER = (NTASK + NT - 1) / NT;
-  uint32_t lo[PER][4], hi[PER][4];
+  static constexpr int CPR = BK / 8, NTASK = (R / 2) * CPR, PER = (NTASK + NT - 1) / NT;
+  uint32_t regs[PER][8];
+  unsigned okbits[PER];
   const uint16_t* src;
   int dy[PER], dx[PER], ci[PER];
   bool okr[PER];
@@ -295,19 +313,17 @@ struct LoadConvDwA {
     for (int i = 0; i < PER; ++i) {
       const int t = tid + NT * i;
       const int kc = t / (R / 2);
-      int pos = k0 + kc * 8;
-      int b = pos / npos, rem = pos - b * npos;
+      const int pos = k0 + kc * 8;
+      int b = pos / npos;
+      const int rem = pos - b * npos;
       int y = rem / g.Wo, x = rem - y * g.Wo;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { lo[i][q] = 0; hi[i][q] = 0; }
+      okbits[i] = 0;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int hi_ = y * g.stride + dy[i], wi_ = x * g.stride + dx[i];
-        uint32_t e0 = 0, e1 = 0;
-        if (okr[i] && (pos + j) < kend && (unsigned)hi_ < (unsigned)g.H && (unsigned)wi_ < (unsigned)g.W)
-          Ld2<uint16_t>::ld(src + ((long)(b * g.H + hi_) * g.W + wi_) * g.cstride + ci[i], e0, e1);
-        lo[i][j >> 1] |= e0 << ((j & 1) * 16);
-        hi[i][j >> 1] |= e1 << ((j & 1) * 16);
+        const bool ok = okr[i] && (pos + j) < kend && (unsigned)hi_ < (unsigned)g.H && (unsigned)wi_ < (unsigned)g.W;
+        okbits[i] |= (ok ? 1u : 0u) << j;
+        regs[i][j] = *reinterpret_cast<const uint32_t*>(src + (ok ? ((long)(b * g.H + hi_) * g.W + wi_) * g.cstride + ci[i] : 0L));
         if (++x == g.Wo) { x = 0; if (++y == g.Ho) { y = 0; ++b; } }
       }
     }
@@ -318,8 +334,15 @@ struct LoadConvDwA {
       const int t = tid + NT * i;
       if (NTASK % NT == 0 || t < NTASK) {
         const int rp = t % (R / 2), kc = t / (R / 2);
-        *reinterpret_cast<uint4*>(lds + (2 * rp) * kLdsStride + kc * 8) = make_uint4(lo[i][0], lo[i][1], lo[i][2], lo[i][3]);
-        *reinterpret_cast<uint4*>(lds + (2 * rp + 1) * kLdsStride + kc * 8) = make_uint4(hi[i][0], hi[i][1], hi[i][2], hi[i][3]);
+        uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t v = ((okbits[i] >> j) & 1u) ? regs[i][j] : 0u;
+          lo[j >> 1] |= (v & 0xffffu) << ((j & 1) * 16);
+          hi[j >> 1] |= (v >> 16) << ((j & 1) * 16);
+        }
+        *reinterpret_cast<uint4*>(lds + (2 * rp) * DTF_LDS_STRIDE + kc * 8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        *reinterpret_cast<uint4*>(lds + (2 * rp + 1) * DTF_LDS_STRIDE + kc * 8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
       }
     }
   }
@@ -415,12 +438,12 @@ struct EpBiasReluPool {
 };
 
 // ------------------------------------------------------------------ the kernel
-template <int BM, int BN, int WM, int WN, class AL, class BL, class EP>
+template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP>
 __global__ __launch_bounds__(64 * WM * WN) void dtf_gemm_kernel(const GemmParams p) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  static_assert(TM >= 1 && TN >= 1 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile");
-  __shared__ __attribute__((aligned(16))) uint16_t As[BM * kLdsStride];
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[BN * kLdsStride];
+  static_assert(TM >= 1 && TN >= 1 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0 && BK % 16 == 0, "tile");
+  __shared__ __attribute__((aligned(16))) uint16_t As[BM * DTF_LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[BN * DTF_LDS_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
@@ -442,24 +465,24 @@ __global__ __launch_bounds__(64 * WM * WN) void dtf_gemm_kernel(const GemmParams
   al.load(kbeg, kend, tid);
   bl.load(kbeg, kend, tid);
   const int r = lane & 31, h = lane >> 5;
-  for (int k = kbeg; k < kend; k += kBK) {
+  for (int k = kbeg; k < kend; k += BK) {
     __syncthreads();
     al.store(As, tid);
     bl.store(Bs, tid);
     __syncthreads();
-    if (k + kBK < kend) {
-      al.load(k + kBK, kend, tid);
-      bl.load(k + kBK, kend, tid);
+    if (k + BK < kend) {
+      al.load(k + BK, kend, tid);
+      bl.load(k + BK, kend, tid);
     }
 #pragma unroll
-    for (int kk = 0; kk < kBK; kk += 16) {
+    for (int kk = 0; kk < BK; kk += 16) {
       bf16x8 af[TM], bfr[TN];
 #pragma unroll
       for (int a = 0; a < TM; ++a)
-        af[a] = *reinterpret_cast<const bf16x8*>(&As[(wm * (BM / WM) + a * 32 + r) * kLdsStride + kk + 8 * h]);
+        af[a] = *reinterpret_cast<const bf16x8*>(&As[(wm * (BM / WM) + a * 32 + r) * DTF_LDS_STRIDE + kk + 8 * h]);
 #pragma unroll
       for (int b = 0; b < TN; ++b)
-        bfr[b] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * (BN / WN) + b * 32 + r) * kLdsStride + kk + 8 * h]);
+        bfr[b] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * (BN / WN) + b * 32 + r) * DTF_LDS_STRIDE + kk + 8 * h]);
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -470,10 +493,10 @@ __global__ __launch_bounds__(64 * WM * WN) void dtf_gemm_kernel(const GemmParams
   EP::template run<TM, TN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, z);
 }
 
-template <int BM, int BN, int WM, int WN, class AL, class BL, class EP>
+template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP>
 static inline int dtf_launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
   dim3 grid(dtf_cdiv(p.M, BM), dtf_cdiv(p.N, BN), splits);
-  hipLaunchKernelGGL((dtf_gemm_kernel<BM, BN, WM, WN, AL, BL, EP>), grid, dim3(64 * WM * WN), 0, st, p);
+  hipLaunchKernelGGL((dtf_gemm_kernel<BM, BN, BK, WM, WN, AL, BL, EP>), grid, dim3(64 * WM * WN), 0, st, p);
   DTF_CHECK_LAUNCH();
   return 0;
 }

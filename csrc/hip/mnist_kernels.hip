@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
   int it = 0;
   for (int row = blockIdx.x; row < p.B; row += gridDim.x, ++it) {
     float4 h = b1;
+#pragma unroll 4
     for (int s = 0; s < p.nslab; ++s) {
       const float4 v = *reinterpret_cast<const float4*>(p.slabs + (long)s * p.slab_stride + (long)row * HID + k);
       h.x += v.x; h.y += v.y; h.z += v.z; h.w += v.w;

@@ -118,7 +118,8 @@ class NativeMnistEngine(_EngineBase):
         for k in ("pool1", "amax1", "pool2", "amax2", "slabs", "h_drop", "dh", "dz", "dpool2", "dy2", "dpool1"):
             setattr(s, k, self.ws[k].data_ptr())
         self.cfg = s
-        self._graph = None
+        self._graphs = {}
+        torch.cuda.synchronize(self.device)  # allocations/zero-fills ran on the default stream
         self.init_params(seed)
 
     # ------------------------------------------------------------------ parameters / state
@@ -167,9 +168,9 @@ class NativeMnistEngine(_EngineBase):
         self._drop_graph()
 
     def _drop_graph(self) -> None:
-        if self._graph is not None:
-            self.lib.dtf_graph_free(self._graph)
-            self._graph = None
+        for h in self._graphs.values():
+            self.lib.dtf_graph_free(h)
+        self._graphs = {}
 
     # ------------------------------------------------------------------ stepping
     def _maybe_reshuffle(self) -> None:
@@ -184,31 +185,56 @@ class NativeMnistEngine(_EngineBase):
         native.check(self.lib.dtf_mnist_apply(C.byref(self.cfg), self.stream.cuda_stream), "mnist apply")
         self._steps_done += 1
 
-    def _capture(self) -> None:
+    def _capture(self, key: str) -> None:
+        """Capture one segment of the step into a hipGraph: ``full`` (fwd+bwd+Adam), ``part1``
+        (forward + head + fc grads), ``part2`` (conv backward) or ``apply`` (Adam)."""
         st = self.stream.cuda_stream
         self.stream.synchronize()
         native.check(self.lib.dtf_graph_begin(st), "graph begin")
-        rc1 = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 3, st)
-        rc2 = self.lib.dtf_mnist_apply(C.byref(self.cfg), st)
+        rc = 0
+        if key == "full":
+            rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 3, st) or self.lib.dtf_mnist_apply(C.byref(self.cfg), st)
+        elif key == "part1":
+            rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 1, st)
+        elif key == "part2":
+            rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 2, st)
+        elif key == "apply":
+            rc = self.lib.dtf_mnist_apply(C.byref(self.cfg), st)
+        else:
+            rc = -22
         h = C.c_void_p()
-        rc3 = self.lib.dtf_graph_end(st, C.byref(h))
-        native.check(rc1 or rc2 or rc3, "graph capture")
-        self._graph = h
+        rc2 = self.lib.dtf_graph_end(st, C.byref(h))
+        native.check(rc or rc2, "graph capture (%s)" % key)
+        self._graphs[key] = h
+
+    def launch(self, key: str) -> None:
+        """Run a step segment (graph replay when ``use_graph``).  ``apply``/``full`` advance the step."""
+        if key in ("full", "part1"):
+            self._maybe_reshuffle()
+        if self.use_graph:
+            if key not in self._graphs:
+                self._capture(key)
+            native.check(self.lib.dtf_graph_launch(self._graphs[key], self.stream.cuda_stream), "graph launch")
+        else:
+            st = self.stream.cuda_stream
+            if key == "full":
+                rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 3, st) or self.lib.dtf_mnist_apply(C.byref(self.cfg), st)
+            elif key == "part1":
+                rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 1, st)
+            elif key == "part2":
+                rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 2, st)
+            else:
+                rc = self.lib.dtf_mnist_apply(C.byref(self.cfg), st)
+            native.check(rc, "mnist " + key)
+        if key in ("full", "apply"):
+            self._steps_done += 1
 
     def train_step(self) -> None:
         """One full step (single-GPU: fwd+bwd+Adam as one hipGraph replay)."""
-        self._maybe_reshuffle()
-        if self.use_graph:
-            if self._graph is None:
-                self._capture()
-            native.check(self.lib.dtf_graph_launch(self._graph, self.stream.cuda_stream), "graph launch")
-            self._steps_done += 1
-        else:
-            self.fwd_bwd(3)
-            self.apply()
+        self.launch("full")
 
     def graph_nodes(self) -> int:
-        return -1 if self._graph is None else self.lib.dtf_graph_num_nodes(self._graph)
+        return sum(self.lib.dtf_graph_num_nodes(h) for h in self._graphs.values()) if self._graphs else -1
 
     # ------------------------------------------------------------------ metrics / eval
     def read_metrics(self, first_step: int, last_step: int) -> Tuple[np.ndarray, np.ndarray]:
@@ -221,6 +247,8 @@ class NativeMnistEngine(_EngineBase):
     def evaluate(self, images: torch.Tensor, labels: torch.Tensor) -> Tuple[float, float]:
         """Mean loss and accuracy over a device-resident split (fp32 [N,784], int32 [N]); chunked on device."""
         n = images.shape[0]
+        assert images.dtype == torch.float32 and labels.dtype == torch.int32 and images.is_contiguous()
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.stream):
             self.eval_metrics.zero_()
             native.check(self.lib.dtf_mnist_eval(C.byref(self.cfg), images.data_ptr(), labels.data_ptr(), n,
@@ -236,6 +264,7 @@ class NativeMnistEngine(_EngineBase):
         probs = torch.empty(n, 10, dtype=torch.float32, device=self.device)
         pred = torch.empty(n, dtype=torch.int32, device=self.device)
         labels = torch.zeros(n, dtype=torch.int32, device=self.device)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.stream):
             self.eval_metrics.zero_()
             native.check(self.lib.dtf_mnist_eval(C.byref(self.cfg), images.data_ptr(), labels.data_ptr(), n,
@@ -331,7 +360,7 @@ class EagerMnistEngine(_EngineBase):
         (g,) = torch.autograd.grad(loss, leaf)
         self.G.copy_(g)
         slot = self._steps_done % self.RING
-        self._ring[slot, 0] = float(loss) * x.shape[0]
+        self._ring[slot, 0] = float(loss.detach()) * x.shape[0]
         self._ring[slot, 1] = float((pred.argmax(1) == y.long()).sum())
 
     def apply(self) -> None:

@@ -35,8 +35,8 @@ def fc_forward(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     M, K = x.shape
     K2, N = w.shape
     assert K == K2
-    ksteps = (K + 31) // 32
-    kchunk = (ksteps + splits - 1) // splits * 32
+    ksteps = (K + 63) // 64  # BK of the fc_fwd kernel (gemm_api.hip)
+    kchunk = (ksteps + splits - 1) // splits * 64
     s_eff = (K + kchunk - 1) // kchunk
     out = torch.empty(s_eff, M, N, dtype=torch.float32, device=x.device)
     native.check(native.hip().dtf_fc_fwd(x.data_ptr(), int(x.dtype == torch.float32), w.data_ptr(), out.data_ptr(),

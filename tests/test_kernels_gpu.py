@@ -200,7 +200,7 @@ def test_adam_tf(ops):
         assert int(step.item()) == t and int(ticket.item()) == 0
         assert float(Gk[1024:].abs().max()) == 0.0 and torch.equal(Gk[:1024], G[:1024])
         assert torch.allclose(P, Pr, rtol=1e-5, atol=1e-6)
-        assert torch.allclose(V, Vr, rtol=1e-5, atol=1e-9)
+        assert torch.allclose(V, Vr, rtol=1e-4, atol=1e-9)
 
 
 def test_sgd(ops):
