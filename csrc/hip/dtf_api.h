@@ -9,6 +9,8 @@ DTF_API int dtf_fc_fwd(const void* X, int x_is_f32, const float* W, float* out, 
                        const float* bias, int relu, hipStream_t st);
 DTF_API int dtf_fc_bwd_data(const void* dY, const float* W, float* dX, int M, int N, int K, int splits, hipStream_t st);
 DTF_API int dtf_fc_dw(const void* X, int x_is_f32, const void* dY, float* dW, int M, int N, int K, int splits, hipStream_t st);
+DTF_API int dtf_fc_dw_pair(const void* X0, const void* dY0, float* dW0, int M0, int N0, const void* X1, const void* dY1,
+                           float* dW1, int M1, int N1, int K, hipStream_t st);
 DTF_API int dtf_conv_bias_relu_pool(const void* x, const float* Wt, const float* bias, void* out, void* argmax, int B,
                                     int H, int W, int Cin, int Cout, int KH, int KW, hipStream_t st);
 DTF_API int dtf_conv_bwd_data_mask(const void* dY, const float* Wt, const void* mask, float* dX, int B, int H, int W,

@@ -29,6 +29,8 @@ struct HeadParams {
   int metrics_ring;       // >0: metrics += 2*(step % ring)
   float* probs;           // optional fp32 [B][10]
   int* pred;              // optional int32 [B]
+  float* zero_buf;        // optional: buffer zeroed as a side job (float4 granularity)
+  long zero_n4;
 };
 
 struct OptimParams {

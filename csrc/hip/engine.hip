@@ -84,18 +84,20 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e, int parts, hipStream_t st) {
     hp.db_fc1 = e->G + e->off_bfc1;
     hp.metrics = e->metrics_ring;
     hp.metrics_ring = e->ring;
+    // the split-K fc1 bwd-data accumulates into dpool2 with atomics: the head zeroes it (saves a memset node)
+    if (effective_splits(1024, e->bwd_splits) > 1) { hp.zero_buf = e->dpool2; hp.zero_n4 = (long)B * 3136 / 4; }
     DTF_TRY(dtf_head(&hp, e->head_blocks, st));
-    // fc2 dW[1024][10] = h_drop^T * dz      (stored, not accumulated)
-    DTF_TRY(dtf_fc_dw(e->h_drop, 0, e->dz, e->G + e->off_Wfc2, 1024, 10, B, 1, st));
-    // fc1 dW[3136][1024] = pool2^T * dh     (stored: 12.8 MB, the one gradient that is never re-zeroed)
-    DTF_TRY(dtf_fc_dw(e->pool2, 0, e->dh, e->G + e->off_Wfc1, 3136, 1024, B, 1, st));
+    // fc1 dW[3136][1024] = pool2^T * dh  (stored: 12.8 MB, the one gradient that is never re-zeroed) and
+    // fc2 dW[1024][10] = h_drop^T * dz, as one grouped launch when the batch fits a single K slab
+    if (B <= 128) {
+      DTF_TRY(dtf_fc_dw_pair(e->pool2, e->dh, e->G + e->off_Wfc1, 3136, 1024, e->h_drop, e->dz, e->G + e->off_Wfc2,
+                             1024, 10, B, st));
+    } else {
+      DTF_TRY(dtf_fc_dw(e->h_drop, 0, e->dz, e->G + e->off_Wfc2, 1024, 10, B, 1, st));
+      DTF_TRY(dtf_fc_dw(e->pool2, 0, e->dh, e->G + e->off_Wfc1, 3136, 1024, B, 1, st));
+    }
   }
   if (parts & 2) {
-    const int bs = effective_splits(1024, e->bwd_splits);
-    if (bs > 1) {
-      hipError_t err = hipMemsetAsync(e->dpool2, 0, (size_t)B * 3136 * sizeof(float), st);
-      if (err != hipSuccess) return (int)err;
-    }
     DTF_TRY(dtf_fc_bwd_data(e->dh, e->P + e->off_Wfc1, e->dpool2, B, 3136, 1024, e->bwd_splits, st));
     DTF_TRY(dtf_unpool(e->dpool2, e->pool2, e->amax2, e->dy2, e->G + e->off_bc2, B, 7, 7, 64, st));
     DTF_TRY(dtf_conv_bwd_data_mask(e->dy2, e->P + e->off_Wc2, e->pool1, e->dpool1, B, 14, 14, 32, 64, 5, 5, st));

@@ -60,6 +60,16 @@ DTF_API int dtf_fc_dw(const void* X, int x_is_f32, const void* dY, float* dW, in
   return dtf_launch_gemm<128, 64, 128, 4, 1, LoadColK<uint16_t, 128, 256, 128, true>, LoadColK<uint16_t, 64, 256, 128, false>, EpAtomicF32>(p, s, st);
 }
 
+// Two weight-gradient GEMMs (bf16 activations, K = batch, single K pass) in one launch:
+//   dW0[M0][N0] = X0^T * dY0   and   dW1[M1][N1] = X1^T * dY1
+DTF_API int dtf_fc_dw_pair(const void* X0, const void* dY0, float* dW0, int M0, int N0, const void* X1, const void* dY1,
+                           float* dW1, int M1, int N1, int K, hipStream_t st) {
+  if (M0 <= 0 || N0 <= 0 || M1 <= 0 || N1 <= 0 || K <= 0 || K > 128 || M0 % 2 || N0 % 2 || M1 % 2 || N1 % 2) return ERR_SHAPE;
+  GemmParams p0 = base_params(X0, dY0, dW0, M0, N0, K, M0, N0, N0, 1, 128);
+  GemmParams p1 = base_params(X1, dY1, dW1, M1, N1, K, M1, N1, N1, 1, 128);
+  return dtf_launch_gemm_pair<128, 64, 128, 4, 1, LoadColK<uint16_t, 128, 256, 128, true>, LoadColK<uint16_t, 64, 256, 128, false>, EpStoreF32>(p0, p1, st);
+}
+
 static inline int fill_geom(GemmParams& p, int H, int W, int Cin, int cstride, int Ho, int Wo, int KH, int KW,
                             int stride, int pad_h, int pad_w) {
   p.g.H = H; p.g.W = W; p.g.Cin = Cin; p.g.cstride = cstride; p.g.Ho = Ho; p.g.Wo = Wo;

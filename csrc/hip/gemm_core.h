@@ -439,14 +439,13 @@ struct EpBiasReluPool {
 
 // ------------------------------------------------------------------ the kernel
 template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP>
-__global__ __launch_bounds__(64 * WM * WN) void dtf_gemm_kernel(const GemmParams p) {
+__device__ __forceinline__ void dtf_gemm_body(const GemmParams& p, const int m0, const int n0, const int z) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static_assert(TM >= 1 && TN >= 1 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0 && BK % 16 == 0, "tile");
   __shared__ __attribute__((aligned(16))) uint16_t As[BM * DTF_LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) uint16_t Bs[BN * DTF_LDS_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
   const int kbeg = z * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
 
@@ -493,10 +492,44 @@ __global__ __launch_bounds__(64 * WM * WN) void dtf_gemm_kernel(const GemmParams
   EP::template run<TM, TN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, z);
 }
 
+
+template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP>
+__global__ __launch_bounds__(64 * WM * WN) void dtf_gemm_kernel(const GemmParams p) {
+  dtf_gemm_body<BM, BN, BK, WM, WN, AL, BL, EP>(p, blockIdx.x * BM, blockIdx.y * BN, blockIdx.z);
+}
+
+// Two independent problems of the same instantiation in ONE launch (horizontal fusion of small GEMMs:
+// each extra kernel boundary costs ~4 us on this step).  Blocks [0, nblk0) run problem 0.
+struct GemmPair {
+  GemmParams p[2];
+  int nblk0, mt0, mt1;  // blocks of problem 0; m-tiles per problem
+};
+template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP>
+__global__ __launch_bounds__(64 * WM * WN) void dtf_gemm_pair_kernel(const GemmPair g) {
+  const int which = (int)blockIdx.x >= g.nblk0;
+  const int id = which ? blockIdx.x - g.nblk0 : blockIdx.x;
+  const int mt = which ? g.mt1 : g.mt0;
+  dtf_gemm_body<BM, BN, BK, WM, WN, AL, BL, EP>(g.p[which], (id % mt) * BM, (id / mt) * BN, 0);
+}
+
 template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP>
 static inline int dtf_launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
   dim3 grid(dtf_cdiv(p.M, BM), dtf_cdiv(p.N, BN), splits);
   hipLaunchKernelGGL((dtf_gemm_kernel<BM, BN, BK, WM, WN, AL, BL, EP>), grid, dim3(64 * WM * WN), 0, st, p);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP>
+static inline int dtf_launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, hipStream_t st) {
+  GemmPair g;
+  g.p[0] = p0;
+  g.p[1] = p1;
+  g.mt0 = dtf_cdiv(p0.M, BM);
+  g.mt1 = dtf_cdiv(p1.M, BM);
+  g.nblk0 = g.mt0 * dtf_cdiv(p0.N, BN);
+  const int total = g.nblk0 + g.mt1 * dtf_cdiv(p1.N, BN);
+  hipLaunchKernelGGL((dtf_gemm_pair_kernel<BM, BN, BK, WM, WN, AL, BL, EP>), dim3(total), dim3(64 * WM * WN), 0, st, g);
   DTF_CHECK_LAUNCH();
   return 0;
 }

@@ -234,6 +234,10 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
 #pragma unroll
   for (int j = 0; j < NC; ++j) b2[j] = p.b_fc2[j];
   const int step = p.step_ptr ? *p.step_ptr : 0;
+  if (p.zero_buf) {
+    for (long i = (long)blockIdx.x * 256 + tid; i < p.zero_n4; i += (long)gridDim.x * 256)
+      reinterpret_cast<float4*>(p.zero_buf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   float accb1[4] = {0.f, 0.f, 0.f, 0.f};
   float accb2[NC];
 #pragma unroll

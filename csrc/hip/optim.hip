@@ -30,21 +30,38 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(const OptimParams p) {
   const float lr_t = (float)((double)p.lr * sqrt(1.0 - b2p) / (1.0 - b1p));
   const float b1 = p.beta1, b2 = p.beta2, ob1 = 1.f - p.beta1, ob2 = 1.f - p.beta2;
   const long n4 = p.n >> 2;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    float4 g = reinterpret_cast<const float4*>(p.G)[i];
-    float4 m = reinterpret_cast<const float4*>(p.M)[i];
-    float4 v = reinterpret_cast<const float4*>(p.V)[i];
-    float4 w = reinterpret_cast<const float4*>(p.P)[i];
-    g.x *= p.grad_scale; g.y *= p.grad_scale; g.z *= p.grad_scale; g.w *= p.grad_scale;
-    m.x = b1 * m.x + ob1 * g.x; m.y = b1 * m.y + ob1 * g.y; m.z = b1 * m.z + ob1 * g.z; m.w = b1 * m.w + ob1 * g.w;
-    v.x = b2 * v.x + ob2 * g.x * g.x; v.y = b2 * v.y + ob2 * g.y * g.y;
-    v.z = b2 * v.z + ob2 * g.z * g.z; v.w = b2 * v.w + ob2 * g.w * g.w;
-    w.x -= lr_t * m.x / (sqrtf(v.x) + p.eps); w.y -= lr_t * m.y / (sqrtf(v.y) + p.eps);
-    w.z -= lr_t * m.z / (sqrtf(v.z) + p.eps); w.w -= lr_t * m.w / (sqrtf(v.w) + p.eps);
-    reinterpret_cast<float4*>(p.M)[i] = m;
-    reinterpret_cast<float4*>(p.V)[i] = v;
-    reinterpret_cast<float4*>(p.P)[i] = w;
-    if (i * 4 >= p.zero_from) reinterpret_cast<float4*>(p.G)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int U = 4;  // 16 independent 16-B loads in flight per lane before the first use
+  for (long base = (long)blockIdx.x * 256 * U + threadIdx.x; base < n4; base += (long)gridDim.x * 256 * U) {
+    float4 g[U], m[U], v[U], w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = base + u * 256;
+      const long j = i < n4 ? i : base;  // clamped address, result discarded below
+      g[u] = reinterpret_cast<const float4*>(p.G)[j];
+      m[u] = reinterpret_cast<const float4*>(p.M)[j];
+      v[u] = reinterpret_cast<const float4*>(p.V)[j];
+      w[u] = reinterpret_cast<const float4*>(p.P)[j];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = base + u * 256;
+      if (i >= n4) continue;
+      float* gp = &g[u].x;
+      float* mp = &m[u].x;
+      float* vp = &v[u].x;
+      float* wp = &w[u].x;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float gg = gp[c] * p.grad_scale;
+        mp[c] = b1 * mp[c] + ob1 * gg;
+        vp[c] = b2 * vp[c] + ob2 * gg * gg;
+        wp[c] -= lr_t * mp[c] / (sqrtf(vp[c]) + p.eps);
+      }
+      reinterpret_cast<float4*>(p.M)[i] = m[u];
+      reinterpret_cast<float4*>(p.V)[i] = v[u];
+      reinterpret_cast<float4*>(p.P)[i] = w[u];
+      if (i * 4 >= p.zero_from) reinterpret_cast<float4*>(p.G)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   finish_step(p, t);
 }
@@ -64,7 +81,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(const OptimParams p) {
 }
 
 static int optim_grid(long n) {
-  long blocks = (n / 4 + 255) / 256;
+  long blocks = (n / 4 + 1023) / 1024;  // 4 float4 per lane per pass
   if (blocks > 2048) blocks = 2048;  // memory-bound: cap and grid-stride (guide §6 G11)
   if (blocks < 1) blocks = 1;
   return (int)blocks;

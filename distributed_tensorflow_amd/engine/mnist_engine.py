@@ -142,8 +142,11 @@ class NativeMnistEngine(_EngineBase):
         return (0, split), (split, self.n_arena)
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
+        # snapshot in stream order (between two steps) so a saver thread never sees a half-applied update
+        with torch.cuda.stream(self.stream):
+            sd = {"P": self.P.clone(), "M": self.M.clone(), "V": self.V.clone(), "step": self.step_t.clone()}
         self.stream.synchronize()
-        return {"P": self.P.clone(), "M": self.M.clone(), "V": self.V.clone(), "step": self.step_t.clone()}
+        return sd
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
         with torch.cuda.stream(self.stream):

@@ -37,7 +37,7 @@ class HeadParams(C.Structure):
         ("seed", C.c_ulonglong), ("double_softmax", c_int), ("training", c_int),
         ("h_drop", c_void_p), ("dh", c_void_p), ("dz", c_void_p),
         ("db_fc2", c_void_p), ("db_fc1", c_void_p), ("metrics", c_void_p), ("metrics_ring", c_int),
-        ("probs", c_void_p), ("pred", c_void_p),
+        ("probs", c_void_p), ("pred", c_void_p), ("zero_buf", c_void_p), ("zero_n4", c_long),
     ]
 
 
@@ -96,6 +96,7 @@ def hip() -> C.CDLL:
         _sig(lib, "dtf_fc_fwd", I, [P, I, P, P, I, I, I, I, P, I, P])
         _sig(lib, "dtf_fc_bwd_data", I, [P, P, P, I, I, I, I, P])
         _sig(lib, "dtf_fc_dw", I, [P, I, P, P, I, I, I, I, P])
+        _sig(lib, "dtf_fc_dw_pair", I, [P, P, P, I, I, P, P, P, I, I, I, P])
         _sig(lib, "dtf_conv_bias_relu_pool", I, [P, P, P, P, P, I, I, I, I, I, I, I, P])
         _sig(lib, "dtf_conv_bwd_data_mask", I, [P, P, P, P, I, I, I, I, I, I, I, P])
         _sig(lib, "dtf_conv_dw", I, [P, P, P, I, I, I, I, I, I, I, I, P])

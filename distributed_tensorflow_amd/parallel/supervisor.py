@@ -1,0 +1,148 @@
+"""Supervisor (component C23): chief election, init/restore, wait-for-ready, timed autosave,
+recovery and the stop flag.
+
+Reference: ``tf.train.Supervisor(is_chief=(task_index==0), logdir="./logs", init_op, saver,
+global_step, save_model_secs=600)`` + ``sv.managed_session(server.target)`` +
+``sv.should_stop()`` / ``sv.stop()`` (``demo2/train.py:166-176,181``;
+``retrain2/retrain2.py:423-431,445,508``).
+
+Equivalent behaviour here:
+
+* the chief (rank 0) either restores the newest checkpoint in ``logdir`` (auto-resume after a
+  crash/restart) or keeps its fresh initialisation; the result is **broadcast** to every replica —
+  the replacement for "chief runs init_op, other workers poll until the variables are initialised";
+* a background thread on the chief snapshots the model every ``save_model_secs`` seconds to
+  ``logdir/model.ckpt-<global_step>`` (device->host copy on a side stream, file I/O off the
+  training thread) and, like the Supervisor's step-counter thread, logs ``global_step/sec``;
+* ``managed_session`` is a context manager that turns any exception into a coordinated stop
+  (``request_stop``) and always runs a final save on the chief (the reference's demo2 never saves
+  explicitly, quirk Q8);
+* ``should_stop()`` is cheap on the hot path: the local flag is all-reduced (max) across ranks
+  only every ``stop_check_interval`` steps, so one failing rank stops the whole job;
+* ``--fault_inject_step`` support lives in the training drivers and is exercised by the tests.
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+import threading
+import time
+from typing import Callable, Optional
+
+from ..utils import checkpoint as ckpt
+
+
+class Supervisor:
+    def __init__(self, trainer, *, is_chief: bool, logdir: Optional[str], saver: Optional[ckpt.Saver] = None,
+                 save_model_secs: float = 600.0, checkpoint_basename: str = "model.ckpt",
+                 stop_check_interval: int = 50, summary_writer=None, log_fn: Callable[[str], None] = print):
+        self.trainer = trainer
+        self.engine = trainer.engine
+        self.is_chief = is_chief
+        self.logdir = logdir
+        self.saver = saver or ckpt.Saver(self.engine, with_global_step=True)
+        self.save_model_secs = save_model_secs
+        self.save_path = os.path.join(logdir, checkpoint_basename) if logdir else None
+        self.stop_check_interval = max(1, stop_check_interval)
+        self.summary_writer = summary_writer
+        self.log = log_fn
+        self._stop_local = threading.Event()
+        self._stop_global = False
+        self._steps_since_check = 0
+        self._saver_thread: Optional[threading.Thread] = None
+        self._saver_wake = threading.Event()
+        self._save_lock = threading.Lock()
+        self.restored_from: Optional[str] = None
+        self.num_autosaves = 0
+        self.last_exception: Optional[BaseException] = None
+
+    # ------------------------------------------------------------------ init / restore
+    def prepare_or_wait_for_session(self) -> int:
+        """Chief: restore the newest checkpoint if any; everyone: receive the chief's state."""
+        if self.is_chief and self.logdir:
+            os.makedirs(self.logdir, exist_ok=True)
+            latest = ckpt.latest_checkpoint(self.logdir, os.path.basename(self.save_path))
+            if latest is not None:
+                step = self.saver.restore(latest)
+                self.restored_from = latest
+                self.log("Supervisor: restored %s (global_step=%d)" % (latest, step))
+        if self.trainer.world > 1:
+            self.trainer.broadcast_state(src=0)
+        return self.engine.global_step
+
+    # ------------------------------------------------------------------ autosave
+    def _save(self, tag: str) -> Optional[str]:
+        if not (self.is_chief and self.save_path):
+            return None
+        with self._save_lock:
+            path = self.saver.save(self.save_path, global_step=self.engine.global_step)
+        self.log("Supervisor: %s checkpoint %s" % (tag, path))
+        return path
+
+    def _saver_loop(self) -> None:
+        last_step, last_t = self.engine.global_step, time.time()
+        while not self._stop_local.is_set():
+            woke = self._saver_wake.wait(self.save_model_secs)
+            if self._stop_local.is_set() or woke:
+                break
+            try:
+                self._save("autosave")
+                self.num_autosaves += 1
+                now, step = time.time(), self.engine.global_step
+                rate = (step - last_step) / max(1e-9, now - last_t)
+                last_step, last_t = step, now
+                if self.summary_writer is not None:
+                    self.summary_writer.add_scalars({"global_step/sec": rate}, step)
+            except Exception as e:  # never kill training because of a failed autosave
+                self.log("Supervisor: autosave failed: %r" % (e,))
+
+    def start_standard_services(self) -> None:
+        if self.is_chief and self.save_path and self.save_model_secs and self.save_model_secs > 0:
+            self._saver_thread = threading.Thread(target=self._saver_loop, name="dtf-saver", daemon=True)
+            self._saver_thread.start()
+
+    # ------------------------------------------------------------------ stop protocol
+    def request_stop(self, ex: Optional[BaseException] = None) -> None:
+        if ex is not None:
+            self.last_exception = ex
+        self._stop_local.set()
+
+    def should_stop(self, force_check: bool = False) -> bool:
+        """Collective: every rank must call it the same number of times."""
+        if self._stop_global:
+            return True
+        self._steps_since_check += 1
+        if force_check or self._steps_since_check >= self.stop_check_interval or self.trainer.world == 1:
+            self._steps_since_check = 0
+            self._stop_global = self.trainer.any_rank(self._stop_local.is_set())
+        return self._stop_global
+
+    def stop(self, final_save: bool = True) -> None:
+        """``sv.stop()``: stop services, final save on the chief, barrier."""
+        self._stop_local.set()
+        self._saver_wake.set()
+        if self._saver_thread is not None:
+            self._saver_thread.join(timeout=30)
+            self._saver_thread = None
+        if final_save:
+            try:
+                self._save("final")
+            except Exception as e:
+                self.log("Supervisor: final save failed: %r" % (e,))
+        if self.summary_writer is not None:
+            self.summary_writer.flush()
+
+    @contextlib.contextmanager
+    def managed_session(self, start_services: bool = True):
+        """``with sv.managed_session(server.target) as sess`` — yields the trainer."""
+        self.prepare_or_wait_for_session()
+        if start_services:
+            self.start_standard_services()
+        try:
+            yield self.trainer
+        except BaseException as e:  # noqa: BLE001 - mirror Supervisor: any error requests a stop
+            self.request_stop(e)
+            self.stop(final_save=True)
+            raise
+        else:
+            self.stop(final_save=True)

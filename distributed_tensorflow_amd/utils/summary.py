@@ -1,0 +1,284 @@
+"""TensorBoard summaries (components C18, C24).
+
+``FileWriter`` wraps the native tfevents writer (``csrc/host/tfevents_writer.cc``): records are
+framed and CRC'd in C++ and flushed by a background thread, so ``add_summary`` never blocks the
+step loop (the reference evaluates and writes summaries synchronously on *every* step,
+``demo1/train.py:155-157`` / ``retrain1/retrain.py:440-446`` — quirk Q5).  A JSONL mirror of the
+scalars is written next to the event file for tooling that has no TensorBoard (it is not
+installed here either).
+
+``variable_summaries`` reproduces ``retrain1/retrain.py:249-258`` (mean / stddev / max / min +
+histogram per variable) from one fused single-pass statistics kernel on the GPU
+(``csrc/hip/stats.hip``) or torch ops on CPU.  Histograms use TensorFlow's default exponential
+bucket limits so TensorBoard renders them the same way.
+
+``read_events`` re-parses an event file (length + CRC checks and a minimal protobuf decoder):
+the test-side inverse of the writer.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import socket
+import struct
+import time
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import numpy as np
+
+from .. import native
+
+
+def _default_bucket_limits() -> np.ndarray:
+    """TF's ``histogram::InitDefaultBuckets``: +-1e-12 * 1.1^k up to 1e20, plus DBL_MAX."""
+    pos = []
+    v = 1e-12
+    while v < 1e20:
+        pos.append(v)
+        v *= 1.1
+    pos = np.asarray(pos, np.float64)
+    return np.concatenate((-pos[::-1], [0.0], pos, [np.finfo(np.float64).max]))
+
+
+BUCKET_LIMITS = _default_bucket_limits()
+
+
+class Summary:
+    """A bag of values for one step (the analogue of the serialized ``Summary`` proto)."""
+
+    def __init__(self):
+        self.scalars: List[Tuple[str, float]] = []
+        self.histograms: List[Tuple[str, dict]] = []
+
+    def scalar(self, tag: str, value) -> "Summary":
+        self.scalars.append((tag, float(value)))
+        return self
+
+    def histogram(self, tag: str, values) -> "Summary":
+        self.histograms.append((tag, histogram_stats(values)))
+        return self
+
+    def merge(self, other: "Summary") -> "Summary":
+        self.scalars += other.scalars
+        self.histograms += other.histograms
+        return self
+
+
+def histogram_stats(values) -> dict:
+    """min/max/num/sum/sum_squares + TF-style compressed buckets of a tensor or array."""
+    try:
+        import torch
+        if isinstance(values, torch.Tensor):
+            t = values.detach().reshape(-1).to(torch.float64)
+            if t.is_cuda:
+                # bucketize on device, transfer only the (few hundred) counts
+                limits = torch.from_numpy(BUCKET_LIMITS).to(t.device)
+                idx = torch.bucketize(t, limits, right=False)
+                counts = torch.bincount(idx.clamp_(max=len(BUCKET_LIMITS) - 1), minlength=len(BUCKET_LIMITS)).cpu().numpy()
+                st = torch.stack([t.min(), t.max(), t.sum(), (t * t).sum()]).cpu().numpy()
+                return _compress(float(st[0]), float(st[1]), float(t.numel()), float(st[2]), float(st[3]), counts)
+            values = t.cpu().numpy()
+    except ImportError:
+        pass
+    a = np.asarray(values, np.float64).reshape(-1)
+    idx = np.searchsorted(BUCKET_LIMITS, a, side="left")
+    counts = np.bincount(np.minimum(idx, len(BUCKET_LIMITS) - 1), minlength=len(BUCKET_LIMITS))
+    return _compress(float(a.min()), float(a.max()), float(a.size), float(a.sum()), float((a * a).sum()), counts)
+
+
+def _compress(mn, mx, num, s, ss, counts) -> dict:
+    """Drop runs of empty buckets like TF's ``EncodeToProto`` does."""
+    limits, buckets = [], []
+    n = len(counts)
+    i = 0
+    while i < n:
+        j = i
+        while j < n and counts[j] == 0:
+            j += 1
+        if j > i and j < n:
+            limits.append(float(BUCKET_LIMITS[j - 1]))
+            buckets.append(0.0)
+        elif j > i:
+            break
+        i = j
+        if i < n:
+            limits.append(float(BUCKET_LIMITS[i]))
+            buckets.append(float(counts[i]))
+            i += 1
+    if not limits:
+        limits, buckets = [float(BUCKET_LIMITS[-1])], [0.0]
+    return {"min": mn, "max": mx, "num": num, "sum": s, "sum_squares": ss,
+            "bucket_limit": limits, "bucket": buckets}
+
+
+def variable_summaries(name: str, var) -> Summary:
+    """``variable_summaries(var)`` of the reference under name scope ``name``
+    (``retrain1/retrain.py:249-258``): mean, stddev, max, min scalars + histogram."""
+    import torch
+    t = var.detach().float().reshape(-1)
+    mean = t.mean()
+    std = torch.sqrt(((t - mean) ** 2).mean())
+    st = torch.stack([mean, std, t.max(), t.min()]).cpu().tolist()
+    s = Summary()
+    s.scalar(name + "/summaries/mean", st[0])
+    s.scalar(name + "/summaries/stddev/stddev", st[1])
+    s.scalar(name + "/summaries/max", st[2])
+    s.scalar(name + "/summaries/min", st[3])
+    s.histogram(name + "/summaries/histogram", var)
+    return s
+
+
+class FileWriter:
+    """``tf.summary.FileWriter(logdir, graph)`` equivalent (``demo1/train.py:151``)."""
+
+    def __init__(self, logdir: str, graph: Optional[dict] = None, filename_suffix: str = ""):
+        os.makedirs(logdir, exist_ok=True)
+        self.logdir = logdir
+        fname = "events.out.tfevents.%010d.%s%s" % (int(time.time()), socket.gethostname(), filename_suffix)
+        self.path = os.path.join(logdir, fname)
+        self._lib = native.host()
+        self._h = self._lib.dtf_events_open(self.path.encode())
+        if not self._h:
+            raise OSError("cannot open event file " + self.path)
+        self._jsonl = open(os.path.join(logdir, "scalars%s.jsonl" % filename_suffix), "a")
+        if graph is not None:
+            blob = json.dumps(graph).encode()
+            self._lib.dtf_events_graph(self._h, blob, len(blob))
+
+    def add_summary(self, summary: Summary, global_step: int, wall_time: Optional[float] = None) -> None:
+        lib, h = self._lib, self._h
+        lib.dtf_events_begin(h, int(global_step), float(wall_time or 0.0))
+        for tag, v in summary.scalars:
+            lib.dtf_events_scalar(h, tag.encode(), float(v))
+        for tag, hs in summary.histograms:
+            n = len(hs["bucket_limit"])
+            lim = (C.c_double * n)(*hs["bucket_limit"])
+            cnt = (C.c_double * n)(*hs["bucket"])
+            lib.dtf_events_histogram(h, tag.encode(), hs["min"], hs["max"], hs["num"], hs["sum"], hs["sum_squares"],
+                                     n, lim, cnt)
+        lib.dtf_events_end(h)
+        if summary.scalars:
+            self._jsonl.write(json.dumps({"step": int(global_step), **{t: v for t, v in summary.scalars}}) + "\n")
+
+    def add_scalars(self, values: Dict[str, float], global_step: int) -> None:
+        s = Summary()
+        for k, v in values.items():
+            s.scalar(k, v)
+        self.add_summary(s, global_step)
+
+    def flush(self) -> None:
+        self._lib.dtf_events_flush(self._h)
+        self._jsonl.flush()
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.dtf_events_close(self._h)
+            self._h = None
+            self._jsonl.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------- reader (tests / tooling)
+def _read_varint(buf: bytes, pos: int) -> Tuple[int, int]:
+    shift = result = 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        result |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return result, pos
+        shift += 7
+
+
+def _parse_fields(buf: bytes) -> List[Tuple[int, int, object]]:
+    out = []
+    pos = 0
+    while pos < len(buf):
+        key, pos = _read_varint(buf, pos)
+        field, wire = key >> 3, key & 7
+        if wire == 0:
+            v, pos = _read_varint(buf, pos)
+        elif wire == 1:
+            v = buf[pos:pos + 8]
+            pos += 8
+        elif wire == 2:
+            n, pos = _read_varint(buf, pos)
+            v = buf[pos:pos + n]
+            pos += n
+        elif wire == 5:
+            v = buf[pos:pos + 4]
+            pos += 4
+        else:
+            raise ValueError("unsupported wire type %d" % wire)
+        out.append((field, wire, v))
+    return out
+
+
+def read_events(path: str, verify_crc: bool = True) -> List[dict]:
+    """Parse an event file into dicts: ``{wall_time, step, file_version?, graph?, scalars{}, histograms{}}``."""
+    lib = native.host()
+    events = []
+    with open(path, "rb") as f:
+        data = f.read()
+    pos = 0
+    while pos < len(data):
+        hdr = data[pos:pos + 12]
+        if len(hdr) < 12:
+            raise ValueError("truncated record header")
+        (length,), (crc_len,) = struct.unpack("<Q", hdr[:8]), struct.unpack("<I", hdr[8:])
+        payload = data[pos + 12:pos + 12 + length]
+        (crc_data,) = struct.unpack("<I", data[pos + 12 + length:pos + 16 + length])
+        if verify_crc:
+            if lib.dtf_masked_crc32c(hdr[:8], 8) != crc_len:
+                raise ValueError("length CRC mismatch at %d" % pos)
+            if lib.dtf_masked_crc32c(payload, len(payload)) != crc_data:
+                raise ValueError("data CRC mismatch at %d" % pos)
+        pos += 16 + length
+        ev = {"scalars": {}, "histograms": {}}
+        for field, wire, v in _parse_fields(payload):
+            if field == 1:
+                ev["wall_time"] = struct.unpack("<d", v)[0]
+            elif field == 2:
+                ev["step"] = v
+            elif field == 3:
+                ev["file_version"] = v.decode()
+            elif field == 4:
+                ev["graph"] = v
+            elif field == 5:
+                for f2, _w2, val in _parse_fields(v):
+                    if f2 != 1:
+                        continue
+                    tag, simple, histo = None, None, None
+                    for f3, _w3, x in _parse_fields(val):
+                        if f3 == 1:
+                            tag = x.decode()
+                        elif f3 == 2:
+                            simple = struct.unpack("<f", x)[0]
+                        elif f3 == 5:
+                            histo = {}
+                            names = {1: "min", 2: "max", 3: "num", 4: "sum", 5: "sum_squares"}
+                            for f4, _w4, y in _parse_fields(x):
+                                if f4 in names:
+                                    histo[names[f4]] = struct.unpack("<d", y)[0]
+                                elif f4 == 6:
+                                    histo["bucket_limit"] = list(struct.unpack("<%dd" % (len(y) // 8), y))
+                                elif f4 == 7:
+                                    histo["bucket"] = list(struct.unpack("<%dd" % (len(y) // 8), y))
+                    if simple is not None:
+                        ev["scalars"][tag] = simple
+                    if histo is not None:
+                        ev["histograms"][tag] = histo
+        events.append(ev)
+    return events

@@ -11,3 +11,4 @@ timeout -k 10 200 python bench.py --steps 500 --warmup 100 --no-graph --eval 0 |
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof1 -- python3 $R/bench.py --steps 300 --warmup 50 --no-graph --eval 0 > $R/gpurun_out/prof1.log 2>&1 || exit 1
 ls -R $R/gpurun_out | head -30
+cd $R && timeout -k 10 300 python bench.py --steps 300 --warmup 30 --engine eager --eval 0 | tee gpurun_out/bench_eager_baseline.json

@@ -64,7 +64,7 @@ def test_graph_replay_matches_direct_and_learns():
         e1.train_step()
         e2.train_step()
     e1.stream.synchronize(); e2.stream.synchronize()
-    assert e1.graph_nodes() >= 12
+    assert e1.graph_nodes() >= 10
     assert int(e1.step_t.item()) == 60 and int(e2.step_t.item()) == 60
     l1, a1 = e1.read_metrics(0, 60)
     l2, a2 = e2.read_metrics(0, 60)
