@@ -319,13 +319,13 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
 #pragma unroll
       for (int j = 0; j < NC; ++j) dzv[j] = pr[j] * (gp[j] - dot);
     } else {
-      float py_ = 0.f;
+      float zy = 0.f;
 #pragma unroll
       for (int j = 0; j < NC; ++j) {
-        if (j == y) py_ = pr[j];
+        if (j == y) zy = z[j];
         dzv[j] = (pr[j] - (j == y ? 1.f : 0.f)) * p.grad_scale;
       }
-      loss = -__logf(fmaxf(py_, 1e-30f));
+      loss = __logf(psum) - (zy - zmax);  // log-sum-exp form: exact even when p[y] underflows
     }
     if (tid == 0) {
       loss_sum += loss;

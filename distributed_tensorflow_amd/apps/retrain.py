@@ -1,0 +1,266 @@
+"""Inception-v3 transfer-learning driver shared by ``retrain1/retrain.py`` and
+``retrain2/retrain2.py`` (component C37; reference ``main``: ``retrain1/retrain.py:372-476``,
+``retrain2/retrain2.py:366-508``).
+
+Flow: wipe + recreate ``summaries_dir`` -> (optional) model download -> build the backbone -> image
+lists with the SHA-1 split -> bail out on 0/1 classes -> new softmax head -> batched bottleneck
+extraction into the HBM cache (or the distortion pipeline) -> per step: train batch + validation
+batch, SGD step, train/validation summaries -> every ``eval_step_interval`` steps the reference log
+line -> final test accuracy on the whole test split -> export bundle + ``retrained_labels.txt``.
+
+Design differences: rank 0 only touches the filesystem and extraction is sharded
+over ranks + all-gathered (Q9); the per-step work never leaves the GPU (Q16); ``--eval_step_interval``
+is honoured by both scripts (Q14); ``--print_misclassified_test_images`` does what its name says
+(Q13); with no network the backbone is random-init (``--model_dir`` weights are loaded when a
+converted ``inception_v3_weights.npz`` is present).
+"""
+from __future__ import annotations
+
+import os
+import random
+import shutil
+import sys
+import time
+from datetime import datetime
+from typing import List, Optional
+
+import numpy as np
+
+DATA_URL = "http://download.tensorflow.org/models/image/imagenet/inception-2015-12-05.tgz"  # retrain1/retrain.py:27
+
+
+def maybe_download_and_extract(model_dir: str, allow_network: bool = False) -> Optional[str]:
+    """``maybe_download_and_extract`` (``retrain1/retrain.py:47-62``).  Kept optional: build/CI boxes have
+    no network, in which case the backbone stays random-init.  Returns the extracted ``.pb`` path if present."""
+    os.makedirs(model_dir, exist_ok=True)
+    filename = DATA_URL.split("/")[-1]
+    filepath = os.path.join(model_dir, filename)
+    pb = os.path.join(model_dir, "classify_image_graph_def.pb")
+    if os.path.exists(pb):
+        return pb
+    if not os.path.exists(filepath) and allow_network:
+        import tarfile
+        import urllib.request
+
+        def _progress(count, block_size, total_size):
+            sys.stdout.write("\r>> Downloading %s %.1f%%" % (filename, float(count * block_size) / float(total_size) * 100.0))
+            sys.stdout.flush()
+        try:
+            filepath, _ = urllib.request.urlretrieve(DATA_URL, filepath, _progress)
+            print("\nSuccessfully downloaded", filename, os.stat(filepath).st_size, "bytes.")
+            tarfile.open(filepath, "r:gz").extractall(model_dir)
+        except Exception as e:  # noqa: BLE001
+            print("download failed (%r): using a random-init backbone" % (e,))
+    return pb if os.path.exists(pb) else None
+
+
+def _log(rank: int, msg: str) -> None:
+    if rank == 0:
+        print(msg, flush=True)
+
+
+def _head_summary(head, prefix_scalars, logits_probs=None):
+    from ..utils.summary import Summary, variable_summaries
+    s = Summary()
+    s.merge(variable_summaries("final_training_ops/weights", head.weights))
+    s.merge(variable_summaries("final_training_ops/biases", head.biases))
+    for k, v in prefix_scalars.items():
+        s.scalar(k, v)
+    if logits_probs is not None:
+        s.histogram("activations", logits_probs)
+    return s
+
+
+def run(FLAGS, distributed: bool) -> int:
+    import torch
+
+    from ..data import image_lists as il
+    from ..data.bottleneck import (BottleneckCache, Distortion, ImagePreprocessor, get_random_distorted_bottlenecks)
+    from ..models.retrain_head import RetrainHead, TinyBackbone
+    from ..parallel import cluster as cl
+    from ..parallel.ddp import init_process_group
+    from ..utils import checkpoint as ckpt
+    from ..utils.summary import FileWriter
+
+    begin_time = time.time()
+    rank, world, server = 0, 1, None
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if distributed and under_launcher:
+        rank, world = init_process_group(FLAGS.backend)
+    elif distributed:
+        if FLAGS.num_gpus and FLAGS.num_gpus > 1:
+            from ..parallel.launcher import spawn_local_workers
+            return spawn_local_workers(sys.argv[0], [a for a in sys.argv[1:] if not a.startswith("--num_gpus")],
+                                       FLAGS.num_gpus)
+        spec = cl.ClusterSpec.from_flags(FLAGS.ps_hosts, FLAGS.worker_hosts)
+        server = cl.Server(spec, FLAGS.job_name, FLAGS.task_index, backend=FLAGS.backend)
+        if FLAGS.job_name == "ps":
+            server.join()
+            return 0
+        rank, world = server.init_collectives()
+    device = cl.bind_device(rank, FLAGS.device)
+    seed = FLAGS.seed if FLAGS.seed is not None else 20151205
+    rng = random.Random(seed * 7919 + rank)
+
+    if rank == 0:  # Q9: only one process wipes the summaries dir
+        if os.path.exists(FLAGS.summaries_dir):
+            shutil.rmtree(FLAGS.summaries_dir)
+        os.makedirs(FLAGS.summaries_dir, exist_ok=True)
+
+    # ---- data: real image_dir, or a generated separable synthetic set (BASELINE config 3)
+    image_dir = FLAGS.image_dir
+    if FLAGS.synthetic or not os.path.exists(image_dir):
+        if not FLAGS.synthetic and FLAGS.synthetic is not None:
+            print("Image directory '" + image_dir + "' not found.")
+            return -1
+        image_dir = os.path.join(FLAGS.bottleneck_dir, "_synthetic_images")
+        if rank == 0 and not os.path.exists(image_dir):
+            il.make_synthetic_image_dir(image_dir, num_classes=FLAGS.synthetic_classes,
+                                        images_per_class=FLAGS.synthetic_images_per_class, seed=seed)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        _log(rank, "using synthetic image set at " + image_dir)
+    image_lists = il.create_image_lists(image_dir, FLAGS.testing_percentage, FLAGS.validation_percentage,
+                                        verbose=(rank == 0))
+    class_count = len(image_lists.keys())
+    if class_count == 0:
+        print("No valid folders of images found at " + image_dir)
+        return -1
+    if class_count == 1:
+        print("Only one valid folder of images found at " + image_dir +
+              " - multiple classes are needed for classification.")
+        return -1
+    index = il.build_image_index(image_lists, image_dir)
+
+    # ---- backbone
+    backbone_kind = getattr(FLAGS, "backbone", "auto")
+    if backbone_kind == "auto":
+        backbone_kind = "inception" if device.type == "cuda" else "tiny"
+    if backbone_kind == "inception":
+        from ..models.inception_v3 import InceptionV3
+        maybe_download_and_extract(FLAGS.model_dir)
+        net = InceptionV3(device, seed=seed)
+        npz = os.path.join(FLAGS.model_dir, "inception_v3_weights.npz")
+        if os.path.exists(npz):
+            z = np.load(npz)
+            layers = {}
+            for k in z.files:
+                layer, field = k.rsplit("__", 1)
+                layers.setdefault(layer.replace("__", "/"), {})[field] = z[k]
+            net.load_tf_weights(layers)
+            _log(rank, "loaded Inception-v3 weights from " + npz)
+        else:
+            _log(rank, "Inception-v3 backbone: random-init weights (no pretrained artefact offline)")
+        backbone = net.forward
+    else:
+        backbone = TinyBackbone(device, seed=seed)
+    preproc = ImagePreprocessor(device)
+
+    head = RetrainHead(class_count, device, learning_rate=FLAGS.learning_rate, double_softmax=FLAGS.double_softmax,
+                       seed=seed, final_tensor_name=FLAGS.final_tensor_name)
+    head.world = world
+    if world > 1:
+        import torch.distributed as dist
+        dist.broadcast(head.P, src=0)
+
+    distortion = Distortion(FLAGS.flip_left_right, FLAGS.random_crop, FLAGS.random_scale, FLAGS.random_brightness)
+    cache = BottleneckCache(index, device)
+    t_extract = time.time()
+    created = cache.extract(backbone, preproc, batch_size=FLAGS.extract_batch_size, rank=rank, world=world,
+                            txt_dir=FLAGS.bottleneck_dir if FLAGS.bottleneck_txt_cache else None,
+                            progress=(print if rank == 0 else None))
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    dt = time.time() - t_extract
+    _log(rank, "bottleneck extraction: %d images on this rank in %.2fs (%.1f images/sec/rank, HBM cache %.1f MB)" % (
+        created, dt, created / max(dt, 1e-9), cache.values.numel() * 4 / 1e6))
+
+    train_writer = validation_writer = None
+    if rank == 0:
+        graph = {"model": "inception_v3->softmax", "classes": list(image_lists.keys()), "backbone": backbone_kind}
+        train_writer = FileWriter(os.path.join(FLAGS.summaries_dir, "train"), graph)
+        validation_writer = FileWriter(os.path.join(FLAGS.summaries_dir, "validation"))
+
+    # Supervisor-equivalent for the head (retrain2): resume from ./retrain_logs/../logs is not part of the reference
+    start_time = time.time()
+    steps = FLAGS.training_steps
+    for i in range(steps):
+        if distortion.enabled:
+            feats, labels = get_random_distorted_bottlenecks(index, FLAGS.train_batch_size, "training", backbone,
+                                                             preproc, distortion, rng)
+            B = head.train_step(feats, labels, None)
+            train_src = (feats, labels, None)
+        else:
+            rows = cache.sample_rows("training", FLAGS.train_batch_size, seed=seed + rank)
+            B = head.train_step(cache.values, cache.labels, rows)
+            train_src = (cache.values, cache.labels, rows)
+        is_last_step = (i + 1 == steps)
+        log_now = (i % FLAGS.eval_step_interval) == 0 or is_last_step
+        if log_now or (train_writer is not None and i % max(1, FLAGS.eval_step_interval) == 0):
+            # metrics of the training batch after the update (what the reference's second sess.run reports)
+            ce, train_acc = head.evaluate(*train_src)
+            vrows = cache.sample_rows("validation", FLAGS.validation_batch_size, seed=seed + 977)
+            vce, val_acc = head.evaluate(cache.values, cache.labels, vrows)
+            if world > 1:
+                import torch.distributed as dist
+                t = torch.tensor([ce, train_acc, vce, val_acc], dtype=torch.float64, device=device)
+                dist.all_reduce(t)
+                ce, train_acc, vce, val_acc = (t / world).tolist()
+            if train_writer is not None:
+                train_writer.add_summary(_head_summary(head, {"cross_entropy": ce, "accuracy": train_acc}), i)
+                validation_writer.add_summary(_head_summary(head, {"cross_entropy": vce, "accuracy": val_acc}), i)
+            if log_now:
+                _log(rank, "%s: Step %d: Train accuracy = %.1f%% Cross entropy = %f Validation accuracy = %.1f%%%s" % (
+                    datetime.now(), i, train_acc * 100, ce, val_acc * 100,
+                    " (N=%d)" % FLAGS.validation_batch_size if distributed else ""))
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    train_time = time.time() - start_time
+
+    test_rows = cache.sample_rows("testing", FLAGS.test_batch_size, seed=seed + 31337)
+    if test_rows.numel() > 0:
+        _ce, test_accuracy, probs, pred = head.evaluate(cache.values, cache.labels, test_rows, want_probs=True)
+        _log(rank, "Final test accuracy = %.1f%% " % (test_accuracy * 100))
+        if FLAGS.print_misclassified_test_images and rank == 0:
+            print("=== MISCLASSIFIED TEST IMAGES ===")
+            truth = cache.labels.index_select(0, test_rows.long()).cpu().tolist()
+            labels = list(image_lists.keys())
+            for f, p, t in zip(cache.filenames(test_rows), pred.cpu().tolist(), truth):
+                if p != t:
+                    print("%70s  %s" % (f, labels[p]))
+    else:
+        test_accuracy = float("nan")
+        _log(rank, "Final test accuracy = n/a (empty testing split)")
+    _log(rank, "Training time: %3.2fs" % train_time)
+    if steps:
+        _log(rank, "Head training throughput: %.1f bottleneck-images/sec (global batch %d)" % (
+            steps * FLAGS.train_batch_size * world / max(train_time, 1e-9), FLAGS.train_batch_size * world))
+
+    if rank == 0:
+        tensors = dict(head.tf_tensors())
+        tensors["_dtf/final_tensor_name"] = np.frombuffer(FLAGS.final_tensor_name.encode(), np.uint8).copy()
+        tensors["_dtf/backbone"] = np.frombuffer(backbone_kind.encode(), np.uint8).copy()
+        tensors["_dtf/backbone_seed"] = np.asarray(seed, np.int64)
+        tensors["_dtf/labels"] = np.frombuffer("\n".join(image_lists.keys()).encode(), np.uint8).copy()
+        ckpt.save_tensors(FLAGS.output_graph, tensors)
+        with open(FLAGS.output_labels, "w") as f:
+            f.write("\n".join(image_lists.keys()) + "\n")
+        train_writer.close()
+        validation_writer.close()
+    _log(rank, "Total time: %3.2fs:" % (time.time() - begin_time))
+    if server is not None:
+        server.report_done()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def main(argv: Optional[List[str]] = None, distributed: bool = False) -> int:
+    from .. import flags
+    parser = flags.build_retrain_parser(distributed)
+    parser.add_argument("--backbone", type=str, default="auto", help="auto | inception | tiny (CPU plumbing)")
+    FLAGS, _unparsed = flags.parse_known(parser, argv)
+    return run(FLAGS, distributed)

@@ -1,0 +1,83 @@
+"""Retrained-classifier inference driver (``retrain1/test.py`` / ``retrain2/test.py``, component C40).
+
+Reference (``retrain1/test.py:10-59``): read ``retrained_labels.txt``, import the frozen graph, and for
+every file under ``imgs`` feed the raw JPEG, fetch ``final_result:0``, show the image, print every class
+sorted by score and the top-1.  Here all images are decoded on host threads, preprocessed and pushed
+through the batched backbone + head in one go; display is opt-in and headless-safe.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+from typing import List
+
+import numpy as np
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="Classify images with a retrained bundle")
+    p.add_argument("--imgs", type=str, default="imgs")
+    p.add_argument("--graph", type=str, default="retrained_graph.pb")
+    p.add_argument("--labels", type=str, default="retrained_labels.txt")
+    p.add_argument("--device", type=str, default="auto")
+    p.add_argument("--show", action="store_true")
+    return p
+
+
+def run(args) -> List[str]:
+    import torch
+
+    from ..data.bottleneck import ImagePreprocessor
+    from ..data.imageprepare import walk_images
+    from ..models.retrain_head import RetrainHead, TinyBackbone
+    from ..utils import checkpoint as ckpt
+
+    lines = open(args.labels).readlines()
+    uid_to_human = {uid: line.strip("\n") for uid, line in enumerate(lines)}  # retrain1/test.py:10-16
+    t = ckpt.load_tensors(args.graph)
+    backbone_kind = bytes(t["_dtf/backbone"]).decode()
+    seed = int(t["_dtf/backbone_seed"])
+    use_cuda = torch.cuda.is_available() and args.device != "cpu"
+    device = torch.device("cuda" if use_cuda else "cpu")
+    C = t["final_training_ops/biases/final_biases"].shape[0]
+    head = RetrainHead(C, device)
+    head.load_tf_tensors(t)
+    if backbone_kind == "inception":
+        if not use_cuda:
+            raise RuntimeError("this bundle was trained on the Inception-v3 backbone, which needs the GPU path")
+        from ..models.inception_v3 import InceptionV3
+        backbone = InceptionV3(device, seed=seed).forward
+    else:
+        backbone = TinyBackbone(device, seed=seed)
+    files = walk_images(args.imgs, (".jpg", ".jpeg"))
+    if not files:
+        raise FileNotFoundError("no JPEG images under %r" % args.imgs)
+    x = ImagePreprocessor(device).load(files)
+    probs = head.predict(backbone(x)).cpu().numpy()
+    top1 = []
+    for f, p in zip(files, probs):
+        print(f)
+        if args.show:
+            try:
+                import matplotlib
+                if not os.environ.get("DISPLAY"):
+                    matplotlib.use("Agg")
+                import matplotlib.pyplot as plt
+                from PIL import Image
+                plt.imshow(Image.open(f))
+                plt.axis("off")
+                plt.show()
+            except Exception as e:  # noqa: BLE001
+                print("(display skipped: %r)" % (e,))
+        top_k = p.argsort()[::-1]
+        for node_id in top_k:
+            print("%s (score = %.5f)" % (uid_to_human[int(node_id)], p[node_id]))
+        print("=> " + uid_to_human[int(top_k[0])])
+        print()
+        top1.append(uid_to_human[int(top_k[0])])
+    return top1
+
+
+def main(argv=None):
+    args, _ = build_parser().parse_known_args(argv)
+    return run(args)

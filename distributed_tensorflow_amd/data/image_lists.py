@@ -54,7 +54,7 @@ def create_image_lists(image_dir: str, testing_percentage: int, validation_perce
         raise ImageDirError("Image directory '" + image_dir + "' not found.")
     result: "OrderedDict[str, Dict[str, object]]" = OrderedDict()
     sub_dirs = [x[0] for x in os.walk(image_dir)]
-    for sub_dir in sub_dirs[1:]:  # first entry is the root itself
+    for sub_dir in sorted(sub_dirs[1:]):  # sorted: the label order (= class ids) must not depend on the filesystem  # first entry is the root itself
         dir_name = os.path.basename(sub_dir)
         if dir_name == image_dir:
             continue
@@ -62,7 +62,7 @@ def create_image_lists(image_dir: str, testing_percentage: int, validation_perce
             print("Looking for images in '" + dir_name + "'")
         file_list: List[str] = []
         for extension in EXTENSIONS:
-            file_list.extend(glob.glob(os.path.join(image_dir, dir_name, "*." + extension)))
+            file_list.extend(sorted(glob.glob(os.path.join(image_dir, dir_name, "*." + extension))))
         if not file_list:
             if verbose:
                 print("No files found")

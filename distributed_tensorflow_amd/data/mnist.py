@@ -193,9 +193,11 @@ def read_data_sets(train_dir: str, one_hot: bool = True, validation_size: int = 
                    synthetic_test_size: int = 10000) -> Datasets:
     """Equivalent of ``input_data.read_data_sets`` (``demo1/train.py:6``).
 
-    ``synthetic=None`` (auto): real IDX files are used when all four exist; when only
-    the train images are missing (the shipped tree) the test split stays real and the
-    train split is synthesised, unless ``train_on_t10k`` carves 8 000/1 000/1 000 out of t10k.
+    ``synthetic=None`` (auto): the real IDX files are used when all four exist; when the train
+    images are missing (the shipped tree, ``.MISSING_LARGE_BLOBS``) but t10k is present, the real
+    t10k images are split 8 000 train / 1 000 validation / 1 000 test so accuracies are still
+    measured on genuine handwriting; with no IDX files at all (or ``synthetic=True``) learnable
+    synthetic digits of the same shapes are generated.
     """
     p = lambda name: os.path.join(train_dir, name)  # noqa: E731
     have_test = os.path.exists(p(TEST_IMAGES)) and os.path.exists(p(TEST_LABELS))
@@ -206,20 +208,15 @@ def read_data_sets(train_dir: str, one_hot: bool = True, validation_size: int = 
         tr_i, tr_l = synthetic_mnist(synthetic_train_size, seed=s0 + 1)
         te_i, te_l = synthetic_mnist(synthetic_test_size, seed=s0 + 2)
         source = "synthetic"
-    elif have_train:
+    elif have_train and not train_on_t10k:
         tr_i, tr_l = read_idx_images(p(TRAIN_IMAGES)), read_idx_labels(p(TRAIN_LABELS))
         te_i, te_l = read_idx_images(p(TEST_IMAGES)), read_idx_labels(p(TEST_LABELS))
-    elif train_on_t10k:
+    else:
         all_i, all_l = read_idx_images(p(TEST_IMAGES)), read_idx_labels(p(TEST_LABELS))
         tr_i, tr_l = all_i[:9000], all_l[:9000]
         te_i, te_l = all_i[9000:], all_l[9000:]
         validation_size = min(validation_size, 1000)
         source = "t10k-split"
-    else:
-        s0 = 0 if seed is None else seed
-        tr_i, tr_l = synthetic_mnist(synthetic_train_size, seed=s0 + 1)
-        te_i, te_l = synthetic_mnist(synthetic_test_size, seed=s0 + 2)
-        source = "synthetic"
     if not 0 <= validation_size <= len(tr_i):
         raise ValueError("Validation size should be between 0 and %d. Received: %d."
                          % (len(tr_i), validation_size))

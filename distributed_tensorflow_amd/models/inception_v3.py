@@ -1,0 +1,353 @@
+"""Inception-v3 (2015-12-05 ``classify_image_graph_def.pb`` topology) — forward to the 2048-d
+``pool_3/_reshape`` bottleneck (components C28, C31).
+
+The reference imports the frozen TensorFlow graph and runs it one image per ``sess.run``
+(``retrain1/retrain.py:66-74,228-231``).  Here the network is stated natively as a small op
+program over named NHWC bf16 buffers and executed in *batches* on the GPU:
+
+* every conv = implicit-GEMM MFMA kernel with the inference BatchNorm folded into the packed
+  bf16 weights + fp32 bias and ReLU in the epilogue (``dtf_conv_bias_relu``);
+* branch outputs are written straight into their channel slice of the block's output buffer —
+  there is no concat kernel and no concat copy;
+* pools are vectorised NHWC kernels (``csrc/hip/inception_ops.hip``); the final 8x8 average pool
+  emits the fp32 bottleneck rows that go into the HBM-resident cache;
+* the whole forward for a fixed batch size is captured once into a hipGraph (≈110 launches).
+
+Weights are random-init (He-normal convs, identity BatchNorm statistics) because the pretrained
+``.pb`` cannot be downloaded here (``maybe_download_and_extract``, ``retrain1/retrain.py:47-62``);
+``load_tf_weights`` accepts a ``{layer: {weights, beta, moving_mean, moving_variance}}`` dict for
+when the artefact is available.  ``reference_forward`` is the PyTorch fp32 oracle of the same graph.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BOTTLENECK_TENSOR_SIZE = 2048      # retrain1/retrain.py:31
+MODEL_INPUT_WIDTH = 299            # :32
+MODEL_INPUT_HEIGHT = 299           # :33
+MODEL_INPUT_DEPTH = 3              # :34
+INPUT_PAD_CHANNELS = 8             # NHWC input is zero-padded 3 -> 8 channels (16-byte gathers)
+BN_EPS = 1e-3
+
+
+@dataclass
+class ConvSpec:
+    name: str
+    cin: int
+    cout: int
+    kh: int
+    kw: int
+    stride: int
+    pad: Tuple[int, int]
+
+
+@dataclass
+class Op:
+    kind: str            # conv | maxpool | avgpool | gap
+    src: str
+    dst: str
+    src_off: int = 0     # channel offset inside src
+    dst_off: int = 0     # channel offset inside dst
+    conv: Optional[ConvSpec] = None
+    channels: int = 0    # for pools
+    stride: int = 1
+
+
+class _Builder:
+    def __init__(self):
+        self.ops: List[Op] = []
+        self.shapes: "OrderedDict[str, Tuple[int, int, int]]" = OrderedDict()  # buffer -> (H, W, C)
+        self.convs: "OrderedDict[str, ConvSpec]" = OrderedDict()
+
+    def buffer(self, name: str, h: int, w: int, c: int) -> str:
+        self.shapes[name] = (h, w, c)
+        return name
+
+    def conv(self, name, src, cout, k, stride=1, padding="SAME", dst=None, dst_off=0, src_off=0, cin=None):
+        kh, kw = (k, k) if isinstance(k, int) else k
+        h, w, c_total = self.shapes[src]
+        cin = c_total if cin is None else cin
+        ph, pw = ((kh - 1) // 2, (kw - 1) // 2) if padding == "SAME" else (0, 0)
+        ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
+        if dst is None:
+            dst = self.buffer(name + ":out", ho, wo, cout)
+        assert self.shapes[dst][:2] == (ho, wo), (name, self.shapes[dst], ho, wo)
+        spec = ConvSpec(name, cin, cout, kh, kw, stride, (ph, pw))
+        self.convs[name] = spec
+        self.ops.append(Op("conv", src, dst, src_off, dst_off, spec))
+        return dst
+
+    def maxpool(self, name, src, stride=2, dst=None, dst_off=0):
+        h, w, c = self.shapes[src]
+        ho, wo = (h - 3) // stride + 1, (w - 3) // stride + 1
+        if dst is None:
+            dst = self.buffer(name + ":out", ho, wo, c)
+        self.ops.append(Op("maxpool", src, dst, 0, dst_off, None, c, stride))
+        return dst
+
+    def avgpool(self, name, src):
+        h, w, c = self.shapes[src]
+        dst = self.buffer(name + ":out", h, w, c)
+        self.ops.append(Op("avgpool", src, dst, 0, 0, None, c, 1))
+        return dst
+
+
+def build_graph() -> _Builder:
+    g = _Builder()
+    x = g.buffer("input", 299, 299, INPUT_PAD_CHANNELS)
+    x = g.conv("conv", x, 32, 3, 2, "VALID")          # 149
+    x = g.conv("conv_1", x, 32, 3, 1, "VALID")        # 147
+    x = g.conv("conv_2", x, 64, 3, 1, "SAME")         # 147
+    x = g.maxpool("pool", x, 2)                       # 73
+    x = g.conv("conv_3", x, 80, 1, 1, "VALID")        # 73
+    x = g.conv("conv_4", x, 192, 3, 1, "VALID")       # 71
+    x = g.maxpool("pool_1", x, 2)                     # 35
+
+    def block_a(name, src, pool_proj):
+        h, w, _ = g.shapes[src]
+        out = g.buffer(name, h, w, 64 + 64 + 96 + pool_proj)
+        g.conv(name + "/conv", src, 64, 1, dst=out, dst_off=0)
+        t = g.conv(name + "/tower/conv", src, 48, 1)
+        g.conv(name + "/tower/conv_1", t, 64, 5, dst=out, dst_off=64)
+        t = g.conv(name + "/tower_1/conv", src, 64, 1)
+        t = g.conv(name + "/tower_1/conv_1", t, 96, 3)
+        g.conv(name + "/tower_1/conv_2", t, 96, 3, dst=out, dst_off=128)
+        t = g.avgpool(name + "/tower_2/pool", src)
+        g.conv(name + "/tower_2/conv", t, pool_proj, 1, dst=out, dst_off=224)
+        return out
+
+    x = block_a("mixed", x, 32)       # 256
+    x = block_a("mixed_1", x, 64)     # 288
+    x = block_a("mixed_2", x, 64)     # 288
+
+    # mixed_3: 35 -> 17, 768 channels
+    h, w, c = g.shapes[x]
+    out = g.buffer("mixed_3", 17, 17, 384 + 96 + c)
+    g.conv("mixed_3/conv", x, 384, 3, 2, "VALID", dst=out, dst_off=0)
+    t = g.conv("mixed_3/tower/conv", x, 64, 1)
+    t = g.conv("mixed_3/tower/conv_1", t, 96, 3)
+    g.conv("mixed_3/tower/conv_2", t, 96, 3, 2, "VALID", dst=out, dst_off=384)
+    g.maxpool("mixed_3/pool", x, 2, dst=out, dst_off=480)
+    x = out
+
+    def block_c(name, src, c7):
+        out = g.buffer(name, 17, 17, 768)
+        g.conv(name + "/conv", src, 192, 1, dst=out, dst_off=0)
+        t = g.conv(name + "/tower/conv", src, c7, 1)
+        t = g.conv(name + "/tower/conv_1", t, c7, (1, 7))
+        g.conv(name + "/tower/conv_2", t, 192, (7, 1), dst=out, dst_off=192)
+        t = g.conv(name + "/tower_1/conv", src, c7, 1)
+        t = g.conv(name + "/tower_1/conv_1", t, c7, (7, 1))
+        t = g.conv(name + "/tower_1/conv_2", t, c7, (1, 7))
+        t = g.conv(name + "/tower_1/conv_3", t, c7, (7, 1))
+        g.conv(name + "/tower_1/conv_4", t, 192, (1, 7), dst=out, dst_off=384)
+        t = g.avgpool(name + "/tower_2/pool", src)
+        g.conv(name + "/tower_2/conv", t, 192, 1, dst=out, dst_off=576)
+        return out
+
+    x = block_c("mixed_4", x, 128)
+    x = block_c("mixed_5", x, 160)
+    x = block_c("mixed_6", x, 160)
+    x = block_c("mixed_7", x, 192)
+
+    # mixed_8: 17 -> 8, 1280 channels
+    out = g.buffer("mixed_8", 8, 8, 320 + 192 + 768)
+    t = g.conv("mixed_8/tower/conv", x, 192, 1)
+    g.conv("mixed_8/tower/conv_1", t, 320, 3, 2, "VALID", dst=out, dst_off=0)
+    t = g.conv("mixed_8/tower_1/conv", x, 192, 1)
+    t = g.conv("mixed_8/tower_1/conv_1", t, 192, (1, 7))
+    t = g.conv("mixed_8/tower_1/conv_2", t, 192, (7, 1))
+    g.conv("mixed_8/tower_1/conv_3", t, 192, 3, 2, "VALID", dst=out, dst_off=320)
+    g.maxpool("mixed_8/pool", x, 2, dst=out, dst_off=512)
+    x = out
+
+    def block_e(name, src):
+        out = g.buffer(name, 8, 8, 2048)
+        g.conv(name + "/conv", src, 320, 1, dst=out, dst_off=0)
+        t = g.conv(name + "/tower/conv", src, 384, 1)
+        g.conv(name + "/tower/mixed/conv", t, 384, (1, 3), dst=out, dst_off=320)
+        g.conv(name + "/tower/mixed/conv_1", t, 384, (3, 1), dst=out, dst_off=704)
+        t = g.conv(name + "/tower_1/conv", src, 448, 1)
+        t = g.conv(name + "/tower_1/conv_1", t, 384, 3)
+        g.conv(name + "/tower_1/mixed/conv", t, 384, (1, 3), dst=out, dst_off=1088)
+        g.conv(name + "/tower_1/mixed/conv_1", t, 384, (3, 1), dst=out, dst_off=1472)
+        t = g.avgpool(name + "/tower_2/pool", src)
+        g.conv(name + "/tower_2/conv", t, 192, 1, dst=out, dst_off=1856)
+        return out
+
+    x = block_e("mixed_9", x)
+    x = block_e("mixed_10", x)
+    g.ops.append(Op("gap", x, "pool_3", 0, 0, None, 2048, 1))
+    return g
+
+
+def graph_flops(g: _Builder) -> float:
+    """Forward FLOPs per image (2 x MACs)."""
+    total = 0.0
+    for op in g.ops:
+        if op.kind == "conv":
+            ho, wo, _ = g.shapes[op.dst]
+            s = op.conv
+            cin = 3 if s.name == "conv" else s.cin
+            total += 2.0 * ho * wo * s.cout * s.kh * s.kw * cin
+    return total
+
+
+class InceptionV3:
+    """Weights + native batched executor."""
+
+    def __init__(self, device="cuda", seed: Optional[int] = 0):
+        self.graph = build_graph()
+        self.device = torch.device(device)
+        self.params: "OrderedDict[str, Dict[str, torch.Tensor]]" = OrderedDict()
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(0 if seed is None else seed)
+        for name, s in self.graph.convs.items():
+            cin_real = MODEL_INPUT_DEPTH if name == "conv" else s.cin
+            fan_in = s.kh * s.kw * cin_real
+            w = torch.empty(s.kh, s.kw, cin_real, s.cout)
+            torch.nn.init.trunc_normal_(w, std=math.sqrt(2.0 / fan_in), a=-2 * math.sqrt(2.0 / fan_in),
+                                        b=2 * math.sqrt(2.0 / fan_in), generator=gen)
+            self.params[name] = {"weights": w, "beta": torch.zeros(s.cout), "moving_mean": torch.zeros(s.cout),
+                                 "moving_variance": torch.ones(s.cout), "gamma": torch.ones(s.cout)}
+        self._packed: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._buffers: Dict[int, Dict[str, torch.Tensor]] = {}
+        self._graphs: Dict[int, object] = {}
+        self._static_in: Dict[int, torch.Tensor] = {}
+        self._static_out: Dict[int, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ weights
+    @property
+    def num_params(self) -> int:
+        return sum(int(p["weights"].numel()) + 2 * int(p["beta"].numel()) for p in self.params.values())
+
+    def load_tf_weights(self, tensors: Dict[str, Dict[str, np.ndarray]]) -> None:
+        for name, d in tensors.items():
+            if name not in self.params:
+                raise KeyError("unknown Inception layer %r" % name)
+            for k, v in d.items():
+                t = torch.as_tensor(np.asarray(v), dtype=torch.float32)
+                if t.shape != self.params[name][k].shape:
+                    raise ValueError("%s/%s: shape %s != %s" % (name, k, tuple(t.shape), tuple(self.params[name][k].shape)))
+                self.params[name][k] = t
+        self._packed.clear()
+
+    def folded(self, name: str) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(HWIO fp32 weights with BN folded, fp32 bias)."""
+        p = self.params[name]
+        scale = p["gamma"] / torch.sqrt(p["moving_variance"] + BN_EPS)
+        return p["weights"] * scale.view(1, 1, 1, -1), p["beta"] - p["moving_mean"] * scale
+
+    def packed(self, name: str) -> Tuple[torch.Tensor, torch.Tensor]:
+        """bf16 [Cout][KH*KW*Cin_padded] + fp32 bias on the device (what the HIP conv consumes)."""
+        if name not in self._packed:
+            s = self.graph.convs[name]
+            w, b = self.folded(name)
+            if w.shape[2] != s.cin:  # first conv: pad 3 -> 8 input channels with zeros
+                w = torch.cat([w, torch.zeros(s.kh, s.kw, s.cin - w.shape[2], s.cout)], dim=2)
+            wp = w.permute(3, 0, 1, 2).reshape(s.cout, s.kh * s.kw * s.cin).contiguous()
+            self._packed[name] = (wp.to(self.device, torch.bfloat16).contiguous(), b.to(self.device, torch.float32).contiguous())
+        return self._packed[name]
+
+    # ------------------------------------------------------------------ native execution
+    def _alloc(self, B: int) -> Dict[str, torch.Tensor]:
+        if B not in self._buffers:
+            bufs = {}
+            for name, (h, w, c) in self.graph.shapes.items():
+                if name == "input":
+                    continue
+                bufs[name] = torch.zeros(B, h, w, c, dtype=torch.bfloat16, device=self.device)
+            bufs["pool_3"] = torch.zeros(B, BOTTLENECK_TENSOR_SIZE, dtype=torch.float32, device=self.device)
+            self._buffers[B] = bufs
+        return self._buffers[B]
+
+    def _run_ops(self, x: torch.Tensor, bufs: Dict[str, torch.Tensor]) -> torch.Tensor:
+        from .. import native
+        from ..ops import hip_ops
+        lib = native.hip()
+        st = torch.cuda.current_stream().cuda_stream
+        B = x.shape[0]
+        for op in self.graph.ops:
+            src = x if op.src == "input" else bufs[op.src]
+            if op.kind == "conv":
+                s = op.conv
+                wp, b = self.packed(s.name)
+                hip_ops.conv_bias_relu(src, wp, b, Cin=s.cin, KH=s.kh, KW=s.kw, stride=s.stride, pad=s.pad, relu=True,
+                                       out=bufs[op.dst], out_channel_offset=op.dst_off, in_channel_offset=op.src_off)
+            elif op.kind == "maxpool":
+                dst = bufs[op.dst]
+                _, H, W, Cs = src.shape
+                native.check(lib.dtf_maxpool3x3(src.data_ptr(), dst.data_ptr() + 2 * op.dst_off, B, H, W, op.channels, Cs,
+                                                dst.shape[3], op.stride, st), "maxpool")
+            elif op.kind == "avgpool":
+                dst = bufs[op.dst]
+                _, H, W, Cs = src.shape
+                native.check(lib.dtf_avgpool3x3_same(src.data_ptr(), dst.data_ptr(), B, H, W, op.channels, Cs, dst.shape[3], st),
+                             "avgpool")
+            elif op.kind == "gap":
+                _, H, W, Cs = src.shape
+                native.check(lib.dtf_global_avgpool(src.data_ptr(), bufs["pool_3"].data_ptr(), B, H * W, Cs, st), "gap")
+        return bufs["pool_3"]
+
+    def forward(self, x: torch.Tensor, use_graph: bool = True) -> torch.Tensor:
+        """bf16 NHWC ``[B,299,299,8]`` -> fp32 bottlenecks ``[B,2048]`` (a fresh tensor)."""
+        assert x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1:] == (299, 299, INPUT_PAD_CHANNELS) and x.is_contiguous()
+        B = x.shape[0]
+        bufs = self._alloc(B)
+        if not use_graph:
+            return self._run_ops(x, bufs).clone()
+        if B not in self._graphs:
+            for s in self.graph.convs:
+                self.packed(s)  # upload weights outside the capture
+            self._static_in[B] = torch.zeros_like(x)
+            self._static_in[B].copy_(x)
+            self._run_ops(self._static_in[B], bufs)  # warm-up (lazy module loads) before capturing
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._static_out[B] = self._run_ops(self._static_in[B], bufs)
+            self._graphs[B] = g
+        self._static_in[B].copy_(x)
+        self._graphs[B].replay()
+        return self._static_out[B].clone()
+
+
+# ----------------------------------------------------------------------------------- oracle
+@torch.no_grad()
+def reference_forward(model: InceptionV3, x_nchw: torch.Tensor, bf16_sim: bool = False,
+                      return_buffers: bool = False):
+    """Plain PyTorch fp32 forward of the same op program.  ``x_nchw`` fp32 ``[B,3,299,299]`` already
+    normalised.  ``bf16_sim`` rounds weights and every stored activation to bf16 like the native path."""
+    r = (lambda t: t.to(torch.bfloat16).float()) if bf16_sim else (lambda t: t)
+    g = model.graph
+    dev = x_nchw.device
+    bufs: Dict[str, torch.Tensor] = {"input": r(x_nchw)}
+    B = x_nchw.shape[0]
+    for op in g.ops:
+        src = bufs[op.src]
+        if op.kind == "conv":
+            s = op.conv
+            w, b = model.folded(s.name)
+            w = r(w.to(dev)).permute(3, 2, 0, 1)
+            cin = w.shape[1]
+            y = F.relu(F.conv2d(src[:, op.src_off:op.src_off + cin], w, b.to(dev), stride=s.stride, padding=s.pad))
+            y = r(y)
+        elif op.kind == "maxpool":
+            y = F.max_pool2d(src, 3, op.stride)
+        elif op.kind == "avgpool":
+            y = r(F.avg_pool2d(src, 3, 1, 1, count_include_pad=False))
+        elif op.kind == "gap":
+            bufs["pool_3"] = src.mean((2, 3))
+            continue
+        if op.dst not in bufs:
+            h, w_, c = g.shapes[op.dst]
+            bufs[op.dst] = torch.zeros(B, c, h, w_, device=dev)
+        bufs[op.dst][:, op.dst_off:op.dst_off + y.shape[1]] = y
+    return (bufs["pool_3"], bufs) if return_buffers else bufs["pool_3"]

@@ -115,6 +115,15 @@ def hip() -> C.CDLL:
         _sig(lib, "dtf_graph_launch", I, [P, P])
         _sig(lib, "dtf_graph_num_nodes", I, [P])
         _sig(lib, "dtf_graph_free", None, [P])
+        # Inception / retrain ops (csrc/hip/inception_ops.hip, retrain_head.hip).  Every exported function gets
+        # an explicit signature here: a missing one would make ctypes truncate 64-bit pointers to c_int.
+        _sig(lib, "dtf_preprocess_images", I, [P, P, P, I, I, P])
+        _sig(lib, "dtf_maxpool3x3", I, [P, P] + [I] * 7 + [P])
+        _sig(lib, "dtf_avgpool3x3_same", I, [P, P] + [I] * 6 + [P])
+        _sig(lib, "dtf_global_avgpool", I, [P, P, I, I, I, P])
+        _sig(lib, "dtf_sample_rows", I, [P, P, I, I, C.c_ulonglong, C.c_ulonglong, P, P])
+        _sig(lib, "dtf_retrain_head_fwd", I, [P, P])
+        _sig(lib, "dtf_retrain_head_bwd", I, [P, P, P, I, I, P, P, P, P, F, P])
         for extra in _HIP_EXTRA_SIGS:
             if hasattr(lib, extra[0]):
                 _sig(lib, *extra)

@@ -1,0 +1,180 @@
+"""Inception-v3 path on the GPU: generic implicit-GEMM conv geometries, pools, preprocessing, the full
+batched forward vs the PyTorch oracle, the retrain head kernels and the device sampler."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def relerr(a, b):
+    return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-12))
+
+
+GEOMS = [  # (H, W, Cin, Cout, kh, kw, stride, padding)
+    (35, 35, 192, 64, 1, 1, 1, "SAME"), (35, 35, 48, 64, 5, 5, 1, "SAME"), (35, 35, 288, 384, 3, 3, 2, "VALID"),
+    (17, 17, 128, 128, 1, 7, 1, "SAME"), (17, 17, 160, 192, 7, 1, 1, "SAME"), (8, 8, 448, 384, 3, 3, 1, "SAME"),
+    (8, 8, 384, 384, 1, 3, 1, "SAME"), (73, 73, 64, 80, 1, 1, 1, "VALID"), (20, 20, 8, 32, 3, 3, 2, "VALID"),
+]
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_conv_bias_relu_geometries(geom):
+    from distributed_tensorflow_amd.ops import hip_ops
+    H, W, Cin, Cout, kh, kw, stride, padding = geom
+    torch.manual_seed(hash(geom) % 1000)
+    B = 3
+    x = torch.randn(B, H, W, Cin, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(kh, kw, Cin, Cout, device=DEV) / (kh * kw * Cin) ** 0.5)
+    b = torch.randn(Cout, device=DEV) * 0.1
+    pad = ((kh - 1) // 2, (kw - 1) // 2) if padding == "SAME" else (0, 0)
+    wp = w.permute(3, 0, 1, 2).reshape(Cout, -1).to(torch.bfloat16).contiguous()
+    out = hip_ops.conv_bias_relu(x, wp, b, Cin=Cin, KH=kh, KW=kw, stride=stride, pad=pad)
+    ref = F.relu(F.conv2d(x.float().permute(0, 3, 1, 2), wp.float().view(Cout, kh, kw, Cin).permute(0, 3, 1, 2), b,
+                          stride=stride, padding=pad)).permute(0, 2, 3, 1)
+    assert out.shape == ref.shape
+    assert relerr(out, ref) < 1.5e-2
+
+
+def test_conv_channel_slices_concat_by_write():
+    from distributed_tensorflow_amd.ops import hip_ops
+    torch.manual_seed(0)
+    B, H, W = 2, 17, 17
+    x = torch.randn(B, H, W, 96, device=DEV).to(torch.bfloat16)
+    w = torch.randn(1, 1, 32, 64, device=DEV) / 6
+    wp = w.permute(3, 0, 1, 2).reshape(64, -1).to(torch.bfloat16).contiguous()
+    b = torch.zeros(64, device=DEV)
+    out = torch.full((B, H, W, 160), 7.0, device=DEV, dtype=torch.bfloat16)
+    hip_ops.conv_bias_relu(x, wp, b, Cin=32, KH=1, KW=1, out=out, out_channel_offset=96, in_channel_offset=64)
+    ref = F.relu(torch.einsum("bhwc,oc->bhwo", x[..., 64:96].float(), wp.float()))
+    assert relerr(out[..., 96:160], ref) < 1.5e-2
+    assert float((out[..., :96].float() - 7).abs().max()) == 0.0  # neighbours untouched
+
+
+def test_pools():
+    from distributed_tensorflow_amd import native
+    import distributed_tensorflow_amd.data.bottleneck  # noqa: F401 (registers signatures)
+    lib = native.hip()
+    st = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(1)
+    B, H, W, C = 2, 35, 35, 64
+    x = torch.randn(B, H, W, C, device=DEV).to(torch.bfloat16)
+    out = torch.zeros(B, 17, 17, 96, device=DEV, dtype=torch.bfloat16)
+    native.check(lib.dtf_maxpool3x3(x.data_ptr(), out.data_ptr() + 2 * 32, B, H, W, C, C, 96, 2, st), "maxpool")
+    ref = F.max_pool2d(x.float().permute(0, 3, 1, 2), 3, 2).permute(0, 2, 3, 1)
+    assert relerr(out[..., 32:96], ref) == 0.0
+    out2 = torch.zeros(B, H, W, C, device=DEV, dtype=torch.bfloat16)
+    native.check(lib.dtf_avgpool3x3_same(x.data_ptr(), out2.data_ptr(), B, H, W, C, C, C, st), "avgpool")
+    ref2 = F.avg_pool2d(x.float().permute(0, 3, 1, 2), 3, 1, 1, count_include_pad=False).permute(0, 2, 3, 1)
+    assert relerr(out2, ref2) < 1e-2
+    y = torch.randn(B, 8, 8, 2048, device=DEV).to(torch.bfloat16)
+    gap = torch.zeros(B, 2048, device=DEV)
+    native.check(lib.dtf_global_avgpool(y.data_ptr(), gap.data_ptr(), B, 64, 2048, st), "gap")
+    assert relerr(gap, y.float().mean((1, 2))) < 1e-5
+
+
+def test_preprocess_plain_and_distorted():
+    from distributed_tensorflow_amd.data.bottleneck import Distortion, ImageDesc, ImagePreprocessor, preprocess_reference
+    rs = np.random.RandomState(0)
+    imgs = [rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8) for h, w in ((480, 640), (100, 100), (333, 211))]
+    pre = ImagePreprocessor(DEV)
+    out = pre.batch(imgs).float().cpu()
+    assert out.shape == (3, 299, 299, 8) and float(out[..., 3:].abs().max()) == 0.0
+    for i, a in enumerate(imgs):
+        d = ImageDesc(0, a.shape[0], a.shape[1], a.shape[0] / 299.0, a.shape[1] / 299.0, 0.0, 0.0, 0, 1.0)
+        ref = preprocess_reference(a, d)
+        assert float((out[i] - ref).abs().max()) < 1.6e-2  # bf16 output rounding of values in [-1, 1]
+    dist = Distortion(True, 10, 20, 30)
+    assert dist.enabled and not Distortion().enabled
+    o2 = pre.batch(imgs, dist, random.Random(3)).float()
+    assert o2.shape == (3, 299, 299, 8) and torch.isfinite(o2).all()
+    assert float((o2.cpu() - out).abs().max()) > 0.05
+
+
+def test_inception_forward_matches_oracle():
+    from distributed_tensorflow_amd.models import inception_v3 as iv3
+    net = iv3.InceptionV3(DEV, seed=0)
+    assert 21.0e6 < net.num_params < 23.5e6            # ~21.8 M parameters up to pool_3
+    assert 11.0e9 < iv3.graph_flops(net.graph) < 12.0e9  # ~11.4 GFLOP / image
+    assert len(net.graph.convs) == 94
+    torch.manual_seed(0)
+    x = (torch.rand(2, 299, 299, 3, device=DEV) * 2 - 1)
+    xin = torch.zeros(2, 299, 299, 8, device=DEV, dtype=torch.bfloat16)
+    xin[..., :3] = x.to(torch.bfloat16)
+    got = net.forward(xin, use_graph=False)
+    got_graph = net.forward(xin, use_graph=True)
+    ref = iv3.reference_forward(net, xin[..., :3].float().permute(0, 3, 1, 2), bf16_sim=True)
+    assert got.shape == (2, 2048) and torch.isfinite(got).all()
+    assert float(ref.abs().mean()) > 1e-3   # activations did not die with the random init
+    assert relerr(got, ref) < 5e-2
+    assert torch.allclose(got, got_graph, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("double_softmax", [True, False])
+def test_retrain_head_native_matches_eager(double_softmax):
+    from distributed_tensorflow_amd.models.retrain_head import RetrainHead
+    torch.manual_seed(2)
+    N, C, B = 300, 5, 100
+    cache = torch.rand(N, 2048, device=DEV)
+    labels = torch.randint(0, C, (N,), device=DEV, dtype=torch.int32)
+    rows = torch.randint(0, N, (B,), device=DEV, dtype=torch.int32)
+    h_gpu = RetrainHead(C, DEV, learning_rate=0.05, double_softmax=double_softmax, seed=1)
+    h_cpu = RetrainHead(C, "cpu", learning_rate=0.05, double_softmax=double_softmax, seed=1)
+    h_gpu.weights.copy_(torch.randn(2048, C, device=DEV) * 0.01)
+    h_cpu.P.copy_(h_gpu.P.cpu())
+    for _ in range(3):
+        h_gpu.train_step(cache, labels, rows)
+        h_cpu.train_step(cache.cpu(), labels.cpu(), rows.cpu())
+        mg, mc = h_gpu.last_metrics(), h_cpu.last_metrics()
+        assert abs(mg[0] - mc[0]) < 1e-4 and abs(mg[1] - mc[1]) < 1e-6
+    assert relerr(h_gpu.P.cpu(), h_cpu.P) < 1e-4
+    ce, acc, probs, pred = h_gpu.evaluate(cache, labels, rows, want_probs=True)
+    ce2, acc2, probs2, pred2 = h_cpu.evaluate(cache.cpu(), labels.cpu(), rows.cpu(), want_probs=True)
+    assert abs(ce - ce2) < 1e-4 and abs(acc - acc2) < 1e-6 and relerr(probs.cpu(), probs2) < 1e-4
+
+
+def test_device_sampler_is_class_balanced():
+    from distributed_tensorflow_amd.data import image_lists as il
+    from distributed_tensorflow_amd.data.bottleneck import BottleneckCache
+    counts = np.array([[50, 5, 5], [10, 2, 3], [200, 20, 20]], np.int64)
+    offsets = np.zeros_like(counts)
+    n = 0
+    paths, cls, spl = [], [], []
+    for c in range(3):
+        for s in range(3):
+            offsets[c, s] = n
+            n += counts[c, s]
+            paths += ["p%d_%d_%d" % (c, s, i) for i in range(counts[c, s])]
+            cls += [c] * counts[c, s]
+            spl += [s] * counts[c, s]
+    idx = il.ImageIndex(["a", "b", "c"], paths, np.asarray(cls, np.int32), np.asarray(spl, np.int32), offsets, counts)
+    cache = BottleneckCache(idx, DEV)
+    rows = cache.sample_rows("training", 30000, seed=5).cpu().numpy()
+    assert np.all(idx.split_id[rows] == 0)
+    frac = np.bincount(idx.class_id[rows], minlength=3) / 30000.0
+    assert np.all(np.abs(frac - 1 / 3) < 0.02)           # balanced over classes, not over images
+    allrows = cache.sample_rows("testing", -1).cpu().numpy()
+    assert len(allrows) == 27 and np.all(idx.split_id[allrows] == 1)
+    r2 = cache.sample_rows("training", 100, seed=5).cpu().numpy()
+    assert not np.array_equal(r2, rows[:100])               # draw counter advances
+
+
+def test_retrain_end_to_end_inception_small(tmp_path):
+    from distributed_tensorflow_amd.apps import retrain
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))
+    try:
+        rc = retrain.main(["--training_steps", "40", "--synthetic_classes", "3", "--synthetic_images_per_class", "24",
+                           "--train_batch_size", "32", "--validation_batch_size", "16", "--eval_step_interval", "20",
+                           "--extract_batch_size", "24", "--learning_rate", "0.05", "--seed", "3"], distributed=False)
+        assert rc == 0
+        assert os.path.exists("retrained_graph.pb")
+        assert open("retrained_labels.txt").read().split("\n")[:3] == ["class 00", "class 01", "class 02"]
+        assert os.path.isdir("retrain_logs/train") and os.path.isdir("retrain_logs/validation")
+    finally:
+        os.chdir(cwd)
