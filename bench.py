@@ -39,6 +39,7 @@ def parse():
     p.add_argument("--engine", type=str, default="native")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-overlap", action="store_true")
+    p.add_argument("--backend", type=str, default="auto", help="auto (nccl==RCCL on GPUs) | gloo (functional tests)")
     p.add_argument("--train-size", type=int, default=55000)
     p.add_argument("--eval", type=int, default=1, help="report final test accuracy on a held-out synthetic split")
     return p.parse_args()
@@ -53,6 +54,10 @@ def main():
                os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
+    if os.environ.get("DTF_HANG_DUMP_SECS"):  # debugging aid: dump every thread's stack if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["DTF_HANG_DUMP_SECS"]), exit=True)
+
     import torch
     import torch.distributed as dist
 
@@ -60,10 +65,10 @@ def main():
     from distributed_tensorflow_amd.engine.mnist_engine import make_engine
     from distributed_tensorflow_amd.parallel.ddp import DataParallelTrainer, init_process_group
 
-    rank, world = init_process_group("auto") if args.gpus > 1 else (0, 1)
+    rank, world = init_process_group(args.backend) if args.gpus > 1 else (0, 1)
     use_cuda = torch.cuda.is_available()
     if use_cuda:
-        local = int(os.environ.get("LOCAL_RANK", 0))
+        local = int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count()
         torch.cuda.set_device(local)
         device = "cuda:%d" % local
     else:
@@ -93,7 +98,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

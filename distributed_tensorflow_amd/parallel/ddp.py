@@ -71,6 +71,9 @@ class DataParallelTrainer:
         self._bucket_a = engine.G[a0:a1]
         self._bucket_b = engine.G[b0:b1]
         self._native = hasattr(engine, "stream")
+        # gloo with device tensors (functional tests: several ranks sharing one GPU, where RCCL refuses duplicate
+        # devices) is staged through host memory explicitly; RCCL reduces the arena slices in place.
+        self._stage_host = (self.world > 1 and self._native and dist.get_backend(group) == "gloo")
         if self.world > 1:
             self.broadcast_state()
 
@@ -81,14 +84,32 @@ class DataParallelTrainer:
         import contextlib
         return contextlib.nullcontext()
 
+    def _reduce(self, t: torch.Tensor, op=None, async_op: bool = False):
+        """all-reduce ``t`` in place on the engine's stream (host-staged when the backend cannot take device memory)."""
+        op = dist.ReduceOp.SUM if op is None else op
+        if not self._stage_host:
+            return dist.all_reduce(t, op=op, group=self.group, async_op=async_op)
+        h = t.to("cpu")  # stream-ordered D2H + wait
+        dist.all_reduce(h, op=op, group=self.group)
+        t.copy_(h)
+        return None
+
+    def _bcast(self, t: torch.Tensor, src: int) -> None:
+        if not self._stage_host:
+            dist.broadcast(t, src=src, group=self.group)
+            return
+        h = t.to("cpu")
+        dist.broadcast(h, src=src, group=self.group)
+        t.copy_(h)
+
     def broadcast_state(self, src: int = 0) -> None:
         """rank-``src`` parameters + optimizer state + step -> every replica."""
         e = self.engine
         with self._ctx():
             for t in (e.P, e.M, e.V):
-                dist.broadcast(t, src=src, group=self.group)
+                self._bcast(t, src)
             step = e.step_t if self._native else torch.tensor([e.global_step], dtype=torch.int32)
-            dist.broadcast(step, src=src, group=self.group)
+            self._bcast(step, src) if self._native else dist.broadcast(step, src=src, group=self.group)
         if self._native:
             e.stream.synchronize()
             e._steps_done = int(e.step_t.item())
@@ -103,6 +124,8 @@ class DataParallelTrainer:
         with self._ctx():
             cs = torch.stack([e.P.double().sum(), e.P.double().abs().sum()])
             lo, hi = cs.clone(), cs.clone()
+            if self._stage_host:
+                lo, hi = lo.cpu(), hi.cpu()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
         return bool(torch.equal(lo.cpu(), hi.cpu()))
@@ -111,7 +134,7 @@ class DataParallelTrainer:
         """Sum a few python floats across ranks (logging points only)."""
         if self.world == 1:
             return [float(v) for v in values]
-        dev = self.engine.device
+        dev = "cpu" if self._stage_host else self.engine.device
         t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
         with self._ctx():
             dist.all_reduce(t, group=self.group)
@@ -121,7 +144,7 @@ class DataParallelTrainer:
         """all-reduce(max) of a stop flag."""
         if self.world == 1:
             return bool(flag)
-        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.engine.device)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cpu" if self._stage_host else self.engine.device)
         with self._ctx():
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return bool(int(t.item()))
@@ -141,21 +164,22 @@ class DataParallelTrainer:
             e.train_step()
             if e.global_step % self.async_period == 0:
                 with self._ctx():
-                    dist.all_reduce(e.P, group=self.group)
+                    self._reduce(e.P)
                     e.P.div_(self.world)
             return
         if self._native:
             with torch.cuda.stream(e.stream):
                 e.launch("part1")
                 if self.overlap:
-                    wa = dist.all_reduce(self._bucket_a, group=self.group, async_op=True)
+                    wa = self._reduce(self._bucket_a, async_op=True)
                     e.launch("part2")
-                    wb = dist.all_reduce(self._bucket_b, group=self.group, async_op=True)
-                    wa.wait()
-                    wb.wait()
+                    wb = self._reduce(self._bucket_b, async_op=True)
+                    if wa is not None:
+                        wa.wait()
+                        wb.wait()
                 else:
                     e.launch("part2")
-                    dist.all_reduce(e.G, group=self.group)
+                    self._reduce(e.G)
                 e.launch("apply")
         else:
             e.fwd_bwd(3)
