@@ -29,3 +29,7 @@ DTF_API int dtf_unpool(const float* dpool, const void* pooled, const void* amax,
 DTF_API int dtf_head(const HeadParams* hp, int blocks, hipStream_t st);
 DTF_API int dtf_adam_tf(const OptimParams* p, hipStream_t st);
 DTF_API int dtf_sgd(const OptimParams* p, hipStream_t st);
+DTF_API int dtf_conv2_lds_init();
+DTF_API int dtf_conv2_bwd_lds_init();
+DTF_API int dtf_conv2_bwd_lds(const float* dpool2, const void* pool2, const void* amax2, const float* W, const void* pool1,
+                              float* dpool1, float* dW, float* db2, int B, int ipw, hipStream_t st);

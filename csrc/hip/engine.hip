@@ -99,9 +99,9 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e, int parts, hipStream_t st) {
   }
   if (parts & 2) {
     DTF_TRY(dtf_fc_bwd_data(e->dh, e->P + e->off_Wfc1, e->dpool2, B, 3136, 1024, e->bwd_splits, st));
-    DTF_TRY(dtf_unpool(e->dpool2, e->pool2, e->amax2, e->dy2, e->G + e->off_bc2, B, 7, 7, 64, st));
-    DTF_TRY(dtf_conv_bwd_data_mask(e->dy2, e->P + e->off_Wc2, e->pool1, e->dpool1, B, 14, 14, 32, 64, 5, 5, st));
-    DTF_TRY(dtf_conv_dw(e->pool1, e->dy2, e->G + e->off_Wc2, B, 14, 14, 32, 64, 5, 5, e->dw2_splits, st));
+    // un-pool + conv2 bwd-data (+db2) and conv2 dW as two LDS-resident kernels (conv2_lds.hip)
+    DTF_TRY(dtf_conv2_bwd_lds(e->dpool2, e->pool2, e->amax2, e->P + e->off_Wc2, e->pool1, e->dpool1, e->G + e->off_Wc2,
+                              e->G + e->off_bc2, B, e->dw2_splits > 0 && e->dw2_splits <= 16 ? e->dw2_splits : 4, st));
     DTF_TRY(dtf_conv1_dw(e->images, e->perm, e->step, e->spe, B, e->dpool1, e->amax1, e->G + e->off_Wc1,
                          e->G + e->off_bc1, st));
   }

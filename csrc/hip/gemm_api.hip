@@ -3,6 +3,9 @@
 // instead of launching when they do not hold (a faulting kernel can reset the whole GPU host).
 #include "gemm_core.h"
 
+DTF_API int dtf_conv2_fwd_lds(const void* x, const float* W, const float* bias, void* out, void* amax, int B,
+                              hipStream_t st);
+
 namespace {
 constexpr int ERR_SHAPE = -22;
 
@@ -83,6 +86,8 @@ static inline int fill_geom(GemmParams& p, int H, int W, int Cin, int cstride, i
 DTF_API int dtf_conv_bias_relu_pool(const void* x, const float* Wt, const float* bias, void* out, void* argmax,
                                     int B, int H, int W, int Cin, int Cout, int KH, int KW, hipStream_t st) {
   if (B <= 0 || H % 2 || W % 2 || Cout % 2) return ERR_SHAPE;
+  if (H == 14 && W == 14 && Cin == 32 && Cout == 64 && KH == 5 && KW == 5)  // MNIST conv2: LDS-resident kernel
+    return dtf_conv2_fwd_lds(x, Wt, bias, out, argmax, B, st);
   const int M = B * H * W, K = KH * KW * Cin;
   GemmParams p = base_params(x, Wt, out, M, Cout, K, 0, Cout, Cout, 1, 128);
   if (fill_geom(p, H, W, Cin, Cin, H, W, KH, KW, 1, (KH - 1) / 2, (KW - 1) / 2)) return ERR_SHAPE;

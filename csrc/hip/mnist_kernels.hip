@@ -30,16 +30,27 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
                                                         const int* __restrict__ step_ptr, int spe, int B,
                                                         const float* __restrict__ Wt, const float* __restrict__ bias,
                                                         uint16_t* __restrict__ out, uint8_t* __restrict__ amax) {
-  __shared__ float img[32 * 32];  // rows/cols -2..29 (SAME padding halo)
+  __shared__ __attribute__((aligned(16))) float img[32 * 32];  // rows/cols -2..29 (SAME padding halo)
+  __shared__ __attribute__((aligned(16))) float wl[26 * 8];    // this block's 8 filters (25 taps) + bias
   const int b = blockIdx.x, cg = blockIdx.y, tid = threadIdx.x;
   const long n = sample_index(perm, step_ptr, spe, B, b);
   const float* src = images + n * 784;
+  // every global load of the block is issued before the first wait: one memory round trip
+  float v[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int e = tid + 256 * i, r = e >> 5, c = e & 31;
     const int y = r - 2, x = c - 2;
-    img[e] = ((unsigned)y < 28u && (unsigned)x < 28u) ? src[y * 28 + x] : 0.f;
+    const bool ok = (unsigned)y < 28u && (unsigned)x < 28u;
+    v[i] = src[ok ? y * 28 + x : 0];
+    v[i] = ok ? v[i] : 0.f;
   }
+  float wv0 = 0.f;
+  if (tid < 200) wv0 = Wt[(tid >> 3) * 32 + cg * 8 + (tid & 7)];
+  else if (tid < 208) wv0 = bias[cg * 8 + (tid - 200)];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) img[tid + 256 * i] = v[i];
+  if (tid < 208) wl[tid] = wv0;
   __syncthreads();
   if (tid >= 196) return;
   const int py = tid / 14, px = tid - py * 14;
@@ -47,25 +58,28 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 #pragma unroll
   for (int r = 0; r < 6; ++r)
 #pragma unroll
-    for (int c = 0; c < 6; ++c) patch[r][c] = img[(2 * py + r) * 32 + 2 * px + c];
+    for (int c = 0; c < 6; c += 2) {
+      const float2 t = *reinterpret_cast<const float2*>(&img[(2 * py + r) * 32 + 2 * px + c]);
+      patch[r][c] = t.x;
+      patch[r][c + 1] = t.y;
+    }
   float acc[4][8];
 #pragma unroll
   for (int s = 0; s < 4; ++s)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[s][j] = 0.f;
-  const float* w = Wt + cg * 8;
 #pragma unroll
   for (int dy = 0; dy < 5; ++dy)
 #pragma unroll
     for (int dx = 0; dx < 5; ++dx) {
-      float wv[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) wv[j] = w[(dy * 5 + dx) * 32 + j];
+      const float4 w0 = *reinterpret_cast<const float4*>(&wl[(dy * 5 + dx) * 8]);      // LDS broadcast reads
+      const float4 w1 = *reinterpret_cast<const float4*>(&wl[(dy * 5 + dx) * 8 + 4]);
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const float v = patch[(s >> 1) + dy][(s & 1) + dx];
+        const float pv = patch[(s >> 1) + dy][(s & 1) + dx];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[s][j] = fmaf(v, wv[j], acc[s][j]);
+        for (int j = 0; j < 8; ++j) acc[s][j] = fmaf(pv, wv[j], acc[s][j]);
       }
     }
   uint32_t ov[4];
@@ -77,7 +91,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 #pragma unroll
     for (int s = 1; s < 4; ++s)
       if (acc[s][j] > best) { best = acc[s][j]; arg = s; }
-    const float o = fmaxf(best + bias[cg * 8 + j], 0.f);
+    const float o = fmaxf(best + wl[200 + j], 0.f);
     const uint32_t bits = f2bf(o);
     if (j & 1) ov[j >> 1] |= bits << 16; else ov[j >> 1] = bits;
     av[j >> 2] |= (uint32_t)arg << ((j & 3) * 8);
@@ -103,8 +117,11 @@ __global__ __launch_bounds__(256) void conv1_dw_kernel(const float* __restrict__
                                                        const int* __restrict__ step_ptr, int spe, int B,
                                                        const float* __restrict__ dpool1, const uint8_t* __restrict__ amax,
                                                        float* __restrict__ dW, float* __restrict__ db) {
-  __shared__ float img[32 * 32];
-  __shared__ float red[8 * 26 * 32];
+  // per image: x halo plane (4 KB) + gradient plane 196x32 fp32 (24.5 KB) + argmax plane (6 KB) are pulled into LDS
+  // with one burst of independent loads; the 196 x 25-tap accumulation then never touches global memory.
+  __shared__ __attribute__((aligned(16))) float img[32 * 32];
+  __shared__ __attribute__((aligned(16))) float gl[7 * 256 * 4];   // 196*32 used; padded so staging needs no predicates
+  __shared__ __attribute__((aligned(16))) uint8_t al[4 * 256 * 8];  // 196*32 used
   const int tid = threadIdx.x, c = tid & 31, pg = tid >> 5;
   float acc[26];
 #pragma unroll
@@ -112,18 +129,46 @@ __global__ __launch_bounds__(256) void conv1_dw_kernel(const float* __restrict__
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const long n = sample_index(perm, step_ptr, spe, B, b);
     const float* src = images + n * 784;
-    __syncthreads();
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(dpool1 + (long)b * 6272);  // ext-vector type: stays in VGPRs
+    const uint2* a8 = reinterpret_cast<const uint2*>(amax + (long)b * 6272);
+    float v[4];
+    f32x4 ga[4], gb[3];  // (HIP's float4 struct copies lower to memcpy and land in scratch/LDS here)
+    uint2 avv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = tid + 256 * i, r = e >> 5, cc = e & 31;
       const int y = r - 2, x = cc - 2;
-      img[e] = ((unsigned)y < 28u && (unsigned)x < 28u) ? src[y * 28 + x] : 0.f;
+      const bool ok = (unsigned)y < 28u && (unsigned)x < 28u;
+      v[i] = src[ok ? y * 28 + x : 0];
+      v[i] = ok ? v[i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ga[i] = g4[tid + 256 * i];  // 1568 float4 in total
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int e = tid + 256 * (4 + i);
+      gb[i] = g4[e < 1568 ? e : 0];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // 784 uint2
+      const int e = tid + 256 * i;
+      avv[i] = a8[e < 784 ? e : 0];
+    }
+    __syncthreads();  // previous image fully consumed
+#pragma unroll
+    for (int i = 0; i < 4; ++i) img[tid + 256 * i] = v[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) reinterpret_cast<f32x4*>(gl)[tid + 256 * i] = ga[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) reinterpret_cast<f32x4*>(gl)[tid + 256 * (4 + i)] = gb[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      reinterpret_cast<uint2*>(al)[tid + 256 * i] = avv[i];
     }
     __syncthreads();
     for (int p = pg; p < 196; p += 8) {
-      const long o = ((long)b * 196 + p) * 32 + c;
-      const float g = dpool1[o];
-      const int a = amax[o];
+      const float g = gl[p * 32 + c];
+      const int a = al[p * 32 + c];
       const int py = p / 14, px = p - py * 14;
       const int r0 = 2 * py + (a >> 1), c0 = 2 * px + (a & 1);
 #pragma unroll
@@ -133,14 +178,15 @@ __global__ __launch_bounds__(256) void conv1_dw_kernel(const float* __restrict__
       acc[25] += g;
     }
   }
+  __shared__ float red[8 * 26 * 32];
 #pragma unroll
   for (int t = 0; t < 26; ++t) red[(pg * 26 + t) * 32 + c] = acc[t];
   __syncthreads();
   for (int e = tid; e < 26 * 32; e += 256) {
-    float s = 0.f;
+    float sum = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) s += red[q * 26 * 32 + e];
-    if (e < 25 * 32) atomicAdd(&dW[e], s); else atomicAdd(&db[e - 25 * 32], s);
+    for (int q = 0; q < 8; ++q) sum += red[q * 26 * 32 + e];
+    if (e < 25 * 32) atomicAdd(&dW[e], sum); else atomicAdd(&db[e - 25 * 32], sum);
   }
 }
 

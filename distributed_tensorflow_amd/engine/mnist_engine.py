@@ -60,11 +60,13 @@ class NativeMnistEngine(_EngineBase):
     def __init__(self, dataset: Optional[DeviceDataset], *, batch_size: int = 100, lr: float = 1e-4,
                  keep_prob: float = 0.7, double_softmax: bool = True, seed: Optional[int] = None,
                  world: int = 1, eval_chunk: int = 5000, use_graph: bool = True,
-                 fc1_splits: int = 14, bwd_splits: int = 4, dw2_splits: int = 32, head_blocks: int = 0,
+                 fc1_splits: int = 14, bwd_splits: int = 4, dw2_splits: int = 4, head_blocks: int = 0,
                  beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, device="cuda"):
         if not torch.cuda.is_available():
             raise native.NativeError("NativeMnistEngine needs a GPU (MI355X); use EagerMnistEngine on CPU")
         self.lib = native.hip()
+        native.check(self.lib.dtf_conv2_lds_init() or self.lib.dtf_conv2_bwd_lds_init(),
+                     "LDS kernel attribute setup")  # before any stream capture
         self.device = torch.device(device)
         self.dataset = dataset
         self.batch_size = batch_size

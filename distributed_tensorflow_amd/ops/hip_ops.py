@@ -150,6 +150,25 @@ def conv_backward_weight(x: torch.Tensor, dy: torch.Tensor, KH: int, KW: int, sp
     return dW
 
 
+def conv2_backward_lds(dpool2: torch.Tensor, pool2: torch.Tensor, amax2: torch.Tensor, w: torch.Tensor,
+                       pool1: torch.Tensor, images_per_block: int = 4):
+    """Fused MNIST conv2 backward (un-pool + bwd-data + ReLU mask + db, and dW) -> (dpool1, dW, db2)."""
+    _chk(dpool2, torch.float32, "dpool2")
+    _chk(pool2, torch.bfloat16, "pool2")
+    _chk(amax2, torch.uint8, "amax2")
+    _chk(w, torch.float32, "w")
+    _chk(pool1, torch.bfloat16, "pool1")
+    B = dpool2.shape[0]
+    assert dpool2.shape[1:] == (7, 7, 64) and pool1.shape == (B, 14, 14, 32) and w.numel() == 25 * 32 * 64
+    dpool1 = torch.empty(B, 14, 14, 32, dtype=torch.float32, device=dpool2.device)
+    dW = torch.zeros(5, 5, 32, 64, dtype=torch.float32, device=dpool2.device)
+    db = torch.zeros(64, dtype=torch.float32, device=dpool2.device)
+    native.check(native.hip().dtf_conv2_bwd_lds(dpool2.data_ptr(), pool2.data_ptr(), amax2.data_ptr(), w.data_ptr(),
+                                                pool1.data_ptr(), dpool1.data_ptr(), dW.data_ptr(), db.data_ptr(), B,
+                                                images_per_block, _st()), "conv2_bwd_lds")
+    return dpool1, dW, db
+
+
 def conv_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, *, Cin: int, KH: int, KW: int,
                    stride: int = 1, pad: Tuple[int, int] = (0, 0), relu: bool = True,
                    out: Optional[torch.Tensor] = None, out_channel_offset: int = 0,

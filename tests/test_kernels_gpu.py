@@ -121,6 +121,19 @@ def test_conv2_forward_pool(ops, B):
     assert float((picked - cw.max(-1).values).abs().max()) < 2e-2
 
 
+def test_conv_pool_generic_shape(ops):
+    """A shape that does not match the LDS-resident MNIST kernel goes through the generic implicit GEMM."""
+    torch.manual_seed(16)
+    B = 5
+    x = bf(torch.rand(B, 10, 12, 16, device=dev()))
+    w = torch.randn(3, 3, 16, 32, device=dev()) * 0.1
+    b = torch.randn(32, device=dev()) * 0.1
+    out, amax = ops.conv_bias_relu_pool(x, w.view(144, 32).contiguous(), b, 3, 3)
+    c = F.conv2d(x.float().permute(0, 3, 1, 2), r(w).permute(3, 2, 0, 1), b, padding=1)
+    ref = F.max_pool2d(torch.relu(c), 2).permute(0, 2, 3, 1)
+    assert relerr(out, ref) < 1e-2
+
+
 def test_unpool(ops):
     torch.manual_seed(7)
     B = 10
@@ -162,6 +175,31 @@ def test_conv_backward_weight(ops, B, splits):
     (gw,) = torch.autograd.grad(y, wt, dy.float().permute(0, 3, 1, 2))
     ref = gw.permute(2, 3, 1, 0)
     assert relerr(got, ref) < 2e-3
+
+
+@pytest.mark.parametrize("B,ipw", [(100, 4), (7, 3)])
+def test_conv2_backward_lds_matches_unfused_chain(ops, B, ipw):
+    torch.manual_seed(20 + B)
+    pool1 = bf(torch.relu(torch.randn(B, 14, 14, 32, device=dev())))
+    w = torch.randn(5, 5, 32, 64, device=dev()) * 0.05
+    b = torch.randn(64, device=dev()) * 0.1
+    pool2, amax2 = ops.conv_bias_relu_pool(pool1, w.view(800, 64).contiguous(), b, 5, 5)
+    dpool2 = torch.randn(B, 7, 7, 64, device=dev())
+    dpool1, dW, db = ops.conv2_backward_lds(dpool2, pool2, amax2, w.contiguous(), pool1, images_per_block=ipw)
+    # reference: explicit un-pool, then PyTorch conv gradients on the same bf16-rounded operands
+    g = dpool2 * (pool2.float() > 0)
+    dy = torch.zeros(B, 7, 2, 7, 2, 64, device=dev())
+    for s_ in range(4):
+        dy[:, :, s_ >> 1, :, s_ & 1, :] = g * (amax2 == s_)
+    dy = r(dy.reshape(B, 14, 14, 64))
+    xin = pool1.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wt = r(w).permute(3, 2, 0, 1).requires_grad_(True)
+    y = F.conv2d(xin, wt, padding=2)
+    gx, gw = torch.autograd.grad(y, (xin, wt), dy.permute(0, 3, 1, 2))
+    ref_dx = gx.permute(0, 2, 3, 1) * (pool1.float() > 0)
+    assert relerr(dpool1, ref_dx) < 2e-3
+    assert relerr(dW, gw.permute(2, 3, 1, 0)) < 2e-3
+    assert relerr(db, g.sum((0, 1, 2))) < 1e-4
 
 
 def test_conv1_backward_weight(ops):
