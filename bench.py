@@ -41,6 +41,8 @@ def parse():
     p.add_argument("--no-overlap", action="store_true")
     p.add_argument("--backend", type=str, default="auto", help="auto (nccl==RCCL on GPUs) | gloo (functional tests)")
     p.add_argument("--train-size", type=int, default=55000)
+    p.add_argument("--dp-path", action="store_true",
+                   help="diagnostic: with --gpus 1, create a 1-rank RCCL group and take the multi-rank step path")
     p.add_argument("--eval", type=int, default=1, help="report final test accuracy on a held-out synthetic split")
     return p.parse_args()
 
@@ -66,6 +68,11 @@ def main():
     from distributed_tensorflow_amd.parallel.ddp import DataParallelTrainer, init_process_group
 
     rank, world = init_process_group(args.backend) if args.gpus > 1 else (0, 1)
+    if args.dp_path and args.gpus == 1 and torch.cuda.is_available():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1)
     use_cuda = torch.cuda.is_available()
     if use_cuda:
         local = int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count()
@@ -81,7 +88,7 @@ def main():
     dd = mnist.DeviceDataset(train, device, rank=rank, world=world, seed=1)
     eng = make_engine(args.engine, dd, batch_size=args.batch, lr=1e-4, keep_prob=0.7, double_softmax=True,
                       seed=1234, device=device, use_graph=not args.no_graph)
-    trainer = DataParallelTrainer(eng, sync=True, overlap=not args.no_overlap)
+    trainer = DataParallelTrainer(eng, sync=True, overlap=not args.no_overlap, force_collectives=args.dp_path)
 
     def sync():
         if world > 1:
@@ -141,6 +148,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -58,8 +58,12 @@ def init_process_group(backend: str = "auto", rank: Optional[int] = None, world:
 class DataParallelTrainer:
     """Drives an engine (native or eager) under synchronous or emulated-async data parallelism."""
 
-    def __init__(self, engine, *, sync: bool = True, async_period: int = 8, group=None, overlap: bool = True):
+    def __init__(self, engine, *, sync: bool = True, async_period: int = 8, group=None, overlap: bool = True,
+                 force_collectives: bool = False):
         self.engine = engine
+        # force_collectives: take the multi-rank code path even with one rank (lets a 1-GPU box exercise the
+        # RCCL stream/event choreography of the overlapped step end to end)
+        self._force = force_collectives and dist.is_initialized()
         self.group = group
         self.sync = sync
         self.async_period = max(1, async_period)
@@ -73,8 +77,9 @@ class DataParallelTrainer:
         self._native = hasattr(engine, "stream")
         # gloo with device tensors (functional tests: several ranks sharing one GPU, where RCCL refuses duplicate
         # devices) is staged through host memory explicitly; RCCL reduces the arena slices in place.
-        self._stage_host = (self.world > 1 and self._native and dist.get_backend(group) == "gloo")
-        if self.world > 1:
+        self._stage_host = (dist.is_initialized() and self._native and dist.get_backend(group) == "gloo")
+        self._multi = self.world > 1 or self._force
+        if self._multi:
             self.broadcast_state()
 
     # ------------------------------------------------------------------ collectives
@@ -118,7 +123,7 @@ class DataParallelTrainer:
 
     def replicas_in_sync(self) -> bool:
         """Debug invariant: parameter checksums identical on every rank."""
-        if self.world == 1:
+        if not self._multi:
             return True
         e = self.engine
         with self._ctx():
@@ -157,7 +162,7 @@ class DataParallelTrainer:
     # ------------------------------------------------------------------ stepping
     def train_step(self) -> None:
         e = self.engine
-        if self.world == 1:
+        if not self._multi:
             e.train_step()
             return
         if not self.sync:

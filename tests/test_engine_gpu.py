@@ -126,3 +126,50 @@ def test_native_data_parallel_path_two_ranks_one_gpu(tmp_path):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 200 and out["replicas_in_sync"] is True
     assert out["final_train_loss"] < 2.35 and out["value"] > 0
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", HSA_ENABLE_IPC_MODE_LEGACY="0")
+import torch, torch.distributed as dist
+from distributed_tensorflow_amd.data import mnist
+from distributed_tensorflow_amd.engine.mnist_engine import NativeMnistEngine
+from distributed_tensorflow_amd.parallel.ddp import DataParallelTrainer
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+def ds():
+    imgs, labels = mnist.synthetic_mnist(3000, seed=1)
+    d = mnist.DataSet(mnist._scale_flatten(imgs), mnist.dense_to_one_hot(labels), seed=1)
+    return mnist.DeviceDataset(d, "cuda", seed=1)
+e1 = NativeMnistEngine(ds(), batch_size=100, seed=5, lr=1e-4)
+e2 = NativeMnistEngine(ds(), batch_size=100, seed=5, lr=1e-4)
+t1 = DataParallelTrainer(e1, force_collectives=True, overlap=True)   # part1 | RCCL bucket A || part2 | RCCL bucket B | Adam
+t2 = DataParallelTrainer(e2)                                          # plain single-graph step
+for _ in range(40):
+    t1.train_step(); t2.train_step()
+torch.cuda.synchronize()
+l1, _ = e1.read_metrics(0, 40); l2, _ = e2.read_metrics(0, 40)
+print(json.dumps({"first": abs(float(l1[0] - l2[0])), "tail": abs(float(l1[-10:].mean() - l2[-10:].mean())),
+                  "drop": float(l1[:5].mean() - l1[-5:].mean()), "sync": t1.replicas_in_sync(),
+                  "steps": int(e1.step_t.item())}))
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_overlapped_step_single_rank(tmp_path):
+    """The RCCL (backend "nccl") variant of the overlapped DP step — async all-reduce of arena slices on RCCL's
+    stream between the part1/part2/apply graphs — run with one rank, compared against the fused single-graph step."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(_RCCL_ONE_RANK)
+    r = subprocess.run([sys.executable, str(script), repo], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["steps"] == 40 and out["sync"] is True
+    assert out["first"] < 1e-4 and out["tail"] < 0.05 and out["drop"] > 0.0
