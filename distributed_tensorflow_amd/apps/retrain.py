@@ -139,10 +139,16 @@ def run(FLAGS, distributed: bool) -> int:
         backbone_kind = "inception" if device.type == "cuda" else "tiny"
     if backbone_kind == "inception":
         from ..models.inception_v3 import InceptionV3
-        maybe_download_and_extract(FLAGS.model_dir)
+        pb = maybe_download_and_extract(FLAGS.model_dir)
         net = InceptionV3(device, seed=seed)
         npz = os.path.join(FLAGS.model_dir, "inception_v3_weights.npz")
-        if os.path.exists(npz):
+        if pb is not None:
+            # the reference's own artefact (retrain1/retrain.py:66-74), parsed without TensorFlow
+            from ..utils.graphdef import inception_weights_from_graphdef
+            layers = inception_weights_from_graphdef(pb)
+            net.load_tf_weights(layers)
+            _log(rank, "loaded %d Inception-v3 conv layers from %s" % (len(layers), pb))
+        elif os.path.exists(npz):
             z = np.load(npz)
             layers = {}
             for k in z.files:
@@ -244,6 +250,12 @@ def run(FLAGS, distributed: bool) -> int:
         tensors["_dtf/backbone_seed"] = np.asarray(seed, np.int64)
         tensors["_dtf/labels"] = np.frombuffer("\n".join(image_lists.keys()).encode(), np.uint8).copy()
         ckpt.save_tensors(FLAGS.output_graph, tensors)
+        # the frozen head as a real GraphDef too (reference tensor names), for TensorFlow-side tooling
+        from ..utils.graphdef import write_retrained_graph
+        tf_t = head.tf_tensors()
+        write_retrained_graph(os.path.splitext(FLAGS.output_graph)[0] + "_frozen_head.pb",
+                              tf_t["final_training_ops/weights/final_weights"],
+                              tf_t["final_training_ops/biases/final_biases"], FLAGS.final_tensor_name)
         with open(FLAGS.output_labels, "w") as f:
             f.write("\n".join(image_lists.keys()) + "\n")
         train_writer.close()

@@ -31,6 +31,7 @@ from . import image_lists as il
 from .image_lists import CATEGORIES, ImageIndex, MAX_NUM_IMAGES_PER_CLASS
 
 BOTTLENECK_SIZE = 2048
+BOTTLENECK_TENSOR_SIZE = BOTTLENECK_SIZE  # the reference's name (retrain1/retrain.py:30)
 INPUT_SIZE = 299
 
 
@@ -289,3 +290,26 @@ def get_random_distorted_bottlenecks(index: ImageIndex, how_many: int, category:
     x = preproc.load(paths, distortion, rng)
     feats = backbone(x).to(torch.float32)
     return feats, torch.as_tensor(labels, dtype=torch.int32, device=feats.device)
+
+
+# ----------------------------------------------------------------------------- packed-double files (C44)
+def write_list_of_floats_to_file(list_of_floats, file_path: str) -> None:
+    """``retrain1/retrain.py:357-360``: ``BOTTLENECK_TENSOR_SIZE`` native doubles, ``struct.pack('d'*2048)``.
+    Never called by the reference's own drivers; kept as the compact binary export of one cache row."""
+    a = np.asarray(list_of_floats, dtype=np.float64).reshape(-1)
+    if a.size != BOTTLENECK_TENSOR_SIZE:
+        raise ValueError("expected %d values, got %d" % (BOTTLENECK_TENSOR_SIZE, a.size))
+    with open(file_path, "wb") as f:
+        f.write(a.tobytes())
+
+
+def read_list_of_floats_from_file(file_path: str) -> List[float]:
+    """``retrain1/retrain.py:363-366``."""
+    with open(file_path, "rb") as f:
+        raw = f.read()
+    if len(raw) != 8 * BOTTLENECK_TENSOR_SIZE:
+        raise ValueError("%s: %d bytes, expected %d" % (file_path, len(raw), 8 * BOTTLENECK_TENSOR_SIZE))
+    return np.frombuffer(raw, dtype=np.float64).tolist()
+
+
+bottleneck_path_2_bottleneck_values: dict = {}  # retrain1/retrain.py:369 (module-level memo the reference never fills)

@@ -99,6 +99,7 @@ def hip() -> C.CDLL:
         _sig(lib, "dtf_fc_dw_pair", I, [P, P, P, I, I, P, P, P, I, I, I, P])
         _sig(lib, "dtf_conv2_lds_init", I, [])
         _sig(lib, "dtf_conv2_fwd_lds", I, [P, P, P, P, P, I, P])
+        _sig(lib, "dtf_tensor_stats", I, [P, C.c_long, P, I, P, P, P])
         _sig(lib, "dtf_conv2_bwd_lds_init", I, [])
         _sig(lib, "dtf_conv2_bwd_lds", I, [P, P, P, P, P, P, P, P, I, I, P])
         _sig(lib, "dtf_conv_bias_relu_pool", I, [P, P, P, P, P, I, I, I, I, I, I, I, P])

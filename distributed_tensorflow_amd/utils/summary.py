@@ -65,25 +65,59 @@ class Summary:
         return self
 
 
+_NPOS = (len(BUCKET_LIMITS) - 2) // 2
+_DEV_LIMITS: dict = {}
+
+
+def _order_key_decode(k: int) -> float:
+    u = (~k & 0xFFFFFFFF) if not (k & 0x80000000) else (k & 0x7FFFFFFF)
+    return struct.unpack("<f", struct.pack("<I", u))[0]
+
+
+def device_stats(t) -> Tuple[float, float, float, float, float, np.ndarray]:
+    """One launch of the fused stats kernel (``csrc/hip/stats.hip``) over a CUDA fp32 tensor ->
+    (min, max, num, sum, sum_squares, bucket counts)."""
+    import torch
+    t = t.detach().reshape(-1)
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.float().contiguous()
+    dev = t.device
+    lim = _DEV_LIMITS.get(dev)
+    if lim is None:
+        lim = torch.from_numpy(BUCKET_LIMITS[_NPOS + 1:_NPOS + 1 + _NPOS].copy()).to(dev)
+        _DEV_LIMITS[dev] = lim
+    sums = torch.empty(2, dtype=torch.float64, device=dev)
+    counts = torch.empty(2 * _NPOS + 4, dtype=torch.int32, device=dev)
+    native.check(native.hip().dtf_tensor_stats(t.data_ptr(), t.numel(), lim.data_ptr(), _NPOS, sums.data_ptr(),
+                                               counts.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                 "tensor_stats")
+    c = counts.cpu().numpy().view(np.uint32)
+    sm = sums.cpu().numpy()
+    nb = 2 * _NPOS + 2
+    hist = c[:nb].astype(np.int64)
+    num = float(hist.sum())
+    mn = _order_key_decode(int(c[nb])) if num else 0.0
+    mx = _order_key_decode(int(c[nb + 1])) if num else 0.0
+    return mn, mx, num, float(sm[0]), float(sm[1]), hist
+
+
 def histogram_stats(values) -> dict:
-    """min/max/num/sum/sum_squares + TF-style compressed buckets of a tensor or array."""
+    """min/max/num/sum/sum_squares + TF-style compressed buckets of a tensor or array.  Bucket ``i`` holds
+    ``limit[i-1] <= v < limit[i]`` (TF's ``Histogram::Add`` uses ``upper_bound``)."""
     try:
         import torch
         if isinstance(values, torch.Tensor):
-            t = values.detach().reshape(-1).to(torch.float64)
-            if t.is_cuda:
-                # bucketize on device, transfer only the (few hundred) counts
-                limits = torch.from_numpy(BUCKET_LIMITS).to(t.device)
-                idx = torch.bucketize(t, limits, right=False)
-                counts = torch.bincount(idx.clamp_(max=len(BUCKET_LIMITS) - 1), minlength=len(BUCKET_LIMITS)).cpu().numpy()
-                st = torch.stack([t.min(), t.max(), t.sum(), (t * t).sum()]).cpu().numpy()
-                return _compress(float(st[0]), float(st[1]), float(t.numel()), float(st[2]), float(st[3]), counts)
-            values = t.cpu().numpy()
+            if values.is_cuda:
+                return _compress(*device_stats(values))
+            values = values.detach().reshape(-1).to(torch.float64).cpu().numpy()
     except ImportError:
         pass
     a = np.asarray(values, np.float64).reshape(-1)
-    idx = np.searchsorted(BUCKET_LIMITS, a, side="left")
+    a = a[~np.isnan(a)]
+    idx = np.searchsorted(BUCKET_LIMITS, a, side="right")
     counts = np.bincount(np.minimum(idx, len(BUCKET_LIMITS) - 1), minlength=len(BUCKET_LIMITS))
+    if a.size == 0:
+        return _compress(0.0, 0.0, 0.0, 0.0, 0.0, counts)
     return _compress(float(a.min()), float(a.max()), float(a.size), float(a.sum()), float((a * a).sum()), counts)
 
 
@@ -114,18 +148,23 @@ def _compress(mn, mx, num, s, ss, counts) -> dict:
 
 def variable_summaries(name: str, var) -> Summary:
     """``variable_summaries(var)`` of the reference under name scope ``name``
-    (``retrain1/retrain.py:249-258``): mean, stddev, max, min scalars + histogram."""
+    (``retrain1/retrain.py:249-258``): mean, stddev, max, min scalars + histogram — all five from
+    one pass over the tensor (one kernel launch + one small read-back on the GPU)."""
     import torch
-    t = var.detach().float().reshape(-1)
-    mean = t.mean()
-    std = torch.sqrt(((t - mean) ** 2).mean())
-    st = torch.stack([mean, std, t.max(), t.min()]).cpu().tolist()
     s = Summary()
-    s.scalar(name + "/summaries/mean", st[0])
-    s.scalar(name + "/summaries/stddev/stddev", st[1])
-    s.scalar(name + "/summaries/max", st[2])
-    s.scalar(name + "/summaries/min", st[3])
-    s.histogram(name + "/summaries/histogram", var)
+    if isinstance(var, torch.Tensor) and var.is_cuda:
+        mn, mx, num, sm, ss, hist = device_stats(var)
+        h = _compress(mn, mx, num, sm, ss, hist)
+    else:
+        h = histogram_stats(var)
+        mn, mx, num, sm, ss = h["min"], h["max"], h["num"], h["sum"], h["sum_squares"]
+    mean = sm / max(num, 1.0)
+    std = max(ss / max(num, 1.0) - mean * mean, 0.0) ** 0.5
+    s.scalar(name + "/summaries/mean", mean)
+    s.scalar(name + "/summaries/stddev/stddev", std)
+    s.scalar(name + "/summaries/max", mx)
+    s.scalar(name + "/summaries/min", mn)
+    s.histograms.append((name + "/summaries/histogram", h))
     return s
 
 

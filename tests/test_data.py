@@ -123,3 +123,16 @@ def test_synthetic_image_dir(tmp_path):
     root = il.make_synthetic_image_dir(str(tmp_path / "syn"), num_classes=3, images_per_class=4, size=(64, 48))
     lists = il.create_image_lists(root, 10, 10, verbose=False)
     assert len(lists) == 3
+
+
+def test_packed_double_bottleneck_files(tmp_path):
+    from distributed_tensorflow_amd.data import bottleneck as bn
+    v = np.random.RandomState(0).randn(2048)
+    p = str(tmp_path / "row.bin")
+    bn.write_list_of_floats_to_file(v.tolist(), p)
+    import struct
+    raw = open(p, "rb").read()
+    assert struct.unpack("d" * 2048, raw) == tuple(v.tolist())  # the reference's exact encoding
+    assert bn.read_list_of_floats_from_file(p) == v.tolist()
+    with pytest.raises(ValueError):
+        bn.write_list_of_floats_to_file([1.0, 2.0], p)

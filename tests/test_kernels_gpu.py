@@ -252,3 +252,25 @@ def test_sgd(ops):
     ops.sgd_(P, G, step, ticket, lr=0.01)
     torch.cuda.synchronize()
     assert torch.allclose(P, ref, rtol=1e-6, atol=1e-7) and float(G.abs().max()) == 0.0 and int(step.item()) == 1
+
+
+def test_tensor_stats_kernel_matches_numpy():
+    from distributed_tensorflow_amd.utils import summary
+    torch.manual_seed(3)
+    parts = [torch.randn(70001) * 0.03, torch.zeros(17), torch.tensor([1e-12, -1e-12, 1.1e-12, 5e19, -3e25, 1.0, -1.0]),
+             torch.randn(3000).exp() * 50, torch.tensor([float("nan")])]
+    x = torch.cat(parts).to(dev())
+    mn, mx, num, sm, ss, hist = summary.device_stats(x)
+    a = x.cpu().numpy().astype(np.float64)
+    a = a[~np.isnan(a)]
+    ref = np.bincount(np.minimum(np.searchsorted(summary.BUCKET_LIMITS, a, side="right"), len(summary.BUCKET_LIMITS) - 1),
+                      minlength=len(summary.BUCKET_LIMITS))
+    assert num == a.size and mn == a.min() and mx == a.max()
+    assert abs(sm - a.sum()) <= 1e-9 * np.abs(a).sum() and abs(ss - (a * a).sum()) <= 1e-9 * (a * a).sum()
+    assert np.array_equal(hist, ref)
+    s = summary.variable_summaries("w", x[:70001])
+    d = dict(s.scalars)
+    b = a[:70001]
+    assert abs(d["w/summaries/mean"] - b.mean()) < 1e-7 and abs(d["w/summaries/stddev/stddev"] - b.std()) < 1e-6
+    assert d["w/summaries/max"] == b.max() and d["w/summaries/min"] == b.min()
+    assert sum(s.histograms[0][1]["bucket"]) == b.size
