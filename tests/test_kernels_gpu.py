@@ -5,6 +5,8 @@ tolerances only have to absorb accumulation-order differences.
 """
 import math
 
+import numpy as np
+
 import pytest
 import torch
 import torch.nn.functional as F
