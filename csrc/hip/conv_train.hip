@@ -1,0 +1,438 @@
+// Training-mode kernels for the Inception-v3 full fine-tune path (BASELINE config 5; SURVEY §2.6 last paragraph):
+//   * conv forward writing the raw bf16 pre-activation and accumulating the batch-norm statistics in its epilogue,
+//   * batch-norm finalize / normalise+ReLU forward / two-pass backward (column reduce, then apply in place),
+//   * conv backward-data for every geometry of the network (1x1, 3x3, 5x5, 1x7, 7x1, 1x3, 3x1; stride 1/2; SAME/VALID),
+//   * conv filter gradient for the same geometries,
+//   * max-pool 3x3/2 (argmax kept), avg-pool 3x3 SAME (TF divisor) and global average pool backward.
+// Master weights are fp32 HWIO ([KH*KW*Cin][Cout], TensorFlow's layout) and are converted to bf16 while staged into
+// LDS, so the optimizer updates one fp32 arena and no shadow copy is maintained.  Activations and activation
+// gradients are bf16 NHWC; a tensor may be a channel slice of a wider concat buffer (explicit channel strides).
+#include "gemm_core.h"
+#include "dtf_api.h"
+
+namespace {
+constexpr int ERR_SHAPE = -22;
+
+inline GemmParams mk_params(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc,
+                            int splits, int BK) {
+  GemmParams p{};
+  p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  const int ksteps = dtf_cdiv(K, BK);
+  p.kchunk = dtf_cdiv(ksteps, splits < 1 ? 1 : splits) * BK;
+  p.slab_stride = (long)M * ldc;
+  return p;
+}
+inline int nsplits(const GemmParams& p) { return dtf_cdiv(p.K, p.kchunk); }
+
+inline int geom(GemmParams& p, int H, int W, int C, int cstride, int Ho, int Wo, int KH, int KW, int stride, int pad_h,
+                int pad_w) {
+  p.g.H = H; p.g.W = W; p.g.Cin = C; p.g.cstride = cstride; p.g.Ho = Ho; p.g.Wo = Wo;
+  p.g.KH = KH; p.g.KW = KW; p.g.stride = stride; p.g.pad_h = pad_h; p.g.pad_w = pad_w;
+  if (C % 8 || cstride % 8 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return ERR_SHAPE;
+  if ((H + 2 * pad_h - KH) / stride + 1 != Ho || (W + 2 * pad_w - KW) / stride + 1 != Wo) return ERR_SHAPE;
+  return 0;
+}
+
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[2 * j] = bf2f((uint16_t)(w[j] & 0xffffu));
+    f[2 * j + 1] = bf2f((uint16_t)(w[j] >> 16));
+  }
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
+}
+__device__ __forceinline__ void ld8f(const float* p, float* f) {
+  const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+inline int ew_blocks(long total, int cap = 8192) {
+  long b = (total + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ conv forward
+// z[B,Ho,Wo,Cout] (bf16, dense) = conv(x, Wt);  stats[2][Cout] += (sum z, sum z^2) per output channel.
+DTF_API int dtf_conv_fwd_stats(const void* x, const float* Wt, void* z, float* stats, int B, int H, int W, int Cin,
+                               int in_cstride, int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int Ho,
+                               int Wo, hipStream_t st) {
+  if (B <= 0 || Cout <= 0 || Cout % 2) return ERR_SHAPE;
+  const int M = B * Ho * Wo, K = KH * KW * Cin;
+  GemmParams p = mk_params(x, Wt, z, M, Cout, K, 0, Cout, Cout, 1, 64);
+  if (geom(p, H, W, Cin, in_cstride, Ho, Wo, KH, KW, stride, pad_h, pad_w)) return ERR_SHAPE;
+  p.aux_out = stats;
+  if (Cout <= 32)
+    return dtf_launch_gemm<128, 32, 64, 4, 1, LoadConvA<128, 256, 64, 0>, LoadColK<float, 32, 256, 64, false>, EpBf16Stats>(p, 1, st);
+  if (M <= 256 * 64)
+    return dtf_launch_gemm<64, 64, 64, 2, 2, LoadConvA<64, 256, 64, 0>, LoadColK<float, 64, 256, 64, false>, EpBf16Stats>(p, 1, st);
+  return dtf_launch_gemm<128, 64, 64, 4, 1, LoadConvA<128, 256, 64, 0>, LoadColK<float, 64, 256, 64, false>, EpBf16Stats>(p, 1, st);
+}
+
+// ------------------------------------------------------------------------------------------------ conv backward-data
+// dx[B,H,W,Cin] (bf16 at channel stride dx_cstride; overwritten or accumulated) = conv^T(dz, Wt)
+DTF_API int dtf_conv_bwd_data(const void* dz, const float* Wt, void* dx, int B, int H, int W, int Cin, int dx_cstride,
+                              int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int Ho, int Wo, int accumulate,
+                              hipStream_t st) {
+  if (B <= 0 || Cin <= 0 || Cin % 8 || (stride != 1 && stride != 2)) return ERR_SHAPE;
+  const int M = B * H * W, K = KH * KW * Cout;
+  GemmParams p = mk_params(dz, Wt, dx, M, Cin, K, 0, 0, dx_cstride, 1, 64);
+  if (geom(p, H, W, Cout, Cout, Ho, Wo, KH, KW, stride, pad_h, pad_w)) return ERR_SHAPE;
+  p.accumulate = accumulate;
+  if (M <= 256 * 64)
+    return dtf_launch_gemm<64, 64, 64, 2, 2, LoadConvBwdA<64, 256, 64>, LoadConvWBwd<64, 256, 64, false>, EpBf16Acc>(p, 1, st);
+  return dtf_launch_gemm<128, 64, 64, 4, 1, LoadConvBwdA<128, 256, 64>, LoadConvWBwd<64, 256, 64, false>, EpBf16Acc>(p, 1, st);
+}
+
+// ------------------------------------------------------------------------------------------------ conv filter gradient
+// dW[(tap,cin)][cout] (fp32 HWIO, pre-zeroed; split-K atomics) += sum_pos x[pos (+) tap][cin] * dz[pos][cout]
+DTF_API int dtf_conv_dw_general(const void* x, int in_cstride, const void* dz, float* dW, int B, int H, int W, int Cin,
+                                int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int Ho, int Wo, int splits,
+                                hipStream_t st) {
+  if (B <= 0 || Cin % 2 || Cout % 2 || splits < 1) return ERR_SHAPE;
+  const int M = KH * KW * Cin, K = B * Ho * Wo;
+  GemmParams p = mk_params(x, dz, dW, M, Cout, K, 0, Cout, Cout, splits, 64);
+  if (geom(p, H, W, Cin, in_cstride, Ho, Wo, KH, KW, stride, pad_h, pad_w)) return ERR_SHAPE;
+  return dtf_launch_gemm<128, 64, 64, 4, 1, LoadConvDwA<128, 256, 64>, LoadColK<uint16_t, 64, 256, 64, false>, EpAtomicF32>(
+      p, nsplits(p), st);
+}
+
+// ------------------------------------------------------------------------------------------------ batch norm
+// bn[4][C] = mean, rstd, scale (= gamma*rstd), shift (= beta - mean*scale); moving stats updated in place.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ mmean,
+                                                          float* __restrict__ mvar, float* __restrict__ bn, int C,
+                                                          float inv_count, float eps, float momentum) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float mean = stats[c] * inv_count;
+  const float var = fmaxf(stats[C + c] * inv_count - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + eps);
+  const float scale = gamma[c] * rstd;
+  bn[c] = mean;
+  bn[C + c] = rstd;
+  bn[2 * C + c] = scale;
+  bn[3 * C + c] = beta[c] - mean * scale;
+  if (mmean) {
+    mmean[c] = momentum * mmean[c] + (1.f - momentum) * mean;
+    mvar[c] = momentum * mvar[c] + (1.f - momentum) * var;
+  }
+}
+
+DTF_API int dtf_bn_finalize(const float* stats, const float* gamma, const float* beta, float* moving_mean,
+                            float* moving_var, float* bn, int C, long count, float eps, float momentum, hipStream_t st) {
+  if (C <= 0 || count <= 0) return ERR_SHAPE;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(dtf_cdiv(C, 256)), dim3(256), 0, st, stats, gamma, beta, moving_mean,
+                     moving_var, bn, C, 1.f / (float)count, eps, momentum);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// y[m*y_cs + c] = bf16(relu(z[m][c]*scale[c] + shift[c]))
+__global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const uint16_t* __restrict__ z, const float* __restrict__ bn,
+                                                          uint16_t* __restrict__ y, long M, int C, int y_cs) {
+  const int c8n = C >> 3;
+  const long total = M * c8n;
+  for (long gi = (long)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (long)gridDim.x * 256) {
+    const int c0 = (int)(gi % c8n) * 8;
+    const long m = gi / c8n;
+    float f[8], sc[8], sh[8];
+    unpack8(*reinterpret_cast<const uint4*>(z + m * C + c0), f);
+    ld8f(bn + 2 * C + c0, sc);
+    ld8f(bn + 3 * C + c0, sh);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * sc[j] + sh[j], 0.f);
+    *reinterpret_cast<uint4*>(y + m * y_cs + c0) = pack8(f);
+  }
+}
+
+DTF_API int dtf_bn_relu_fwd(const void* z, const float* bn, void* y, long M, int C, int y_cstride, hipStream_t st) {
+  if (M <= 0 || C <= 0 || C % 8 || y_cstride % 8) return ERR_SHAPE;
+  hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(ew_blocks(M * (C / 8))), dim3(256), 0, st, (const uint16_t*)z, bn,
+                     (uint16_t*)y, M, C, y_cstride);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// sums[2][C] += (sum g, sum g*xhat) with g = dy * (y > 0), xhat = (z - mean) * rstd
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const uint16_t* __restrict__ dy, int dy_cs,
+                                                                 const uint16_t* __restrict__ y, int y_cs,
+                                                                 const uint16_t* __restrict__ z, const float* __restrict__ bn,
+                                                                 float* __restrict__ sums, long M, int C, int rows_per_block) {
+  __shared__ float red[256 * 16];
+  const int c8n = C >> 3;
+  const int rpb = 256 / c8n;
+  const int tid = threadIdx.x;
+  const int ry = tid / c8n, cg = tid - ry * c8n, c0 = cg * 8;
+  const bool active = ry < rpb;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  if (active) {
+    float mean[8], rstd[8];
+    ld8f(bn + c0, mean);
+    ld8f(bn + C + c0, rstd);
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    for (long r = r0 + ry; r < r1; r += rpb) {
+      float g[8], yy[8], zz[8];
+      unpack8(*reinterpret_cast<const uint4*>(dy + r * dy_cs + c0), g);
+      unpack8(*reinterpret_cast<const uint4*>(y + r * y_cs + c0), yy);
+      unpack8(*reinterpret_cast<const uint4*>(z + r * C + c0), zz);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gj = yy[j] > 0.f ? g[j] : 0.f;
+        s1[j] += gj;
+        s2[j] += gj * (zz[j] - mean[j]) * rstd[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    red[tid * 16 + j] = s1[j];
+    red[tid * 16 + 8 + j] = s2[j];
+  }
+  __syncthreads();
+  if (active && ry == 0) {
+    for (int k = 1; k < rpb; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s1[j] += red[(k * c8n + cg) * 16 + j];
+        s2[j] += red[(k * c8n + cg) * 16 + 8 + j];
+      }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      atomicAdd(&sums[c0 + j], s1[j]);
+      atomicAdd(&sums[C + c0 + j], s2[j]);
+    }
+  }
+}
+
+DTF_API int dtf_bn_relu_bwd_reduce(const void* dy, int dy_cstride, const void* y, int y_cstride, const void* z,
+                                   const float* bn, float* sums, long M, int C, hipStream_t st) {
+  if (M <= 0 || C <= 0 || C % 8 || C > 2048 || dy_cstride % 8 || y_cstride % 8) return ERR_SHAPE;
+  const int rpb = 256 / (C / 8);
+  long rows = (M + 1023) / 1024;
+  if (rows < 8L * rpb) rows = 8L * rpb;
+  hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(dtf_cdiv(M, rows)), dim3(256), 0, st, (const uint16_t*)dy, dy_cstride,
+                     (const uint16_t*)y, y_cstride, (const uint16_t*)z, bn, sums, M, C, (int)rows);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// z <- dz = scale * (g - s1/M - xhat * s2/M)  in place; block 0 also emits dgamma = s2, dbeta = s1.
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const uint16_t* __restrict__ dy, int dy_cs,
+                                                                const uint16_t* __restrict__ y, int y_cs,
+                                                                uint16_t* __restrict__ z, const float* __restrict__ bn,
+                                                                const float* __restrict__ sums, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, long M, int C, float inv_m) {
+  if (blockIdx.x == 0 && dgamma)
+    for (int c = threadIdx.x; c < C; c += 256) {
+      dbeta[c] = sums[c];
+      dgamma[c] = sums[C + c];
+    }
+  const int c8n = C >> 3;
+  const long total = M * c8n;
+  for (long gi = (long)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (long)gridDim.x * 256) {
+    const int c0 = (int)(gi % c8n) * 8;
+    const long m = gi / c8n;
+    float g[8], yy[8], zz[8], mean[8], rstd[8], sc[8], a[8], b[8];
+    unpack8(*reinterpret_cast<const uint4*>(dy + m * dy_cs + c0), g);
+    unpack8(*reinterpret_cast<const uint4*>(y + m * y_cs + c0), yy);
+    unpack8(*reinterpret_cast<const uint4*>(z + m * C + c0), zz);
+    ld8f(bn + c0, mean);
+    ld8f(bn + C + c0, rstd);
+    ld8f(bn + 2 * C + c0, sc);
+    ld8f(sums + c0, a);
+    ld8f(sums + C + c0, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gj = yy[j] > 0.f ? g[j] : 0.f;
+      const float xh = (zz[j] - mean[j]) * rstd[j];
+      zz[j] = sc[j] * (gj - a[j] * inv_m - xh * b[j] * inv_m);
+    }
+    *reinterpret_cast<uint4*>(z + m * C + c0) = pack8(zz);
+  }
+}
+
+DTF_API int dtf_bn_relu_bwd_apply(const void* dy, int dy_cstride, const void* y, int y_cstride, void* z, const float* bn,
+                                  const float* sums, float* dgamma, float* dbeta, long M, int C, hipStream_t st) {
+  if (M <= 0 || C <= 0 || C % 8 || dy_cstride % 8 || y_cstride % 8) return ERR_SHAPE;
+  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(ew_blocks(M * (C / 8))), dim3(256), 0, st, (const uint16_t*)dy,
+                     dy_cstride, (const uint16_t*)y, y_cstride, (uint16_t*)z, bn, sums, dgamma, dbeta, M, C, 1.f / (float)M);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ pools
+// max 3x3 stride s VALID, keeping the window-relative argmax (0..8, first maximum like TF's MaxPoolGrad)
+__global__ __launch_bounds__(256) void maxpool3x3_arg_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ out,
+                                                             uint8_t* __restrict__ arg, int B, int H, int W, int C, int in_cs,
+                                                             int Ho, int Wo, int out_cs, int stride) {
+  const int c8n = C >> 3;
+  const long total = (long)B * Ho * Wo * c8n;
+  for (long gi = (long)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (long)gridDim.x * 256) {
+    const int c0 = (int)(gi % c8n) * 8;
+    long t = gi / c8n;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float best[8];
+    unsigned am[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { best[j] = -3.0e38f; am[j] = 0; }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(x + (((long)b * H + ho * stride + dy) * W + wo * stride + dx) * in_cs + c0), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (f[j] > best[j]) { best[j] = f[j]; am[j] = dy * 3 + dx; }
+      }
+    const long o = ((long)b * Ho + ho) * Wo + wo;
+    *reinterpret_cast<uint4*>(out + o * out_cs + c0) = pack8(best);
+    *reinterpret_cast<uint2*>(arg + o * C + c0) =
+        make_uint2(am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24), am[4] | (am[5] << 8) | (am[6] << 16) | (am[7] << 24));
+  }
+}
+
+DTF_API int dtf_maxpool3x3_arg(const void* x, void* out, void* argmax, int B, int H, int W, int C, int in_cs, int out_cs,
+                               int stride, hipStream_t st) {
+  if (B <= 0 || C % 8 || in_cs % 8 || out_cs % 8 || H < 3 || W < 3 || stride < 1) return ERR_SHAPE;
+  const int Ho = (H - 3) / stride + 1, Wo = (W - 3) / stride + 1;
+  hipLaunchKernelGGL(maxpool3x3_arg_kernel, dim3(ew_blocks((long)B * Ho * Wo * (C / 8))), dim3(256), 0, st,
+                     (const uint16_t*)x, (uint16_t*)out, (uint8_t*)argmax, B, H, W, C, in_cs, Ho, Wo, out_cs, stride);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// dx[b,h,w,c] (+)= sum over the windows (ho,wo) containing (h,w) whose argmax is (h,w) of dy[b,ho,wo,c]  (gather, no atomics)
+__global__ __launch_bounds__(256) void maxpool3x3_bwd_kernel(const uint16_t* __restrict__ dy, int dy_cs,
+                                                             const uint8_t* __restrict__ arg, uint16_t* __restrict__ dx,
+                                                             int dx_cs, int B, int H, int W, int C, int Ho, int Wo, int stride,
+                                                             int accumulate) {
+  const int c8n = C >> 3;
+  const long total = (long)B * H * W * c8n;
+  for (long gi = (long)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (long)gridDim.x * 256) {
+    const int c0 = (int)(gi % c8n) * 8;
+    long t = gi / c8n;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int b = (int)(t / H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int ho_lo = h >= 2 ? (h - 2 + stride - 1) / stride : 0, ho_hi = min(h / stride, Ho - 1);
+    const int wo_lo = w >= 2 ? (w - 2 + stride - 1) / stride : 0, wo_hi = min(w / stride, Wo - 1);
+    for (int ho = ho_lo; ho <= ho_hi; ++ho)
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        const unsigned want = (unsigned)((h - ho * stride) * 3 + (w - wo * stride));
+        const long o = ((long)b * Ho + ho) * Wo + wo;
+        const uint2 a = *reinterpret_cast<const uint2*>(arg + o * C + c0);
+        float g[8];
+        unpack8(*reinterpret_cast<const uint4*>(dy + o * dy_cs + c0), g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned aj = ((j < 4 ? a.x : a.y) >> (8 * (j & 3))) & 0xffu;
+          if (aj == want) acc[j] += g[j];
+        }
+      }
+    uint16_t* dst = dx + (((long)b * H + h) * W + w) * dx_cs + c0;
+    if (accumulate) {
+      float old[8];
+      unpack8(*reinterpret_cast<const uint4*>(dst), old);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += old[j];
+    }
+    *reinterpret_cast<uint4*>(dst) = pack8(acc);
+  }
+}
+
+DTF_API int dtf_maxpool3x3_bwd(const void* dy, int dy_cs, const void* argmax, void* dx, int dx_cs, int B, int H, int W,
+                               int C, int stride, int accumulate, hipStream_t st) {
+  if (B <= 0 || C % 8 || dy_cs % 8 || dx_cs % 8 || H < 3 || W < 3 || stride < 1) return ERR_SHAPE;
+  const int Ho = (H - 3) / stride + 1, Wo = (W - 3) / stride + 1;
+  hipLaunchKernelGGL(maxpool3x3_bwd_kernel, dim3(ew_blocks((long)B * H * W * (C / 8))), dim3(256), 0, st,
+                     (const uint16_t*)dy, dy_cs, (const uint8_t*)argmax, (uint16_t*)dx, dx_cs, B, H, W, C, Ho, Wo, stride,
+                     accumulate);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// avg 3x3/1 SAME with TF's divisor (valid taps only): dx[h,w] (+)= sum_{|ho-h|<=1,|wo-w|<=1} dy[ho,wo] / cnt(ho,wo)
+__global__ __launch_bounds__(256) void avgpool3x3_bwd_kernel(const uint16_t* __restrict__ dy, int dy_cs,
+                                                             uint16_t* __restrict__ dx, int dx_cs, int B, int H, int W, int C,
+                                                             int accumulate) {
+  const int c8n = C >> 3;
+  const long total = (long)B * H * W * c8n;
+  for (long gi = (long)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (long)gridDim.x * 256) {
+    const int c0 = (int)(gi % c8n) * 8;
+    long t = gi / c8n;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int b = (int)(t / H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int ho = max(h - 1, 0); ho <= min(h + 1, H - 1); ++ho) {
+      const int nr = min(ho + 1, H - 1) - max(ho - 1, 0) + 1;
+      for (int wo = max(w - 1, 0); wo <= min(w + 1, W - 1); ++wo) {
+        const int nc = min(wo + 1, W - 1) - max(wo - 1, 0) + 1;
+        const float inv = 1.f / (float)(nr * nc);
+        float g[8];
+        unpack8(*reinterpret_cast<const uint4*>(dy + (((long)b * H + ho) * W + wo) * dy_cs + c0), g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += g[j] * inv;
+      }
+    }
+    uint16_t* dst = dx + (((long)b * H + h) * W + w) * dx_cs + c0;
+    if (accumulate) {
+      float old[8];
+      unpack8(*reinterpret_cast<const uint4*>(dst), old);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += old[j];
+    }
+    *reinterpret_cast<uint4*>(dst) = pack8(acc);
+  }
+}
+
+DTF_API int dtf_avgpool3x3_same_bwd(const void* dy, int dy_cs, void* dx, int dx_cs, int B, int H, int W, int C,
+                                    int accumulate, hipStream_t st) {
+  if (B <= 0 || C % 8 || dy_cs % 8 || dx_cs % 8 || H <= 0 || W <= 0) return ERR_SHAPE;
+  hipLaunchKernelGGL(avgpool3x3_bwd_kernel, dim3(ew_blocks((long)B * H * W * (C / 8))), dim3(256), 0, st,
+                     (const uint16_t*)dy, dy_cs, (uint16_t*)dx, dx_cs, B, H, W, C, accumulate);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// dx[b,p,c] = bf16(df[b,c] / HW)
+__global__ __launch_bounds__(256) void global_avgpool_bwd_kernel(const float* __restrict__ df, uint16_t* __restrict__ dx,
+                                                                 int B, int HW, int C) {
+  const int c8n = C >> 3;
+  const long total = (long)B * HW * c8n;
+  const float inv = 1.f / (float)HW;
+  for (long gi = (long)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (long)gridDim.x * 256) {
+    const int c0 = (int)(gi % c8n) * 8;
+    const long bp = gi / c8n;
+    const int b = (int)(bp / HW);
+    float f[8];
+    ld8f(df + (long)b * C + c0, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] *= inv;
+    *reinterpret_cast<uint4*>(dx + bp * C + c0) = pack8(f);
+  }
+}
+
+DTF_API int dtf_global_avgpool_bwd(const float* df, void* dx, int B, int HW, int C, hipStream_t st) {
+  if (B <= 0 || C % 8 || HW <= 0) return ERR_SHAPE;
+  hipLaunchKernelGGL(global_avgpool_bwd_kernel, dim3(ew_blocks((long)B * HW * (C / 8))), dim3(256), 0, st, df,
+                     (uint16_t*)dx, B, HW, C);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}

@@ -45,6 +45,7 @@ struct GemmParams {
   const void* aux_in;
   void* aux_out;
   ConvGeom g;
+  int accumulate;  // epilogues that support it add to the existing output instead of overwriting
 };
 
 // ------------------------------------------------------------------ raw element loads (convert later)
@@ -243,7 +244,7 @@ struct LoadConvA {
 // Backward-data weight view of an fp32 HWIO filter W[tap][n=cin][kc=cout]:
 //   B[n][k = (tap', cout)] = W[(KH*KW-1) - tap'][n][cout]      (taps flipped, k contiguous)
 // g.Cin holds the channels per tap of the gathered tensor (= cout of the forward conv).
-template <int R, int NT, int BK>
+template <int R, int NT, int BK, bool FLIP = true>
 struct LoadConvWBwd {
   static constexpr int CPR = BK / 8, NCHUNK = R * CPR, PER = (NCHUNK + NT - 1) / NT;
   Raw8<float> regs[PER];
@@ -267,7 +268,7 @@ struct LoadConvWBwd {
       const int c = tid + NT * i;
       const int row = c / CPR, kk = k0 + (c % CPR) * 8;
       const int tapp = kk / kc_per_tap, co = kk - tapp * kc_per_tap;
-      const int tap = ntaps - 1 - tapp;
+      const int tap = FLIP ? ntaps - 1 - tapp : tapp;
       regs[i].ld(src + (ok(c) ? ((long)tap * rows + (r0 + row)) * kc_per_tap + co : 0L));
     }
   }
@@ -277,6 +278,63 @@ struct LoadConvWBwd {
       const int c = tid + NT * i;
       if (NCHUNK % NT == 0 || c < NCHUNK)
         *reinterpret_cast<uint4*>(lds + (c / CPR) * DTF_LDS_STRIDE + (c % CPR) * 8) = ok(c) ? regs[i].bf() : make_uint4(0, 0, 0, 0);
+    }
+  }
+};
+
+// Backward-data gather for a general (stride 1 or 2, any padding) conv: row m = input position (b,h,w),
+// k = (tap, cout) over the output-gradient tensor dz[B,Ho,Wo,Cout] (bf16, channel stride cstride):
+//   A[m][(tap,co)] = dz[b, (h + pad_h - dy)/s, (w + pad_w - dx)/s, co]   when divisible and in range, else 0
+// pairs with LoadConvWBwd<.., FLIP=false> (same tap order).  g.H/g.W = input dims, g.Ho/g.Wo = dz dims,
+// g.Cin = channels per tap (= forward Cout).
+template <int R, int NT, int BK>
+struct LoadConvBwdA {
+  static constexpr int CPR = BK / 8, NCHUNK = R * CPR, PER = (NCHUNK + NT - 1) / NT;
+  static_assert(NT % CPR == 0, "every thread keeps one k-chunk column");
+  uint4 regs[PER];
+  unsigned okbits;
+  const uint16_t* src;
+  int img[PER], hb[PER], wb[PER];
+  bool okr[PER];
+  ConvGeom g;
+  int sh;  // log2(stride)
+  __device__ __forceinline__ void init(const GemmParams& p, int m0, int tid) {
+    src = reinterpret_cast<const uint16_t*>(p.A);
+    g = p.g;
+    sh = g.stride - 1;  // stride in {1, 2}
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + NT * i;
+      const int m = m0 + c / CPR;
+      okr[i] = (NCHUNK % NT == 0 || c < NCHUNK) && m < p.M;
+      const int w = m % g.W, t = m / g.W;
+      img[i] = t / g.H;
+      hb[i] = t % g.H + g.pad_h;
+      wb[i] = w + g.pad_w;
+    }
+  }
+  __device__ __forceinline__ void load(int k0, int kend, int tid) {
+    const int kk = k0 + (tid % CPR) * 8;
+    const int tap = kk / g.Cin, co = kk - tap * g.Cin;
+    const int dy = tap / g.KW, dx = tap - dy * g.KW;
+    const int smask = g.stride - 1;
+    okbits = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int hz = hb[i] - dy, wz = wb[i] - dx;
+      const int ho = hz >> sh, wo = wz >> sh;
+      const bool ok = okr[i] && kk < kend && hz >= 0 && wz >= 0 && ((hz | wz) & smask) == 0 && ho < g.Ho && wo < g.Wo;
+      okbits |= (ok ? 1u : 0u) << i;
+      regs[i] = *reinterpret_cast<const uint4*>(src + (ok ? ((long)(img[i] * g.Ho + ho) * g.Wo + wo) * g.cstride + co : 0L));
+    }
+  }
+  __device__ __forceinline__ void store(uint16_t* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + NT * i;
+      if (NCHUNK % NT == 0 || c < NCHUNK)
+        *reinterpret_cast<uint4*>(lds + (c / CPR) * DTF_LDS_STRIDE + (c % CPR) * 8) =
+            ((okbits >> i) & 1u) ? regs[i] : make_uint4(0, 0, 0, 0);
     }
   }
 };
@@ -400,6 +458,51 @@ struct EpMaskMulF32 {  // C = acc * (mask_bf16 > 0): conv bwd-data through the R
       const long o = (long)row * p.ldc + col;
       const uint16_t mk = mask[o];
       C[o] = ((mk & 0x7fffu) != 0 && (mk & 0x8000u) == 0) ? v : 0.f;
+    })
+  }
+};
+
+// Training-mode conv: raw bf16 output z[m][n] plus per-channel sum / sum of squares of the stored (bf16-rounded)
+// values accumulated into aux_out = float[2][N] (pre-zeroed) — the batch-norm statistics come out of the conv.
+struct EpBf16Stats {
+  template <int TM, int TN>
+  static __device__ __forceinline__ void run(const GemmParams& p, f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int) {
+    uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
+    float* stats = reinterpret_cast<float*>(p.aux_out);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = nbase + tn * 32 + (lane & 31);
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = mbase + tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+          if (row < p.M && col < p.N) {
+            const uint32_t b = f2bf(acc[tm][tn][i]);
+            C[(long)row * p.ldc + col] = (uint16_t)b;
+            const float v = bf2f(b);
+            s += v;
+            ss += v * v;
+          }
+        }
+      s += __shfl_xor(s, 32);
+      ss += __shfl_xor(ss, 32);
+      if (lane < 32 && col < p.N) {
+        atomicAdd(&stats[col], s);
+        atomicAdd(&stats[p.N + col], ss);
+      }
+    }
+  }
+};
+
+struct EpBf16Acc {  // out[m*ldc + n] = bf16(acc (+ existing out when p.accumulate))   (gradient into a shared buffer)
+  template <int TM, int TN>
+  static __device__ __forceinline__ void run(const GemmParams& p, f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int) {
+    uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
+    DTF_EP_FOREACH(if (row < p.M && col < p.N) {
+      const long o = (long)row * p.ldc + col;
+      C[o] = (uint16_t)f2bf(p.accumulate ? v + bf2f(C[o]) : v);
     })
   }
 };

@@ -1,0 +1,413 @@
+"""Inception-v3 full fine-tune (BASELINE config 5: "Inception-v3 full fine-tune bf16, DP") — training executor.
+
+The reference only ever trains the 2048->C head on frozen bottlenecks (``retrain1/retrain.py:262-297``); SURVEY §2.6
+lists the full fine-tune as the scale-up configuration: every conv gets training-mode BatchNorm forward/backward,
+backward-data and filter gradients, and the ≈95 MB of fp32 gradients are all-reduced across GPUs.
+
+Design (MI355X-first):
+
+* one flat fp32 arena ``P`` (and ``G``; ``M``/``V`` for Adam) holds the head and, per conv, ``W`` (HWIO, TensorFlow's
+  layout), ``gamma``, ``beta`` — ordered by *gradient readiness* (head first, then convs in reverse execution order)
+  so contiguous arena ranges become final while the backward is still running and can be all-reduced bucket by
+  bucket on RCCL's stream (xGMI is per-link bound: few large buckets);
+* activations ``y`` (bf16 NHWC, branches written straight into their concat slice), raw conv outputs ``z`` (bf16)
+  and activation gradients (bf16) are preallocated per batch size — ≈57 MB/image, i.e. B=256 fits many times over in
+  288 GB of HBM — and ``z`` is overwritten in place by ``dz`` in the backward;
+* per conv: forward = MFMA implicit GEMM whose epilogue also accumulates the BN statistics, a 1-block finalize, one
+  fused normalise+ReLU pass; backward = BN reduce, BN apply (in place), filter-gradient GEMM, data-gradient GEMM
+  (``csrc/hip/conv_train.hip``);
+* the fp32 master weights are read directly by the GEMM loaders (converted to bf16 while staged in LDS): the
+  optimizer touches one arena, no bf16 shadow copy exists;
+* the tiny head (``[B,2048]x[2048,C]``) uses torch matmuls on arena views with the closed-form (double-)softmax
+  gradient.
+
+``torch_train_step`` is the PyTorch autograd oracle of exactly the same computation (used by the tests and as the
+eager baseline in ``scripts/bench_inception_train.py``).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from .inception_v3 import BN_EPS, BOTTLENECK_TENSOR_SIZE, INPUT_PAD_CHANNELS, InceptionV3, build_graph
+
+ALIGN = 64  # arena segment alignment in elements (256 B)
+
+
+def _round_up(n: int, a: int = ALIGN) -> int:
+    return (n + a - 1) // a * a
+
+
+class ArenaLayout:
+    """Offsets of every trainable tensor in the flat arena, in gradient-readiness order."""
+
+    def __init__(self, graph, num_classes: int):
+        self.entries: "Dict[str, Tuple[int, Tuple[int, ...]]]" = {}
+        off = 0
+
+        def add(name, shape):
+            nonlocal off
+            n = 1
+            for d in shape:
+                n *= d
+            self.entries[name] = (off, tuple(shape))
+            off += _round_up(n)
+
+        add("final_training_ops/weights/final_weights", (BOTTLENECK_TENSOR_SIZE, num_classes))
+        add("final_training_ops/biases/final_biases", (num_classes,))
+        self.conv_order: List[str] = [op.conv.name for op in reversed(graph.ops) if op.kind == "conv"]
+        self.conv_end: Dict[str, int] = {}  # arena offset at which conv `name`'s segment ends
+        for name in self.conv_order:
+            s = graph.convs[name]
+            add(name + "/conv2d_params", (s.kh, s.kw, s.cin, s.cout))
+            add(name + "/batchnorm/gamma", (s.cout,))
+            add(name + "/batchnorm/beta", (s.cout,))
+            self.conv_end[name] = off
+        self.size = off
+
+    def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        off, shape = self.entries[name]
+        n = 1
+        for d in shape:
+            n *= d
+        return flat[off:off + n].view(shape)
+
+
+def softmax_xent_grad(logits: torch.Tensor, labels: torch.Tensor, double_softmax: bool):
+    """(mean loss, dloss/dlogits, probabilities) for CE(softmax(z)) or the reference's CE(softmax(softmax(z)))
+    (``retrain1/retrain.py:278,282``)."""
+    B, C = logits.shape
+    p = torch.softmax(logits, 1)
+    onehot = F.one_hot(labels.long(), C).to(logits.dtype)
+    if not double_softmax:
+        loss = -(torch.log_softmax(logits, 1) * onehot).sum(1).mean()
+        return loss, (p - onehot) / B, p
+    loss = -(torch.log_softmax(p, 1) * onehot).sum(1).mean()
+    dp = (torch.softmax(p, 1) - onehot) / B
+    return loss, p * (dp - (dp * p).sum(1, keepdim=True)), p
+
+
+class InceptionTrainer:
+    """Native full-network training step for a fixed batch size."""
+
+    def __init__(self, num_classes: int, batch_size: int, device="cuda", *, lr: float = 0.01, optimizer: str = "sgd",
+                 seed: int = 0, init: Optional[InceptionV3] = None, bn_momentum: float = 0.9997,
+                 double_softmax: bool = False, head_std: float = 0.001):
+        from .. import native
+        self.lib = native.hip()
+        self.native = native
+        self.device = torch.device(device)
+        self.B = batch_size
+        self.C = num_classes
+        self.lr = lr
+        self.optimizer = optimizer
+        self.bn_momentum = bn_momentum
+        self.double_softmax = double_softmax
+        self.world = 1
+        self.graph = build_graph()
+        g = self.graph
+        self.layout = ArenaLayout(g, num_classes)
+        dev = self.device
+        self.P = torch.zeros(self.layout.size, dtype=torch.float32, device=dev)
+        self.G = torch.zeros_like(self.P)
+        if optimizer == "adam":
+            self.M = torch.zeros_like(self.P)
+            self.V = torch.zeros_like(self.P)
+        self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        src = init if init is not None else InceptionV3(device="cpu", seed=seed)
+        gen = torch.Generator(device="cpu").manual_seed(seed + 17)
+        hw = torch.empty(BOTTLENECK_TENSOR_SIZE, num_classes)
+        torch.nn.init.trunc_normal_(hw, std=head_std, a=-2 * head_std, b=2 * head_std, generator=gen)
+        self.param("final_training_ops/weights/final_weights").copy_(hw)
+        # moving statistics (not trained): [mean | var] per conv in one buffer
+        self.stat_off: Dict[str, int] = {}
+        off = 0
+        for name, s in g.convs.items():
+            self.stat_off[name] = off
+            off += _round_up(s.cout, 8)
+        self.stat_total = off
+        self.moving_mean = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.moving_var = torch.ones(off, dtype=torch.float32, device=dev)
+        for name, s in g.convs.items():
+            p = src.params[name]
+            w = p["weights"]
+            if w.shape[2] != s.cin:  # first conv: 3 -> 8 zero-padded input channels
+                w = torch.cat([w, torch.zeros(s.kh, s.kw, s.cin - w.shape[2], s.cout)], dim=2)
+            self.param(name + "/conv2d_params").copy_(w)
+            self.param(name + "/batchnorm/gamma").copy_(p["gamma"])
+            self.param(name + "/batchnorm/beta").copy_(p["beta"])
+            o = self.stat_off[name]
+            self.moving_mean[o:o + s.cout].copy_(p["moving_mean"])
+            self.moving_var[o:o + s.cout].copy_(p["moving_variance"])
+        self._alloc()
+        self._plan_backward()
+
+    # ------------------------------------------------------------------ arena
+    def param(self, name: str) -> torch.Tensor:
+        return self.layout.view(self.P, name)
+
+    def grad(self, name: str) -> torch.Tensor:
+        return self.layout.view(self.G, name)
+
+    @property
+    def num_params(self) -> int:
+        n = 0
+        for _name, (_off, shape) in self.layout.entries.items():
+            k = 1
+            for d in shape:
+                k *= d
+            n += k
+        return n
+
+    def export_to(self, model: InceptionV3) -> None:
+        """Copy trained weights + moving statistics into an inference ``InceptionV3`` (folded-BN path)."""
+        layers = {}
+        for name, s in self.graph.convs.items():
+            w = self.param(name + "/conv2d_params").detach().cpu()
+            o = self.stat_off[name]
+            layers[name] = {"weights": w[:, :, :model.params[name]["weights"].shape[2], :].contiguous().numpy(),
+                            "gamma": self.param(name + "/batchnorm/gamma").cpu().numpy(),
+                            "beta": self.param(name + "/batchnorm/beta").cpu().numpy(),
+                            "moving_mean": self.moving_mean[o:o + s.cout].cpu().numpy(),
+                            "moving_variance": self.moving_var[o:o + s.cout].cpu().numpy()}
+        model.load_tf_weights(layers)
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc(self) -> None:
+        g, B, dev = self.graph, self.B, self.device
+        bf = torch.bfloat16
+        self.act: Dict[str, torch.Tensor] = {}
+        self.dact: Dict[str, torch.Tensor] = {}
+        for name, (h, w, c) in g.shapes.items():
+            if name == "input":
+                continue
+            self.act[name] = torch.zeros(B, h, w, c, dtype=bf, device=dev)
+            self.dact[name] = torch.zeros(B, h, w, c, dtype=bf, device=dev)
+        self.z: Dict[str, torch.Tensor] = {}
+        self.argmax: Dict[int, torch.Tensor] = {}
+        for i, op in enumerate(g.ops):
+            if op.kind == "conv":
+                ho, wo, _ = g.shapes[op.dst]
+                self.z[op.conv.name] = torch.empty(B, ho, wo, op.conv.cout, dtype=bf, device=dev)
+            elif op.kind == "maxpool":
+                ho, wo, _ = g.shapes[op.dst]
+                self.argmax[i] = torch.empty(B, ho, wo, op.channels, dtype=torch.uint8, device=dev)
+        # per-step scratch, zeroed by one memset: [fwd sum|sumsq] and [bwd s1|s2] per conv
+        self.scratch = torch.zeros(4 * self.stat_total, dtype=torch.float32, device=dev)
+        self.bn = torch.zeros(4 * self.stat_total, dtype=torch.float32, device=dev)  # mean, rstd, scale, shift per conv
+        self.feat = torch.zeros(B, BOTTLENECK_TENSOR_SIZE, dtype=torch.float32, device=dev)
+        self.dfeat = torch.zeros_like(self.feat)
+        self.last_loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self.last_correct = torch.zeros((), dtype=torch.float32, device=dev)
+
+    def activation_bytes(self) -> int:
+        n = sum(t.numel() * t.element_size() for d in (self.act, self.dact, self.z) for t in d.values())
+        return n + sum(t.numel() for t in self.argmax.values())
+
+    def _plan_backward(self) -> None:
+        """Static first-writer analysis: the first backward op that produces a gradient for a buffer stores, later
+        ones (other branches reading the same tensor) accumulate."""
+        written = set()
+        self.accumulate: Dict[int, bool] = {}
+        ops = self.graph.ops
+        for i in range(len(ops) - 1, -1, -1):
+            op = ops[i]
+            if op.kind == "gap":
+                written.add(op.src)
+                continue
+            if op.src == "input":
+                continue
+            self.accumulate[i] = op.src in written
+            written.add(op.src)
+
+    # ------------------------------------------------------------------ forward / backward
+    def _stats(self, name: str, which: int) -> int:
+        """Device pointer of the [2][Cout] scratch block of conv ``name`` (which: 0 = forward stats, 1 = backward sums)."""
+        return self.scratch.data_ptr() + 4 * (2 * self.stat_total * which + 2 * self.stat_off[name])
+
+    def _bn_ptr(self, name: str) -> int:
+        return self.bn.data_ptr() + 4 * 4 * self.stat_off[name]
+
+    def forward(self, x: torch.Tensor, training: bool = True) -> torch.Tensor:
+        g, B, lib, chk = self.graph, self.B, self.lib, self.native.check
+        assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and tuple(x.shape) == (B, 299, 299, INPUT_PAD_CHANNELS)
+        st = torch.cuda.current_stream().cuda_stream
+        self.scratch.zero_()
+        self._x = x
+        for i, op in enumerate(g.ops):
+            src = x if op.src == "input" else self.act[op.src]
+            _, H, W, Cs = src.shape
+            if op.kind == "conv":
+                s = op.conv
+                dst = self.act[op.dst]
+                _, Ho, Wo, Cd = dst.shape
+                z = self.z[s.name]
+                M = B * Ho * Wo
+                chk(lib.dtf_conv_fwd_stats(src.data_ptr(), self.param(s.name + "/conv2d_params").data_ptr(), z.data_ptr(),
+                                           self._stats(s.name, 0), B, H, W, s.cin, Cs, s.cout, s.kh, s.kw, s.stride,
+                                           s.pad[0], s.pad[1], Ho, Wo, st), "conv_fwd_stats " + s.name)
+                o = self.stat_off[s.name]
+                chk(lib.dtf_bn_finalize(self._stats(s.name, 0), self.param(s.name + "/batchnorm/gamma").data_ptr(),
+                                        self.param(s.name + "/batchnorm/beta").data_ptr(),
+                                        self.moving_mean.data_ptr() + 4 * o if training else 0,
+                                        self.moving_var.data_ptr() + 4 * o if training else 0,
+                                        self._bn_ptr(s.name), s.cout, M, BN_EPS, self.bn_momentum, st), "bn_finalize")
+                chk(lib.dtf_bn_relu_fwd(z.data_ptr(), self._bn_ptr(s.name), dst.data_ptr() + 2 * op.dst_off, M, s.cout, Cd, st),
+                    "bn_relu_fwd")
+            elif op.kind == "maxpool":
+                dst = self.act[op.dst]
+                chk(lib.dtf_maxpool3x3_arg(src.data_ptr(), dst.data_ptr() + 2 * op.dst_off, self.argmax[i].data_ptr(), B, H, W,
+                                           op.channels, Cs, dst.shape[3], op.stride, st), "maxpool_arg")
+            elif op.kind == "avgpool":
+                dst = self.act[op.dst]
+                chk(lib.dtf_avgpool3x3_same(src.data_ptr(), dst.data_ptr(), B, H, W, op.channels, Cs, dst.shape[3], st), "avgpool")
+            elif op.kind == "gap":
+                chk(lib.dtf_global_avgpool(src.data_ptr(), self.feat.data_ptr(), B, H * W, Cs, st), "gap")
+        return self.feat
+
+    def head_forward_backward(self, labels: torch.Tensor) -> None:
+        W = self.param("final_training_ops/weights/final_weights")
+        b = self.param("final_training_ops/biases/final_biases")
+        logits = torch.addmm(b, self.feat, W)
+        loss, dlogits, p = softmax_xent_grad(logits, labels, self.double_softmax)
+        self.last_loss.copy_(loss)
+        self.last_correct.copy_((p.argmax(1) == labels.long()).float().sum())
+        torch.mm(self.feat.t(), dlogits, out=self.grad("final_training_ops/weights/final_weights"))
+        self.grad("final_training_ops/biases/final_biases").copy_(dlogits.sum(0))
+        torch.mm(dlogits, W.t(), out=self.dfeat)
+
+    def _dw_splits(self, K: int, Cout: int, npos: int) -> int:
+        blocks = ((K + 127) // 128) * ((Cout + 63) // 64)
+        want = max(1, 1536 // blocks)
+        return max(1, min(want, npos // 512 if npos >= 512 else 1))
+
+    def backward(self, on_conv_done=None) -> None:
+        """Runs the backward program; ``on_conv_done(name)`` is called after the kernels that finalise conv ``name``'s
+        arena segment have been enqueued (the DP trainer launches bucket all-reduces from it)."""
+        g, B, lib, chk = self.graph, self.B, self.lib, self.native.check
+        st = torch.cuda.current_stream().cuda_stream
+        x = self._x
+        for i in range(len(g.ops) - 1, -1, -1):
+            op = g.ops[i]
+            src = x if op.src == "input" else self.act[op.src]
+            _, H, W, Cs = src.shape
+            if op.kind == "gap":
+                chk(lib.dtf_global_avgpool_bwd(self.dfeat.data_ptr(), self.dact[op.src].data_ptr(), B, H * W, Cs, st), "gap_bwd")
+                continue
+            dst, ddst = self.act[op.dst], self.dact[op.dst]
+            _, Ho, Wo, Cd = dst.shape
+            if op.kind == "conv":
+                s = op.conv
+                z = self.z[s.name]
+                M = B * Ho * Wo
+                dy_p, y_p = ddst.data_ptr() + 2 * op.dst_off, dst.data_ptr() + 2 * op.dst_off
+                chk(lib.dtf_bn_relu_bwd_reduce(dy_p, Cd, y_p, Cd, z.data_ptr(), self._bn_ptr(s.name), self._stats(s.name, 1),
+                                               M, s.cout, st), "bn_bwd_reduce")
+                chk(lib.dtf_bn_relu_bwd_apply(dy_p, Cd, y_p, Cd, z.data_ptr(), self._bn_ptr(s.name), self._stats(s.name, 1),
+                                              self.grad(s.name + "/batchnorm/gamma").data_ptr(),
+                                              self.grad(s.name + "/batchnorm/beta").data_ptr(), M, s.cout, st), "bn_bwd_apply")
+                K = s.kh * s.kw * s.cin
+                chk(lib.dtf_conv_dw_general(src.data_ptr(), Cs, z.data_ptr(), self.grad(s.name + "/conv2d_params").data_ptr(),
+                                            B, H, W, s.cin, s.cout, s.kh, s.kw, s.stride, s.pad[0], s.pad[1], Ho, Wo,
+                                            self._dw_splits(K, s.cout, M), st), "conv_dw " + s.name)
+                if op.src != "input":
+                    chk(lib.dtf_conv_bwd_data(z.data_ptr(), self.param(s.name + "/conv2d_params").data_ptr(),
+                                              self.dact[op.src].data_ptr(), B, H, W, s.cin, Cs, s.cout, s.kh, s.kw, s.stride,
+                                              s.pad[0], s.pad[1], Ho, Wo, int(self.accumulate[i]), st), "conv_bwd_data " + s.name)
+                if on_conv_done is not None:
+                    on_conv_done(s.name)
+            elif op.kind == "maxpool":
+                chk(lib.dtf_maxpool3x3_bwd(ddst.data_ptr() + 2 * op.dst_off, Cd, self.argmax[i].data_ptr(),
+                                           self.dact[op.src].data_ptr(), Cs, B, H, W, op.channels, op.stride,
+                                           int(self.accumulate[i]), st), "maxpool_bwd")
+            elif op.kind == "avgpool":
+                chk(lib.dtf_avgpool3x3_same_bwd(ddst.data_ptr(), Cd, self.dact[op.src].data_ptr(), Cs, B, H, W, op.channels,
+                                                int(self.accumulate[i]), st), "avgpool_bwd")
+
+    def apply(self) -> None:
+        from ..ops import hip_ops
+        scale = 1.0 / self.world
+        if self.optimizer == "adam":
+            hip_ops.adam_tf_(self.P, self.G, self.M, self.V, self.step_t, self.ticket, lr=self.lr, grad_scale=scale,
+                             zero_from=0)
+        else:
+            hip_ops.sgd_(self.P, self.G, self.step_t, self.ticket, lr=self.lr, grad_scale=scale, zero_from=0)
+
+    def fwd_bwd(self, x: torch.Tensor, labels: torch.Tensor, on_conv_done=None) -> None:
+        self.forward(x, training=True)
+        self.head_forward_backward(labels)
+        self.backward(on_conv_done)
+
+    def train_step(self, x: torch.Tensor, labels: torch.Tensor) -> None:
+        """One full step: forward, loss, backward, optimizer (which also re-zeroes the gradient arena)."""
+        self.fwd_bwd(x, labels)
+        self.apply()
+
+    def metrics(self) -> Tuple[float, float]:
+        return float(self.last_loss.item()), float(self.last_correct.item()) / self.B
+
+    def flops_per_step(self) -> float:
+        from .inception_v3 import graph_flops
+        return 3.0 * graph_flops(self.graph) * self.B
+
+
+# ------------------------------------------------------------------------------------------------ PyTorch oracle
+def torch_forward_train(graph, params: Dict[str, torch.Tensor], x_nchw: torch.Tensor, *, bf16_sim: bool = False,
+                        channels_last: bool = False, return_buffers: bool = False):
+    """Training-mode (batch statistics) forward of the op program with differentiable torch ops.
+    ``params[name + '/conv2d_params' | '/batchnorm/gamma' | '/batchnorm/beta']``; returns the [B,2048] features."""
+    r = (lambda t: t + (t.to(torch.bfloat16).to(t.dtype) - t).detach()) if bf16_sim else (lambda t: t)
+    bufs: Dict[str, List[Tuple[int, torch.Tensor]]] = {}
+    whole: Dict[str, torch.Tensor] = {"input": x_nchw}
+
+    def get(name):
+        if name not in whole:
+            parts = sorted(bufs[name], key=lambda t: t[0])
+            whole[name] = torch.cat([p for _o, p in parts], dim=1)
+        return whole[name]
+
+    feat = None
+    for op in graph.ops:
+        src = get(op.src)
+        if op.kind == "conv":
+            s = op.conv
+            w = params[s.name + "/conv2d_params"]
+            w = r(w[:, :, :src.shape[1], :]).permute(3, 2, 0, 1)
+            if channels_last:
+                w = w.contiguous(memory_format=torch.channels_last)
+            z = r(F.conv2d(src, w.to(src.dtype), None, stride=s.stride, padding=s.pad))
+            zf = z.float()
+            mean = zf.mean((0, 2, 3), keepdim=True)
+            var = zf.var((0, 2, 3), unbiased=False, keepdim=True)
+            gmm = params[s.name + "/batchnorm/gamma"].view(1, -1, 1, 1)
+            bta = params[s.name + "/batchnorm/beta"].view(1, -1, 1, 1)
+            y = r(F.relu((zf - mean) * torch.rsqrt(var + BN_EPS) * gmm + bta)).to(src.dtype)
+        elif op.kind == "maxpool":
+            y = F.max_pool2d(src, 3, op.stride)
+        elif op.kind == "avgpool":
+            y = r(F.avg_pool2d(src, 3, 1, 1, count_include_pad=False))
+        elif op.kind == "gap":
+            feat = src.float().mean((2, 3))
+            continue
+        bufs.setdefault(op.dst, []).append((op.dst_off, y))
+    if return_buffers:
+        return feat, {name: get(name) for name in bufs}
+    return feat
+
+
+def torch_train_step(graph, params: Dict[str, torch.Tensor], x_nchw: torch.Tensor, labels: torch.Tensor, *,
+                     double_softmax: bool = False, bf16_sim: bool = False):
+    """Oracle: (loss, {name: grad}) of one step with autograd."""
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    feat = torch_forward_train(graph, leaf, x_nchw, bf16_sim=bf16_sim)
+    logits = feat @ leaf["final_training_ops/weights/final_weights"] + leaf["final_training_ops/biases/final_biases"]
+    if double_softmax:
+        loss = F.cross_entropy(torch.softmax(logits, 1), labels.long())
+    else:
+        loss = F.cross_entropy(logits, labels.long())
+    grads = torch.autograd.grad(loss, list(leaf.values()), allow_unused=True)
+    return loss.detach(), dict(zip(leaf.keys(), grads)), feat.detach()

@@ -1,0 +1,284 @@
+"""Training-mode Inception kernels (csrc/hip/conv_train.hip) vs PyTorch autograd on the same bf16-rounded operands,
+and the full native fine-tune step vs the autograd oracle of the whole network (GPU only)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def _lib():
+    from distributed_tensorflow_amd import native
+    return native.hip(), native.check
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _r(t):
+    return t.to(BF).float()
+
+
+def _relerr(a, b):
+    return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-12))
+
+
+GEOMS = [  # H, W, Cin, Cout, KH, KW, stride, pad_h, pad_w
+    (17, 17, 128, 128, 1, 7, 1, 0, 3),
+    (17, 17, 160, 192, 7, 1, 1, 3, 0),
+    (35, 35, 48, 64, 5, 5, 1, 2, 2),
+    (35, 35, 288, 384, 3, 3, 2, 0, 0),
+    (8, 8, 448, 384, 3, 3, 1, 1, 1),
+    (13, 13, 80, 32, 1, 1, 1, 0, 0),
+    (21, 21, 8, 32, 3, 3, 2, 0, 0),
+]
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_conv_forward_stats_backward_data_and_filter(geom):
+    lib, chk = _lib()
+    H, W, Cin, Cout, KH, KW, s, ph, pw = geom
+    B = 3
+    torch.manual_seed(H * 7 + Cin)
+    Ho, Wo = (H + 2 * ph - KH) // s + 1, (W + 2 * pw - KW) // s + 1
+    Ctot = Cin + 16  # the input is a channel slice [8, 8+Cin) of a wider buffer
+    xfull = torch.randn(B, H, W, Ctot, device="cuda").to(BF)
+    w = (torch.randn(KH, KW, Cin, Cout, device="cuda") / (KH * KW * Cin) ** 0.5).contiguous()
+    z = torch.empty(B, Ho, Wo, Cout, dtype=BF, device="cuda")
+    stats = torch.zeros(2, Cout, device="cuda")
+    chk(lib.dtf_conv_fwd_stats(xfull.data_ptr() + 2 * 8, w.data_ptr(), z.data_ptr(), stats.data_ptr(), B, H, W, Cin, Ctot, Cout,
+                               KH, KW, s, ph, pw, Ho, Wo, _st()), "fwd")
+    x = xfull[..., 8:8 + Cin].float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    wt = _r(w).permute(3, 2, 0, 1).contiguous().requires_grad_(True)
+    ref = F.conv2d(x, wt, stride=s, padding=(ph, pw))
+    assert _relerr(z.permute(0, 3, 1, 2), ref) < 1e-2
+    zf = z.float()
+    assert _relerr(stats[0], zf.sum((0, 1, 2))) < 1e-4 * max(1.0, (B * Ho * Wo) ** 0.5)
+    assert _relerr(stats[1], (zf * zf).sum((0, 1, 2))) < 1e-4
+
+    dz = torch.randn(B, Ho, Wo, Cout, device="cuda").to(BF)
+    gx, gw = torch.autograd.grad(ref, (x, wt), dz.float().permute(0, 3, 1, 2))
+    # backward-data into a slice of a wider gradient buffer, then accumulated on top of itself
+    dxfull = torch.full((B, H, W, Ctot), 7.0, dtype=BF, device="cuda")
+    for acc in (0, 1):
+        chk(lib.dtf_conv_bwd_data(dz.data_ptr(), w.data_ptr(), dxfull.data_ptr() + 2 * 8, B, H, W, Cin, Ctot, Cout, KH, KW, s,
+                                  ph, pw, Ho, Wo, acc, _st()), "bwd_data")
+        got = dxfull[..., 8:8 + Cin].float()
+        want = gx.permute(0, 2, 3, 1) * (acc + 1)
+        assert _relerr(got, want) < 2e-2, acc
+    assert float((dxfull[..., :8].float() - 7.0).abs().max()) == 0.0 and float((dxfull[..., 8 + Cin:].float() - 7.0).abs().max()) == 0.0
+    # filter gradient (split-K atomics into a zeroed HWIO buffer)
+    for splits in (1, 5):
+        dW = torch.zeros(KH, KW, Cin, Cout, device="cuda")
+        chk(lib.dtf_conv_dw_general(xfull.data_ptr() + 2 * 8, Ctot, dz.data_ptr(), dW.data_ptr(), B, H, W, Cin, Cout, KH, KW, s,
+                                    ph, pw, Ho, Wo, splits, _st()), "dw")
+        assert _relerr(dW, gw.permute(2, 3, 1, 0)) < 5e-3, splits
+
+
+@pytest.mark.parametrize("M,C", [(3 * 17 * 17, 192), (2 * 35 * 35, 48), (5 * 8 * 8, 448), (700, 32)])
+def test_batchnorm_relu_forward_backward(M, C):
+    lib, chk = _lib()
+    torch.manual_seed(M + C)
+    Cd = C + 24
+    z = (torch.randn(M, C, device="cuda") * 1.7 + 0.3).to(BF)
+    gamma = torch.rand(C, device="cuda") + 0.5
+    beta = torch.randn(C, device="cuda") * 0.2
+    zf = z.float()
+    stats = torch.stack([zf.sum(0), (zf * zf).sum(0)]).contiguous()
+    mm, mv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    bn = torch.zeros(4, C, device="cuda")
+    chk(lib.dtf_bn_finalize(stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr(), bn.data_ptr(), C, M,
+                            1e-3, 0.9, _st()), "fin")
+    mean, var = zf.mean(0), zf.var(0, unbiased=False)
+    assert _relerr(bn[0], mean) < 1e-4 and _relerr(bn[1], torch.rsqrt(var + 1e-3)) < 1e-3
+    assert _relerr(mm, 0.1 * mean) < 1e-4 and _relerr(mv, 0.9 + 0.1 * var) < 1e-3
+    ybuf = torch.zeros(M, Cd, dtype=BF, device="cuda")
+    chk(lib.dtf_bn_relu_fwd(z.data_ptr(), bn.data_ptr(), ybuf.data_ptr() + 2 * 16, M, C, Cd, _st()), "fwd")
+    zl = zf.clone().requires_grad_(True)
+    gl, bl = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yref = F.relu((zl - zl.mean(0)) * torch.rsqrt(zl.var(0, unbiased=False) + 1e-3) * gl + bl)
+    assert _relerr(ybuf[:, 16:16 + C], yref) < 1e-2
+    assert float(ybuf[:, :16].float().abs().max()) == 0.0
+    dybuf = torch.randn(M, Cd, device="cuda").to(BF)
+    dy = dybuf[:, 16:16 + C].float()
+    # the native backward masks with the stored (bf16) y > 0
+    mask = (ybuf[:, 16:16 + C].float() > 0).float()
+    gz, gg, gb = torch.autograd.grad(yref, (zl, gl, bl), dy * mask + 0 * dy)
+    sums = torch.zeros(2, C, device="cuda")
+    chk(lib.dtf_bn_relu_bwd_reduce(dybuf.data_ptr() + 2 * 16, Cd, ybuf.data_ptr() + 2 * 16, Cd, z.data_ptr(), bn.data_ptr(),
+                                   sums.data_ptr(), M, C, _st()), "reduce")
+    dgamma, dbeta = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    chk(lib.dtf_bn_relu_bwd_apply(dybuf.data_ptr() + 2 * 16, Cd, ybuf.data_ptr() + 2 * 16, Cd, z.data_ptr(), bn.data_ptr(),
+                                  sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), M, C, _st()), "apply")
+    assert _relerr(dbeta, gb) < 2e-3 and _relerr(dgamma, gg) < 5e-3
+    assert _relerr(z, gz) < 2e-2  # z now holds dz
+
+
+def test_pool_backward_kernels():
+    lib, chk = _lib()
+    torch.manual_seed(5)
+    B, H, W, C = 2, 17, 17, 40
+    Cs, Cd = C + 8, C + 16
+    xfull = torch.relu(torch.randn(B, H, W, Cs, device="cuda")).to(BF)  # ReLU zeros -> ties inside windows
+    Ho = Wo = (H - 3) // 2 + 1
+    out = torch.zeros(B, Ho, Wo, Cd, dtype=BF, device="cuda")
+    arg = torch.zeros(B, Ho, Wo, C, dtype=torch.uint8, device="cuda")
+    chk(lib.dtf_maxpool3x3_arg(xfull.data_ptr(), out.data_ptr() + 2 * 8, arg.data_ptr(), B, H, W, C, Cs, Cd, 2, _st()), "mp")
+    x = xfull[..., :C].float().permute(0, 3, 1, 2).contiguous()
+    ref, idx = F.max_pool2d(x, 3, 2, return_indices=True)
+    assert torch.equal(out[..., 8:8 + C].float().permute(0, 3, 1, 2), ref)
+    dyfull = torch.randn(B, Ho, Wo, Cd, device="cuda").to(BF)
+    dx = torch.full((B, H, W, Cs), 3.0, dtype=BF, device="cuda")
+    chk(lib.dtf_maxpool3x3_bwd(dyfull.data_ptr() + 2 * 8, Cd, arg.data_ptr(), dx.data_ptr(), Cs, B, H, W, C, 2, 0, _st()), "mpb")
+    dy = dyfull[..., 8:8 + C].float().permute(0, 3, 1, 2).contiguous()
+    # reference with the first-maximum convention (what the kernel and TF's MaxPoolGrad use)
+    a = arg.long().permute(0, 3, 1, 2)
+    hh = torch.arange(Ho, device="cuda").view(1, 1, Ho, 1) * 2 + a // 3
+    ww = torch.arange(Wo, device="cuda").view(1, 1, 1, Wo) * 2 + a % 3
+    want = torch.zeros(B, C, H * W, device="cuda")
+    want.scatter_add_(2, (hh * W + ww).reshape(B, C, -1), dy.reshape(B, C, -1))
+    want = want.view(B, C, H, W)
+    picked = torch.gather(x.reshape(B, C, -1), 2, (hh * W + ww).reshape(B, C, -1)).view_as(ref)
+    assert torch.equal(picked, ref)  # the stored argmax really points at a maximum
+    assert _relerr(dx[..., :C].float().permute(0, 3, 1, 2), want) < 1e-2
+    assert float((dx[..., C:].float() - 3.0).abs().max()) == 0.0
+    chk(lib.dtf_maxpool3x3_bwd(dyfull.data_ptr() + 2 * 8, Cd, arg.data_ptr(), dx.data_ptr(), Cs, B, H, W, C, 2, 1, _st()), "mpb2")
+    assert _relerr(dx[..., :C].float().permute(0, 3, 1, 2), 2 * want) < 2e-2
+
+    # average pool 3x3 SAME, padding excluded from the divisor
+    xa = torch.randn(B, C, H, W, device="cuda", requires_grad=True)
+    ya = F.avg_pool2d(xa, 3, 1, 1, count_include_pad=False)
+    dya = torch.randn(B, H, W, C, device="cuda").to(BF)
+    (gxa,) = torch.autograd.grad(ya, xa, dya.float().permute(0, 3, 1, 2))
+    dxa = torch.zeros(B, H, W, Cs, dtype=BF, device="cuda")
+    chk(lib.dtf_avgpool3x3_same_bwd(dya.data_ptr(), C, dxa.data_ptr(), Cs, B, H, W, C, 0, _st()), "apb")
+    assert _relerr(dxa[..., :C].float().permute(0, 3, 1, 2), gxa) < 1e-2
+
+    df = torch.randn(B, 64, device="cuda")
+    dxg = torch.zeros(B, 8, 8, 64, dtype=BF, device="cuda")
+    chk(lib.dtf_global_avgpool_bwd(df.data_ptr(), dxg.data_ptr(), B, 64, 64, _st()), "gapb")
+    assert _relerr(dxg.float(), (df / 64).view(B, 1, 1, 64).expand(B, 8, 8, 64)) < 1e-2
+
+
+def _l2err(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _cos(a, b):
+    a, b = a.float().flatten(), b.float().flatten()
+    return float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+
+
+def test_full_network_step_matches_autograd_layerwise():
+    """A random-init 47-layer BatchNorm net amplifies bf16 rounding noise ~1.5x per block (measured: exact in the stem,
+    4% at mixed_4, 30% at mixed_10 against the bf16-simulating oracle), so the end-to-end comparison is only a loose
+    sanity check; the rigorous check is teacher-forced: every conv's forward and all of its gradients are recomputed
+    with autograd from the native executor's own input activation and upstream gradient."""
+    from distributed_tensorflow_amd.models.inception_train import InceptionTrainer, torch_train_step
+    from distributed_tensorflow_amd.models.inception_v3 import BN_EPS
+    torch.manual_seed(0)
+    B, C = 4, 5
+    tr = InceptionTrainer(C, B, "cuda", lr=0.01, seed=3)
+    x = torch.zeros(B, 299, 299, 8, device="cuda")
+    x[..., :3] = torch.randn(B, 299, 299, 3, device="cuda")
+    x = x.to(BF)
+    labels = torch.tensor([0, 3, 1, 4], device="cuda", dtype=torch.int32)
+    params = {k: tr.layout.view(tr.P, k).clone() for k in tr.layout.entries}
+    tr.fwd_bwd(x, labels)
+    torch.cuda.synchronize()
+    loss_ref, grads, feat_ref = torch_train_step(tr.graph, params, x[..., :3].float().permute(0, 3, 1, 2).contiguous(), labels,
+                                                 bf16_sim=True)
+    loss, acc = tr.metrics()
+    assert _cos(tr.feat, feat_ref) > 0.98
+    assert abs(loss - float(loss_ref)) < 5e-2
+    # head gradients from the native features
+    W = params["final_training_ops/weights/final_weights"].clone().requires_grad_(True)
+    b = params["final_training_ops/biases/final_biases"].clone().requires_grad_(True)
+    f = tr.feat.clone().requires_grad_(True)
+    l = F.cross_entropy(f @ W + b, labels.long())
+    gW, gb_, gf = torch.autograd.grad(l, (W, b, f))
+    assert _relerr(tr.grad("final_training_ops/weights/final_weights"), gW) < 1e-3
+    assert _relerr(tr.grad("final_training_ops/biases/final_biases"), gb_) < 1e-3
+    assert _relerr(tr.dfeat, gf) < 1e-3
+    consumers = {}
+    for op in tr.graph.ops:
+        consumers[op.src] = consumers.get(op.src, 0) + 1
+    worst = {"y": 0.0, "dW": 0.0, "dgamma": 0.0, "dbeta": 0.0, "dx": 0.0}
+    n_dx = 0
+    for op in tr.graph.ops:
+        if op.kind != "conv":
+            continue
+        s = op.conv
+        src = x if op.src == "input" else tr.act[op.src]
+        xin = src.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+        w = _r(params[s.name + "/conv2d_params"]).permute(3, 2, 0, 1).contiguous().requires_grad_(True)
+        gm = params[s.name + "/batchnorm/gamma"].clone().requires_grad_(True)
+        bt = params[s.name + "/batchnorm/beta"].clone().requires_grad_(True)
+        z = F.conv2d(xin, w, stride=s.stride, padding=s.pad)
+        z = z + (_r(z) - z).detach()
+        mean, var = z.mean((0, 2, 3), keepdim=True), z.var((0, 2, 3), unbiased=False, keepdim=True)
+        y = F.relu((z - mean) * torch.rsqrt(var + BN_EPS) * gm.view(1, -1, 1, 1) + bt.view(1, -1, 1, 1))
+        y_nat = tr.act[op.dst][..., op.dst_off:op.dst_off + s.cout].float().permute(0, 3, 1, 2)
+        dy = tr.dact[op.dst][..., op.dst_off:op.dst_off + s.cout].float().permute(0, 3, 1, 2)
+        gx, gw, gg, gb = torch.autograd.grad(y, (xin, w, gm, bt), dy)
+        errs = {"y": _l2err(y_nat, y.detach()), "dW": _l2err(tr.grad(s.name + "/conv2d_params"), gw.permute(2, 3, 1, 0)),
+                "dgamma": _l2err(tr.grad(s.name + "/batchnorm/gamma"), gg), "dbeta": _l2err(tr.grad(s.name + "/batchnorm/beta"), gb)}
+        if op.src != "input" and consumers[op.src] == 1:
+            errs["dx"] = _l2err(tr.dact[op.src], gx.permute(0, 2, 3, 1))
+            n_dx += 1
+        for k, v in errs.items():
+            worst[k] = max(worst[k], v)
+            assert v < 2e-2, (s.name, k, v)
+    print("worst layerwise relative L2 errors:", worst)
+    assert n_dx > 40
+    # branch points: the gradient of a block input is the sum over its four consumers
+    for blk_src, blk in (("mixed_8", "mixed_9"), ("pool_1:out", "mixed")):
+        xin = tr.act[blk_src].float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+        total = torch.zeros_like(xin)
+        for op in tr.graph.ops:
+            if op.src != blk_src:
+                continue
+            if op.kind == "conv":
+                s = op.conv
+                w = _r(params[s.name + "/conv2d_params"]).permute(3, 2, 0, 1).contiguous()
+                z = F.conv2d(xin, w, stride=s.stride, padding=s.pad)
+                z = z + (_r(z) - z).detach()
+                mean, var = z.mean((0, 2, 3), keepdim=True), z.var((0, 2, 3), unbiased=False, keepdim=True)
+                y = F.relu((z - mean) * torch.rsqrt(var + BN_EPS) * params[s.name + "/batchnorm/gamma"].view(1, -1, 1, 1)
+                           + params[s.name + "/batchnorm/beta"].view(1, -1, 1, 1))
+                dy = tr.dact[op.dst][..., op.dst_off:op.dst_off + s.cout].float().permute(0, 3, 1, 2)
+            elif op.kind == "avgpool":
+                y = F.avg_pool2d(xin, 3, 1, 1, count_include_pad=False)
+                dy = tr.dact[op.dst].float().permute(0, 3, 1, 2)
+            else:
+                continue
+            total = total + torch.autograd.grad(y, xin, dy)[0]
+        assert _l2err(tr.dact[blk_src], total.permute(0, 2, 3, 1)) < 2e-2, blk_src
+    # the optimizer step consumes and clears the gradient arena
+    p0 = tr.P.clone()
+    g0 = tr.G.clone()
+    tr.apply()
+    torch.cuda.synchronize()
+    assert torch.allclose(tr.P, p0 - 0.01 * g0, atol=1e-6) and float(tr.G.abs().max()) == 0.0
+    assert int(tr.step_t.item()) == 1
+
+
+def test_fine_tune_learns_on_tiny_problem():
+    from distributed_tensorflow_amd.models.inception_train import InceptionTrainer
+    torch.manual_seed(1)
+    B, C = 8, 2
+    tr = InceptionTrainer(C, B, "cuda", lr=0.05, seed=5, head_std=0.01)
+    x = torch.zeros(B, 299, 299, 8, device="cuda")
+    labels = torch.arange(B, device="cuda", dtype=torch.int32) % 2
+    x[..., :3] = torch.randn(B, 299, 299, 3, device="cuda") * 0.3 + (labels.float().view(B, 1, 1, 1) - 0.5)
+    x = x.to(BF)
+    losses = []
+    for _ in range(12):
+        tr.train_step(x, labels)
+        losses.append(tr.metrics()[0])
+    assert all(l == l for l in losses)
+    assert losses[-1] < 0.5 * losses[0], losses
