@@ -103,15 +103,24 @@ DTF_API int dtf_conv_dw_general(const void* x, int in_cstride, const void* dz, f
 }
 
 // ------------------------------------------------------------------------------------------------ batch norm
-// bn[4][C] = mean, rstd, scale (= gamma*rstd), shift (= beta - mean*scale); moving stats updated in place.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ gamma,
+// bn[4][C] = mean, rstd, scale (= gamma*rstd), shift (= beta - mean*scale) from stats[DTF_STAT_SLOTS][2][C] (which is
+// cleared again); moving stats updated in place.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(float* __restrict__ stats, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ mmean,
                                                           float* __restrict__ mvar, float* __restrict__ bn, int C,
                                                           float inv_count, float eps, float momentum) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  const float mean = stats[c] * inv_count;
-  const float var = fmaxf(stats[C + c] * inv_count - mean * mean, 0.f);
+  float s = 0.f, ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < DTF_STAT_SLOTS; ++k) {
+    s += stats[(2 * k) * C + c];
+    ss += stats[(2 * k + 1) * C + c];
+    stats[(2 * k) * C + c] = 0.f;  // re-arm the accumulators for the next step (this kernel is their only reader)
+    stats[(2 * k + 1) * C + c] = 0.f;
+  }
+  const float mean = s * inv_count;
+  const float var = fmaxf(ss * inv_count - mean * mean, 0.f);
   const float rstd = rsqrtf(var + eps);
   const float scale = gamma[c] * rstd;
   bn[c] = mean;
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
-DTF_API int dtf_bn_finalize(const float* stats, const float* gamma, const float* beta, float* moving_mean,
+DTF_API int dtf_bn_finalize(float* stats, const float* gamma, const float* beta, float* moving_mean,
                             float* moving_var, float* bn, int C, long count, float eps, float momentum, hipStream_t st) {
   if (C <= 0 || count <= 0) return ERR_SHAPE;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(dtf_cdiv(C, 256)), dim3(256), 0, st, stats, gamma, beta, moving_mean,
@@ -159,12 +168,18 @@ DTF_API int dtf_bn_relu_fwd(const void* z, const float* bn, void* y, long M, int
   return 0;
 }
 
-// sums[2][C] += (sum g, sum g*xhat) with g = dy * (y > 0), xhat = (z - mean) * rstd
+// sums[2][C] = (sum g, sum g*xhat) with g = dy * (y > 0), xhat = (z - mean) * rstd; dbeta = sums[0], dgamma = sums[1].
+// Workgroups accumulate into DTF_STAT_SLOTS replicas (atomic contention, see EpBf16Stats); the last workgroup to
+// finish (device-scope ticket) folds the replicas into `sums`, emits dgamma/dbeta and re-arms replicas + ticket.
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const uint16_t* __restrict__ dy, int dy_cs,
                                                                  const uint16_t* __restrict__ y, int y_cs,
                                                                  const uint16_t* __restrict__ z, const float* __restrict__ bn,
-                                                                 float* __restrict__ sums, long M, int C, int rows_per_block) {
+                                                                 float* __restrict__ slots, float* __restrict__ sums,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                 unsigned* __restrict__ ticket, long M, int C,
+                                                                 int rows_per_block) {
   __shared__ float red[256 * 16];
+  __shared__ int is_last;
   const int c8n = C >> 3;
   const int rpb = 256 / c8n;
   const int tid = threadIdx.x;
@@ -179,7 +194,29 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const uint16_t*
     ld8f(bn + C + c0, rstd);
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-    for (long r = r0 + ry; r < r1; r += rpb) {
+    long r = r0 + ry;
+    for (; r + rpb < r1; r += 2 * rpb) {  // two rows in flight per lane
+      const long rb = r + rpb;
+      const uint4 ga = *reinterpret_cast<const uint4*>(dy + r * dy_cs + c0), gb = *reinterpret_cast<const uint4*>(dy + rb * dy_cs + c0);
+      const uint4 ya = *reinterpret_cast<const uint4*>(y + r * y_cs + c0), yb = *reinterpret_cast<const uint4*>(y + rb * y_cs + c0);
+      const uint4 za = *reinterpret_cast<const uint4*>(z + r * C + c0), zb = *reinterpret_cast<const uint4*>(z + rb * C + c0);
+      float g[8], yy[8], zz[8];
+      unpack8(ga, g); unpack8(ya, yy); unpack8(za, zz);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gj = yy[j] > 0.f ? g[j] : 0.f;
+        s1[j] += gj;
+        s2[j] += gj * (zz[j] - mean[j]) * rstd[j];
+      }
+      unpack8(gb, g); unpack8(yb, yy); unpack8(zb, zz);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gj = yy[j] > 0.f ? g[j] : 0.f;
+        s1[j] += gj;
+        s2[j] += gj * (zz[j] - mean[j]) * rstd[j];
+      }
+    }
+    if (r < r1) {
       float g[8], yy[8], zz[8];
       unpack8(*reinterpret_cast<const uint4*>(dy + r * dy_cs + c0), g);
       unpack8(*reinterpret_cast<const uint4*>(y + r * y_cs + c0), yy);
@@ -205,27 +242,49 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const uint16_t*
         s1[j] += red[(k * c8n + cg) * 16 + j];
         s2[j] += red[(k * c8n + cg) * 16 + 8 + j];
       }
+    float* slot = slots + (long)(blockIdx.x % DTF_STAT_SLOTS) * 2 * C;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      atomicAdd(&sums[c0 + j], s1[j]);
-      atomicAdd(&sums[C + c0 + j], s2[j]);
+      atomicAdd(&slot[c0 + j], s1[j]);
+      atomicAdd(&slot[C + c0 + j], s2[j]);
     }
   }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) is_last = (atomicAdd(ticket, 1u) == gridDim.x - 1);
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  for (int i = tid; i < 2 * C; i += 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < DTF_STAT_SLOTS; ++k) {
+      t += __hip_atomic_load(&slots[(long)k * 2 * C + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      slots[(long)k * 2 * C + i] = 0.f;
+    }
+    sums[i] = t;
+    if (dgamma) {
+      if (i < C) dbeta[i] = t;
+      else dgamma[i - C] = t;
+    }
+  }
+  if (tid == 0) *ticket = 0u;
 }
 
 DTF_API int dtf_bn_relu_bwd_reduce(const void* dy, int dy_cstride, const void* y, int y_cstride, const void* z,
-                                   const float* bn, float* sums, long M, int C, hipStream_t st) {
-  if (M <= 0 || C <= 0 || C % 8 || C > 2048 || dy_cstride % 8 || y_cstride % 8) return ERR_SHAPE;
+                                   const float* bn, float* slots, float* sums, float* dgamma, float* dbeta,
+                                   unsigned* ticket, long M, int C, hipStream_t st) {
+  if (M <= 0 || C <= 0 || C % 8 || C > 2048 || dy_cstride % 8 || y_cstride % 8 || !ticket) return ERR_SHAPE;
   const int rpb = 256 / (C / 8);
-  long rows = (M + 1023) / 1024;
+  long rows = (M + 511) / 512;  // <= 512 workgroups: two per CU stream the three tensors
   if (rows < 8L * rpb) rows = 8L * rpb;
   hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(dtf_cdiv(M, rows)), dim3(256), 0, st, (const uint16_t*)dy, dy_cstride,
-                     (const uint16_t*)y, y_cstride, (const uint16_t*)z, bn, sums, M, C, (int)rows);
+                     (const uint16_t*)y, y_cstride, (const uint16_t*)z, bn, slots, sums, dgamma, dbeta, ticket, M, C, (int)rows);
   DTF_CHECK_LAUNCH();
   return 0;
 }
 
-// z <- dz = scale * (g - s1/M - xhat * s2/M)  in place; block 0 also emits dgamma = s2, dbeta = s1.
+// z <- dz = scale * (g - s1/M - xhat * s2/M)  in place (dgamma/dbeta may be null: the reduce kernel already wrote them).
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const uint16_t* __restrict__ dy, int dy_cs,
                                                                 const uint16_t* __restrict__ y, int y_cs,
                                                                 uint16_t* __restrict__ z, const float* __restrict__ bn,

@@ -35,6 +35,7 @@ import torch.nn.functional as F
 from .inception_v3 import BN_EPS, BOTTLENECK_TENSOR_SIZE, INPUT_PAD_CHANNELS, InceptionV3, build_graph
 
 ALIGN = 64  # arena segment alignment in elements (256 B)
+STAT_SLOTS = 16  # DTF_STAT_SLOTS in csrc/hip/gemm_core.h
 
 
 def _round_up(n: int, a: int = ALIGN) -> int:
@@ -196,8 +197,12 @@ class InceptionTrainer:
             elif op.kind == "maxpool":
                 ho, wo, _ = g.shapes[op.dst]
                 self.argmax[i] = torch.empty(B, ho, wo, op.channels, dtype=torch.uint8, device=dev)
-        # per-step scratch, zeroed by one memset: [fwd sum|sumsq] and [bwd s1|s2] per conv
-        self.scratch = torch.zeros(4 * self.stat_total, dtype=torch.float32, device=dev)
+        # statistic accumulators: STAT_SLOTS replicas of [fwd sum|sumsq] and of [bwd s1|s2] per conv (their consumer
+        # kernels re-zero them, so no per-step memset), the folded backward sums, and one ticket per conv
+        self.scratch = torch.zeros(2 * STAT_SLOTS * 2 * self.stat_total, dtype=torch.float32, device=dev)
+        self.bsums = torch.zeros(2 * self.stat_total, dtype=torch.float32, device=dev)
+        self.tickets = torch.zeros(len(g.convs), dtype=torch.int32, device=dev)
+        self.conv_index = {name: k for k, name in enumerate(g.convs)}
         self.bn = torch.zeros(4 * self.stat_total, dtype=torch.float32, device=dev)  # mean, rstd, scale, shift per conv
         self.feat = torch.zeros(B, BOTTLENECK_TENSOR_SIZE, dtype=torch.float32, device=dev)
         self.dfeat = torch.zeros_like(self.feat)
@@ -226,8 +231,11 @@ class InceptionTrainer:
 
     # ------------------------------------------------------------------ forward / backward
     def _stats(self, name: str, which: int) -> int:
-        """Device pointer of the [2][Cout] scratch block of conv ``name`` (which: 0 = forward stats, 1 = backward sums)."""
-        return self.scratch.data_ptr() + 4 * (2 * self.stat_total * which + 2 * self.stat_off[name])
+        """Device pointer of the [STAT_SLOTS][2][Cout] accumulator block of conv ``name`` (0 = forward stats, 1 = backward)."""
+        return self.scratch.data_ptr() + 4 * STAT_SLOTS * 2 * (self.stat_total * which + self.stat_off[name])
+
+    def _bsums(self, name: str) -> int:
+        return self.bsums.data_ptr() + 4 * 2 * self.stat_off[name]
 
     def _bn_ptr(self, name: str) -> int:
         return self.bn.data_ptr() + 4 * 4 * self.stat_off[name]
@@ -236,7 +244,6 @@ class InceptionTrainer:
         g, B, lib, chk = self.graph, self.B, self.lib, self.native.check
         assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and tuple(x.shape) == (B, 299, 299, INPUT_PAD_CHANNELS)
         st = torch.cuda.current_stream().cuda_stream
-        self.scratch.zero_()
         self._x = x
         for i, op in enumerate(g.ops):
             src = x if op.src == "input" else self.act[op.src]
@@ -306,10 +313,12 @@ class InceptionTrainer:
                 M = B * Ho * Wo
                 dy_p, y_p = ddst.data_ptr() + 2 * op.dst_off, dst.data_ptr() + 2 * op.dst_off
                 chk(lib.dtf_bn_relu_bwd_reduce(dy_p, Cd, y_p, Cd, z.data_ptr(), self._bn_ptr(s.name), self._stats(s.name, 1),
-                                               M, s.cout, st), "bn_bwd_reduce")
-                chk(lib.dtf_bn_relu_bwd_apply(dy_p, Cd, y_p, Cd, z.data_ptr(), self._bn_ptr(s.name), self._stats(s.name, 1),
-                                              self.grad(s.name + "/batchnorm/gamma").data_ptr(),
-                                              self.grad(s.name + "/batchnorm/beta").data_ptr(), M, s.cout, st), "bn_bwd_apply")
+                                               self._bsums(s.name), self.grad(s.name + "/batchnorm/gamma").data_ptr(),
+                                               self.grad(s.name + "/batchnorm/beta").data_ptr(),
+                                               self.tickets.data_ptr() + 4 * self.conv_index[s.name], M, s.cout, st),
+                    "bn_bwd_reduce")
+                chk(lib.dtf_bn_relu_bwd_apply(dy_p, Cd, y_p, Cd, z.data_ptr(), self._bn_ptr(s.name), self._bsums(s.name),
+                                              0, 0, M, s.cout, st), "bn_bwd_apply")
                 K = s.kh * s.kw * s.cin
                 chk(lib.dtf_conv_dw_general(src.data_ptr(), Cs, z.data_ptr(), self.grad(s.name + "/conv2d_params").data_ptr(),
                                             B, H, W, s.cin, s.cout, s.kh, s.kw, s.stride, s.pad[0], s.pad[1], Ho, Wo,

@@ -48,7 +48,7 @@ def test_conv_forward_stats_backward_data_and_filter(geom):
     xfull = torch.randn(B, H, W, Ctot, device="cuda").to(BF)
     w = (torch.randn(KH, KW, Cin, Cout, device="cuda") / (KH * KW * Cin) ** 0.5).contiguous()
     z = torch.empty(B, Ho, Wo, Cout, dtype=BF, device="cuda")
-    stats = torch.zeros(2, Cout, device="cuda")
+    stats = torch.zeros(16, 2, Cout, device="cuda")  # DTF_STAT_SLOTS replicas
     chk(lib.dtf_conv_fwd_stats(xfull.data_ptr() + 2 * 8, w.data_ptr(), z.data_ptr(), stats.data_ptr(), B, H, W, Cin, Ctot, Cout,
                                KH, KW, s, ph, pw, Ho, Wo, _st()), "fwd")
     x = xfull[..., 8:8 + Cin].float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
@@ -56,6 +56,7 @@ def test_conv_forward_stats_backward_data_and_filter(geom):
     ref = F.conv2d(x, wt, stride=s, padding=(ph, pw))
     assert _relerr(z.permute(0, 3, 1, 2), ref) < 1e-2
     zf = z.float()
+    stats = stats.sum(0)
     assert _relerr(stats[0], zf.sum((0, 1, 2))) < 1e-4 * max(1.0, (B * Ho * Wo) ** 0.5)
     assert _relerr(stats[1], (zf * zf).sum((0, 1, 2))) < 1e-4
 
@@ -87,7 +88,8 @@ def test_batchnorm_relu_forward_backward(M, C):
     gamma = torch.rand(C, device="cuda") + 0.5
     beta = torch.randn(C, device="cuda") * 0.2
     zf = z.float()
-    stats = torch.stack([zf.sum(0), (zf * zf).sum(0)]).contiguous()
+    stats = torch.zeros(16, 2, C, device="cuda")
+    stats[3] = torch.stack([zf.sum(0), (zf * zf).sum(0)])
     mm, mv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
     bn = torch.zeros(4, C, device="cuda")
     chk(lib.dtf_bn_finalize(stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr(), bn.data_ptr(), C, M,
@@ -95,6 +97,7 @@ def test_batchnorm_relu_forward_backward(M, C):
     mean, var = zf.mean(0), zf.var(0, unbiased=False)
     assert _relerr(bn[0], mean) < 1e-4 and _relerr(bn[1], torch.rsqrt(var + 1e-3)) < 1e-3
     assert _relerr(mm, 0.1 * mean) < 1e-4 and _relerr(mv, 0.9 + 0.1 * var) < 1e-3
+    assert float(stats.abs().max()) == 0.0  # accumulators re-armed
     ybuf = torch.zeros(M, Cd, dtype=BF, device="cuda")
     chk(lib.dtf_bn_relu_fwd(z.data_ptr(), bn.data_ptr(), ybuf.data_ptr() + 2 * 16, M, C, Cd, _st()), "fwd")
     zl = zf.clone().requires_grad_(True)
@@ -108,11 +111,16 @@ def test_batchnorm_relu_forward_backward(M, C):
     mask = (ybuf[:, 16:16 + C].float() > 0).float()
     gz, gg, gb = torch.autograd.grad(yref, (zl, gl, bl), dy * mask + 0 * dy)
     sums = torch.zeros(2, C, device="cuda")
-    chk(lib.dtf_bn_relu_bwd_reduce(dybuf.data_ptr() + 2 * 16, Cd, ybuf.data_ptr() + 2 * 16, Cd, z.data_ptr(), bn.data_ptr(),
-                                   sums.data_ptr(), M, C, _st()), "reduce")
+    slots = torch.zeros(16, 2, C, device="cuda")
+    ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
     dgamma, dbeta = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    for _ in range(2):  # twice: the kernel re-arms its accumulators and ticket
+        chk(lib.dtf_bn_relu_bwd_reduce(dybuf.data_ptr() + 2 * 16, Cd, ybuf.data_ptr() + 2 * 16, Cd, z.data_ptr(), bn.data_ptr(),
+                                       slots.data_ptr(), sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ticket.data_ptr(),
+                                       M, C, _st()), "reduce")
+    assert int(ticket.item()) == 0 and float(slots.abs().max()) == 0.0
     chk(lib.dtf_bn_relu_bwd_apply(dybuf.data_ptr() + 2 * 16, Cd, ybuf.data_ptr() + 2 * 16, Cd, z.data_ptr(), bn.data_ptr(),
-                                  sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), M, C, _st()), "apply")
+                                  sums.data_ptr(), 0, 0, M, C, _st()), "apply")
     assert _relerr(dbeta, gb) < 2e-3 and _relerr(dgamma, gg) < 5e-3
     assert _relerr(z, gz) < 2e-2  # z now holds dz
 
