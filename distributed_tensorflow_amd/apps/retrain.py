@@ -131,6 +131,16 @@ def run(FLAGS, distributed: bool) -> int:
         print("Only one valid folder of images found at " + image_dir +
               " - multiple classes are needed for classification.")
         return -1
+    if getattr(FLAGS, "finetune", False):
+        from . import finetune
+        rc = finetune.run(FLAGS, image_lists, image_dir, rank, world, device, seed)
+        if server is not None:
+            server.report_done()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return rc
     index = il.build_image_index(image_lists, image_dir)
 
     # ---- backbone

@@ -139,6 +139,12 @@ def build_retrain_parser(distributed: bool) -> argparse.ArgumentParser:
                    help="also read/write reference-compatible <image>.txt bottleneck files")
     p.add_argument("--extract_batch_size", type=int, default=64,
                    help="images per batched Inception-v3 forward during bottleneck extraction")
+    # full fine-tune mode (BASELINE config 5): train every Inception-v3 layer instead of the head only
+    p.add_argument("--finetune", type="bool", nargs="?", const=True, default=False,
+                   help="Fine-tune the whole network (training-mode batch norm, all conv gradients).")
+    p.add_argument("--finetune_batch_size", type=int, default=32, help="Per-GPU batch of the fine-tune step.")
+    p.add_argument("--finetune_optimizer", type=str, default="sgd", choices=["sgd", "adam"])
+    p.add_argument("--bucket_mb", type=float, default=25.0, help="Gradient all-reduce bucket size (fine-tune DP).")
     p.add_argument("--synthetic_classes", type=int, default=5)
     p.add_argument("--synthetic_images_per_class", type=int, default=40)
     add_framework_flags(p)

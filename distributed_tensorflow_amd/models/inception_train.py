@@ -420,3 +420,79 @@ def torch_train_step(graph, params: Dict[str, torch.Tensor], x_nchw: torch.Tenso
         loss = F.cross_entropy(logits, labels.long())
     grads = torch.autograd.grad(loss, list(leaf.values()), allow_unused=True)
     return loss.detach(), dict(zip(leaf.keys(), grads)), feat.detach()
+
+
+class EagerInceptionTrainer:
+    """Same interface as ``InceptionTrainer`` on plain torch autograd (any device, fp32): the CPU path of the
+    fine-tune application and of the multi-process gloo tests."""
+
+    def __init__(self, num_classes: int, batch_size: int, device="cpu", *, lr: float = 0.01, optimizer: str = "sgd",
+                 seed: int = 0, init: Optional[InceptionV3] = None, double_softmax: bool = False, head_std: float = 0.001,
+                 **_unused):
+        if optimizer != "sgd":
+            raise ValueError("the eager fine-tune path implements SGD only")
+        self.device = torch.device(device)
+        self.B, self.C, self.lr, self.double_softmax, self.world = batch_size, num_classes, lr, double_softmax, 1
+        self.graph = build_graph()
+        self.layout = ArenaLayout(self.graph, num_classes)
+        self.P = torch.zeros(self.layout.size, dtype=torch.float32, device=self.device)
+        self.G = torch.zeros_like(self.P)
+        self.step_t = torch.zeros(1, dtype=torch.int32, device=self.device)
+        src = init if init is not None else InceptionV3(device="cpu", seed=seed)
+        gen = torch.Generator(device="cpu").manual_seed(seed + 17)
+        hw = torch.empty(BOTTLENECK_TENSOR_SIZE, num_classes)
+        torch.nn.init.trunc_normal_(hw, std=head_std, a=-2 * head_std, b=2 * head_std, generator=gen)
+        self.param("final_training_ops/weights/final_weights").copy_(hw)
+        for name, s in self.graph.convs.items():
+            p = src.params[name]
+            w = p["weights"]
+            if w.shape[2] != s.cin:
+                w = torch.cat([w, torch.zeros(s.kh, s.kw, s.cin - w.shape[2], s.cout)], dim=2)
+            self.param(name + "/conv2d_params").copy_(w)
+            self.param(name + "/batchnorm/gamma").copy_(p["gamma"])
+            self.param(name + "/batchnorm/beta").copy_(p["beta"])
+        self.last_loss = torch.zeros(())
+        self.last_correct = torch.zeros(())
+
+    def param(self, name: str) -> torch.Tensor:
+        return self.layout.view(self.P, name)
+
+    def grad(self, name: str) -> torch.Tensor:
+        return self.layout.view(self.G, name)
+
+    def fwd_bwd(self, x: torch.Tensor, labels: torch.Tensor, on_conv_done=None) -> None:
+        """``x``: NHWC ``[B,299,299,>=3]`` (the native layout; extra pad channels ignored)."""
+        leaf = {k: self.layout.view(self.P, k).detach().clone().requires_grad_(True) for k in self.layout.entries}
+        xin = x[..., :3].float().permute(0, 3, 1, 2).contiguous()
+        feat = torch_forward_train(self.graph, leaf, xin)
+        logits = feat @ leaf["final_training_ops/weights/final_weights"] + leaf["final_training_ops/biases/final_biases"]
+        loss = F.cross_entropy(torch.softmax(logits, 1) if self.double_softmax else logits, labels.long())
+        grads = torch.autograd.grad(loss, list(leaf.values()), allow_unused=True)
+        for (k, _v), g in zip(leaf.items(), grads):
+            if g is not None:
+                self.grad(k).copy_(g)
+        self.last_loss = loss.detach()
+        self.last_correct = (logits.argmax(1) == labels.long()).float().sum()
+        if on_conv_done is not None:
+            for name in self.layout.conv_order:
+                on_conv_done(name)
+
+    def apply(self) -> None:
+        self.P.add_(self.G, alpha=-self.lr / self.world)
+        self.G.zero_()
+        self.step_t += 1
+
+    def train_step(self, x, labels) -> None:
+        self.fwd_bwd(x, labels)
+        self.apply()
+
+    def metrics(self) -> Tuple[float, float]:
+        return float(self.last_loss), float(self.last_correct) / self.B
+
+
+def make_inception_trainer(kind: str, *args, **kw):
+    if kind == "native":
+        return InceptionTrainer(*args, **kw)
+    if kind == "eager":
+        return EagerInceptionTrainer(*args, **kw)
+    raise ValueError("unknown fine-tune engine %r" % kind)

@@ -290,3 +290,72 @@ def test_fine_tune_learns_on_tiny_problem():
         losses.append(tr.metrics()[0])
     assert all(l == l for l in losses)
     assert losses[-1] < 0.5 * losses[0], losses
+
+
+_RCCL_FT = r"""
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29593", HSA_ENABLE_IPC_MODE_LEGACY="0")
+import torch, torch.distributed as dist
+from distributed_tensorflow_amd.models.inception_train import InceptionTrainer
+from distributed_tensorflow_amd.parallel.finetune_dp import FinetuneDataParallel
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+torch.manual_seed(0)
+B = 4
+x = torch.zeros(B, 299, 299, 8, device="cuda"); x[..., :3] = torch.randn(B, 299, 299, 3, device="cuda"); x = x.to(torch.bfloat16)
+y = torch.tensor([0, 1, 2, 1], device="cuda", dtype=torch.int32)
+a = InceptionTrainer(3, B, "cuda", lr=0.01, seed=2)
+b = InceptionTrainer(3, B, "cuda", lr=0.01, seed=2)
+dp = FinetuneDataParallel(a, bucket_mb=20.0, force_collectives=True)
+# Two runs of the same random-init step are not comparable number by number: fp32 atomics (dW split-K, BN statistics)
+# change the rounding, bf16 flips follow, and the 47-layer random-init BatchNorm net amplifies them chaotically
+# (measured: two plain trainers differ by ~100% of the update norm at B=4).  So the RCCL path is checked against the
+# plain path on its invariants: every bucket all-reduced, optimizer applied, gradients consumed, loss finite and
+# decreasing like the plain trainer's; the reduction arithmetic itself is covered by the 2-rank gloo test on CPU.
+la, lb = [], []
+for _ in range(6):
+    dp.train_step(x, y)
+    b.train_step(x, y)
+    la.append(a.metrics()[0]); lb.append(b.metrics()[0])
+torch.cuda.synchronize()
+print(json.dumps({"la": la, "lb": lb, "buckets": len(dp.buckets.ranges), "ncoll": dp.last_num_collectives,
+                  "sync": dp.replicas_in_sync(), "gmax": float(a.G.abs().max()), "steps": int(a.step_t.item())}))
+dist.destroy_process_group()
+"""
+
+
+def test_finetune_bucketed_allreduce_over_rccl_single_rank(tmp_path):
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_ft.py"
+    script.write_text(_RCCL_FT)
+    r = subprocess.run([sys.executable, str(script), repo], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["buckets"] >= 3 and out["ncoll"] == out["buckets"] and out["sync"] is True and out["steps"] == 6
+    assert out["gmax"] == 0.0
+    assert abs(out["la"][0] - out["lb"][0]) < 0.05  # same weights, same batch: the first loss agrees
+    assert out["la"][-1] < out["la"][0] and out["lb"][-1] < out["lb"][0], out
+
+
+def test_retrain_cli_finetune_on_gpu(tmp_path):
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cwd = str(tmp_path)
+    cmd = [sys.executable, os.path.join(repo, "retrain1", "retrain.py"), "--synthetic", "--finetune", "--synthetic_classes", "3",
+           "--synthetic_images_per_class", "30", "--training_steps", "40", "--finetune_batch_size", "16", "--learning_rate", "0.05",
+           "--eval_step_interval", "10", "--bottleneck_dir", os.path.join(cwd, "bn"), "--summaries_dir", os.path.join(cwd, "logs"),
+           "--output_graph", os.path.join(cwd, "ft.pb"), "--output_labels", os.path.join(cwd, "labels.txt"),
+           "--model_dir", os.path.join(cwd, "model"), "--seed", "3"]
+    r = subprocess.run(cmd, cwd=cwd, env=dict(os.environ, PYTHONPATH=repo), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=500)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "Fine-tune throughput" in r.stdout and "Final test accuracy" in r.stdout
+    accs = [float(l.split("Train accuracy = ")[1].split("%")[0]) for l in r.stdout.splitlines() if "Train accuracy" in l]
+    assert accs[-1] >= 90.0, r.stdout[-2000:]  # the synthetic classes are trivially separable

@@ -1,0 +1,89 @@
+"""Inception-v3 full fine-tune plumbing on CPU: arena layout / bucket plan, the eager trainer, 2-rank gloo data
+parallelism with bucketed all-reduce, and the ``retrain2.py --finetune`` command line."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_arena_layout_and_bucket_plan():
+    from distributed_tensorflow_amd.models.inception_train import ArenaLayout
+    from distributed_tensorflow_amd.models.inception_v3 import build_graph
+    from distributed_tensorflow_amd.parallel.finetune_dp import ArenaBuckets
+    g = build_graph()
+    lay = ArenaLayout(g, 5)
+    assert len(lay.conv_order) == 94 and lay.conv_order[0].startswith("mixed_10") and lay.conv_order[-1] == "conv"
+    offs = sorted(off for off, _ in lay.entries.values())
+    assert offs[0] == 0 and all(o % 64 == 0 for o in offs) and lay.size % 64 == 0
+    # head first (its gradient is ready before the backward starts), stem last
+    assert lay.entries["final_training_ops/weights/final_weights"][0] == 0
+    assert lay.entries["conv/conv2d_params"][0] > lay.entries["mixed/conv/conv2d_params"][0] > lay.entries["mixed_9/conv/conv2d_params"][0]
+    n = sum(int(torch.tensor(shape).prod()) for _o, shape in lay.entries.values())
+    assert 21.7e6 < n < 21.9e6  # ~21.8 M parameters up to pool_3 + the 5-class head
+    b = ArenaBuckets(lay, bucket_mb=25.0)
+    assert b.ranges[0][0] == 0 and b.ranges[-1][1] == lay.size
+    assert all(b.ranges[i][1] == b.ranges[i + 1][0] for i in range(len(b.ranges) - 1))
+    assert 3 <= len(b.ranges) <= 5
+    ends = set(lay.conv_end.values())
+    assert all(e in ends for _s, e in b.ranges)
+    # readiness: nothing is ready before the first conv is done; everything after the stem conv
+    assert b.ready(lay.conv_end[lay.conv_order[0]], 0) == 0
+    assert b.ready(lay.conv_end["conv"], 0) == len(b.ranges)
+    assert len(ArenaBuckets(lay, bucket_mb=1e9).ranges) == 1
+
+
+def _worker(rank, world, initfile, outdir):
+    from distributed_tensorflow_amd.models.inception_train import EagerInceptionTrainer
+    from distributed_tensorflow_amd.parallel.finetune_dp import FinetuneDataParallel
+    torch.set_num_threads(3)
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    tr = EagerInceptionTrainer(3, 2, "cpu", lr=0.05, seed=10 + rank)  # different init per rank: broadcast must fix it
+    dp = FinetuneDataParallel(tr, bucket_mb=20.0)
+    res = {"sync0": dp.replicas_in_sync(), "nb": len(dp.buckets.ranges)}
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(2, 299, 299, 8, generator=g)
+    y = torch.tensor([rank, 2 - rank])
+    p0 = tr.P.clone()
+    dp.train_step(x, y)
+    res["sync1"] = dp.replicas_in_sync()
+    res["moved"] = float((tr.P - p0).abs().max())
+    res["gzero"] = float(tr.G.abs().max())
+    res["loss"] = dp.mean_metrics()[0]
+    res["P"] = tr.P[:20000].clone()
+    torch.save(res, os.path.join(outdir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_bucketed_allreduce_keeps_replicas_identical():
+    tmp = tempfile.mkdtemp()
+    mp.spawn(_worker, args=(2, os.path.join(tmp, "init"), tmp), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp, "r%d.pt" % r)) for r in range(2))
+    assert r0["sync0"] and r0["sync1"] and r1["sync1"]
+    assert r0["nb"] >= 3
+    assert r0["moved"] > 0 and r0["gzero"] == 0.0
+    assert torch.equal(r0["P"], r1["P"]) and abs(r0["loss"] - r1["loss"]) < 1e-9
+
+
+def test_retrain_cli_finetune_mode(tmp_path):
+    cwd = str(tmp_path)
+    env = dict(os.environ, PYTHONPATH=REPO, OMP_NUM_THREADS="4")
+    cmd = [sys.executable, os.path.join(REPO, "retrain1", "retrain.py"), "--device", "cpu", "--synthetic", "--finetune",
+           "--synthetic_classes", "2", "--synthetic_images_per_class", "12", "--training_steps", "2",
+           "--finetune_batch_size", "2", "--eval_step_interval", "1", "--bottleneck_dir", os.path.join(cwd, "bn"),
+           "--summaries_dir", os.path.join(cwd, "logs"), "--output_graph", os.path.join(cwd, "ft.pb"),
+           "--output_labels", os.path.join(cwd, "labels.txt"), "--model_dir", os.path.join(cwd, "model"), "--seed", "3"]
+    r = subprocess.run(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "Step 1: Train accuracy" in r.stdout and "Fine-tune throughput" in r.stdout and "replicas in sync: True" in r.stdout
+    from distributed_tensorflow_amd.utils import checkpoint as ckpt
+    t = ckpt.load_tensors(os.path.join(cwd, "ft.pb"))
+    assert t["conv/conv2d_params"].shape == (3, 3, 8, 32) and t["final_training_ops/weights/final_weights"].shape == (2048, 2)
+    assert open(os.path.join(cwd, "labels.txt")).read().split("\n")[:2] == ["class 00", "class 01"]
