@@ -168,18 +168,15 @@ DTF_API int dtf_bn_relu_fwd(const void* z, const float* bn, void* y, long M, int
   return 0;
 }
 
-// sums[2][C] = (sum g, sum g*xhat) with g = dy * (y > 0), xhat = (z - mean) * rstd; dbeta = sums[0], dgamma = sums[1].
-// Workgroups accumulate into DTF_STAT_SLOTS replicas (atomic contention, see EpBf16Stats); the last workgroup to
-// finish (device-scope ticket) folds the replicas into `sums`, emits dgamma/dbeta and re-arms replicas + ticket.
+// slots[DTF_STAT_SLOTS][2][C] += (sum g, sum g*xhat) with g = dy * (y > 0), xhat = (z - mean) * rstd.
+// Workgroups accumulate into DTF_STAT_SLOTS replicas (atomic contention, see EpBf16Stats).  No fence / ticket here:
+// an agent-scope release on this multi-XCD part writes back the whole L2 (measured ~18 us per launch); the apply
+// kernel that follows folds the replicas itself.
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const uint16_t* __restrict__ dy, int dy_cs,
                                                                  const uint16_t* __restrict__ y, int y_cs,
                                                                  const uint16_t* __restrict__ z, const float* __restrict__ bn,
-                                                                 float* __restrict__ slots, float* __restrict__ sums,
-                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                 unsigned* __restrict__ ticket, long M, int C,
-                                                                 int rows_per_block) {
+                                                                 float* __restrict__ slots, long M, int C, int rows_per_block) {
   __shared__ float red[256 * 16];
-  __shared__ int is_last;
   const int c8n = C >> 3;
   const int rpb = 256 / c8n;
   const int tid = threadIdx.x;
@@ -194,38 +191,26 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const uint16_t*
     ld8f(bn + C + c0, rstd);
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-    long r = r0 + ry;
-    for (; r + rpb < r1; r += 2 * rpb) {  // two rows in flight per lane
-      const long rb = r + rpb;
-      const uint4 ga = *reinterpret_cast<const uint4*>(dy + r * dy_cs + c0), gb = *reinterpret_cast<const uint4*>(dy + rb * dy_cs + c0);
-      const uint4 ya = *reinterpret_cast<const uint4*>(y + r * y_cs + c0), yb = *reinterpret_cast<const uint4*>(y + rb * y_cs + c0);
-      const uint4 za = *reinterpret_cast<const uint4*>(z + r * C + c0), zb = *reinterpret_cast<const uint4*>(z + rb * C + c0);
-      float g[8], yy[8], zz[8];
-      unpack8(ga, g); unpack8(ya, yy); unpack8(za, zz);
+    for (long r = r0 + ry; r < r1; r += 4L * rpb) {  // four rows in flight per lane (clamped address + select)
+      uint4 gv[4], yv[4], zv[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float gj = yy[j] > 0.f ? g[j] : 0.f;
-        s1[j] += gj;
-        s2[j] += gj * (zz[j] - mean[j]) * rstd[j];
+      for (int u = 0; u < 4; ++u) {
+        const long rr = r + (long)u * rpb < r1 ? r + (long)u * rpb : r;
+        gv[u] = *reinterpret_cast<const uint4*>(dy + rr * dy_cs + c0);
+        yv[u] = *reinterpret_cast<const uint4*>(y + rr * y_cs + c0);
+        zv[u] = *reinterpret_cast<const uint4*>(z + rr * C + c0);
       }
-      unpack8(gb, g); unpack8(yb, yy); unpack8(zb, zz);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float gj = yy[j] > 0.f ? g[j] : 0.f;
-        s1[j] += gj;
-        s2[j] += gj * (zz[j] - mean[j]) * rstd[j];
-      }
-    }
-    if (r < r1) {
-      float g[8], yy[8], zz[8];
-      unpack8(*reinterpret_cast<const uint4*>(dy + r * dy_cs + c0), g);
-      unpack8(*reinterpret_cast<const uint4*>(y + r * y_cs + c0), yy);
-      unpack8(*reinterpret_cast<const uint4*>(z + r * C + c0), zz);
+      for (int u = 0; u < 4; ++u) {
+        const bool ok = r + (long)u * rpb < r1;
+        float g[8], yy[8], zz[8];
+        unpack8(gv[u], g); unpack8(yv[u], yy); unpack8(zv[u], zz);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float gj = yy[j] > 0.f ? g[j] : 0.f;
-        s1[j] += gj;
-        s2[j] += gj * (zz[j] - mean[j]) * rstd[j];
+        for (int j = 0; j < 8; ++j) {
+          const float gj = (ok && yy[j] > 0.f) ? g[j] : 0.f;
+          s1[j] += gj;
+          s2[j] += gj * (zz[j] - mean[j]) * rstd[j];
+        }
       }
     }
   }
@@ -249,81 +234,76 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const uint16_t*
       atomicAdd(&slot[C + c0 + j], s2[j]);
     }
   }
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) is_last = (atomicAdd(ticket, 1u) == gridDim.x - 1);
-  __syncthreads();
-  if (!is_last) return;
-  __threadfence();
-  for (int i = tid; i < 2 * C; i += 256) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < DTF_STAT_SLOTS; ++k) {
-      t += __hip_atomic_load(&slots[(long)k * 2 * C + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      slots[(long)k * 2 * C + i] = 0.f;
-    }
-    sums[i] = t;
-    if (dgamma) {
-      if (i < C) dbeta[i] = t;
-      else dgamma[i - C] = t;
-    }
-  }
-  if (tid == 0) *ticket = 0u;
 }
 
 DTF_API int dtf_bn_relu_bwd_reduce(const void* dy, int dy_cstride, const void* y, int y_cstride, const void* z,
-                                   const float* bn, float* slots, float* sums, float* dgamma, float* dbeta,
-                                   unsigned* ticket, long M, int C, hipStream_t st) {
-  if (M <= 0 || C <= 0 || C % 8 || C > 2048 || dy_cstride % 8 || y_cstride % 8 || !ticket) return ERR_SHAPE;
+                                   const float* bn, float* slots, long M, int C, hipStream_t st) {
+  if (M <= 0 || C <= 0 || C % 8 || C > 2048 || dy_cstride % 8 || y_cstride % 8) return ERR_SHAPE;
   const int rpb = 256 / (C / 8);
-  long rows = (M + 511) / 512;  // <= 512 workgroups: two per CU stream the three tensors
-  if (rows < 8L * rpb) rows = 8L * rpb;
+  long rows = (M + 1023) / 1024;
+  if (rows < 4L * rpb) rows = 4L * rpb;
   hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(dtf_cdiv(M, rows)), dim3(256), 0, st, (const uint16_t*)dy, dy_cstride,
-                     (const uint16_t*)y, y_cstride, (const uint16_t*)z, bn, slots, sums, dgamma, dbeta, ticket, M, C, (int)rows);
+                     (const uint16_t*)y, y_cstride, (const uint16_t*)z, bn, slots, M, C, (int)rows);
   DTF_CHECK_LAUNCH();
   return 0;
 }
 
-// z <- dz = scale * (g - s1/M - xhat * s2/M)  in place (dgamma/dbeta may be null: the reduce kernel already wrote them).
+// z <- dz = scale * (g - s1/M - xhat * s2/M) in place.  Every workgroup first folds the DTF_STAT_SLOTS replicas of
+// (s1, s2) into LDS (2C x 16 L2-resident floats); workgroup 0 also emits dbeta = s1, dgamma = s2 and clears
+// `slots_prev` — the replica set the previous step used (the two sets alternate, so nobody is reading it any more).
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const uint16_t* __restrict__ dy, int dy_cs,
                                                                 const uint16_t* __restrict__ y, int y_cs,
                                                                 uint16_t* __restrict__ z, const float* __restrict__ bn,
-                                                                const float* __restrict__ sums, float* __restrict__ dgamma,
-                                                                float* __restrict__ dbeta, long M, int C, float inv_m) {
-  if (blockIdx.x == 0 && dgamma)
-    for (int c = threadIdx.x; c < C; c += 256) {
-      dbeta[c] = sums[c];
-      dgamma[c] = sums[C + c];
+                                                                const float* __restrict__ slots, float* __restrict__ slots_prev,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, long M,
+                                                                int C, float inv_m) {
+  extern __shared__ float sm[];  // [2C]
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < DTF_STAT_SLOTS; ++k) t += slots[(long)k * 2 * C + i];
+    sm[i] = t;
+    if (blockIdx.x == 0) {
+      if (dgamma) {
+        if (i < C) dbeta[i] = t;
+        else dgamma[i - C] = t;
+      }
+      if (slots_prev)
+#pragma unroll
+        for (int k = 0; k < DTF_STAT_SLOTS; ++k) slots_prev[(long)k * 2 * C + i] = 0.f;
     }
+  }
+  __syncthreads();
   const int c8n = C >> 3;
   const long total = M * c8n;
   for (long gi = (long)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (long)gridDim.x * 256) {
     const int c0 = (int)(gi % c8n) * 8;
     const long m = gi / c8n;
-    float g[8], yy[8], zz[8], mean[8], rstd[8], sc[8], a[8], b[8];
+    float g[8], yy[8], zz[8], mean[8], rstd[8], sc[8];
     unpack8(*reinterpret_cast<const uint4*>(dy + m * dy_cs + c0), g);
     unpack8(*reinterpret_cast<const uint4*>(y + m * y_cs + c0), yy);
     unpack8(*reinterpret_cast<const uint4*>(z + m * C + c0), zz);
     ld8f(bn + c0, mean);
     ld8f(bn + C + c0, rstd);
     ld8f(bn + 2 * C + c0, sc);
-    ld8f(sums + c0, a);
-    ld8f(sums + C + c0, b);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float gj = yy[j] > 0.f ? g[j] : 0.f;
       const float xh = (zz[j] - mean[j]) * rstd[j];
-      zz[j] = sc[j] * (gj - a[j] * inv_m - xh * b[j] * inv_m);
+      zz[j] = sc[j] * (gj - sm[c0 + j] * inv_m - xh * sm[C + c0 + j] * inv_m);
     }
     *reinterpret_cast<uint4*>(z + m * C + c0) = pack8(zz);
   }
 }
 
 DTF_API int dtf_bn_relu_bwd_apply(const void* dy, int dy_cstride, const void* y, int y_cstride, void* z, const float* bn,
-                                  const float* sums, float* dgamma, float* dbeta, long M, int C, hipStream_t st) {
-  if (M <= 0 || C <= 0 || C % 8 || dy_cstride % 8 || y_cstride % 8) return ERR_SHAPE;
-  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(ew_blocks(M * (C / 8))), dim3(256), 0, st, (const uint16_t*)dy,
-                     dy_cstride, (const uint16_t*)y, y_cstride, (uint16_t*)z, bn, sums, dgamma, dbeta, M, C, 1.f / (float)M);
+                                  const float* slots, float* slots_prev, float* dgamma, float* dbeta, long M, int C,
+                                  hipStream_t st) {
+  if (M <= 0 || C <= 0 || C % 8 || C > 2048 || dy_cstride % 8 || y_cstride % 8) return ERR_SHAPE;
+  int blocks = ew_blocks(M * (C / 8) / 4, 2048);  // >= 4 elements-of-8 per lane amortise the fold
+  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(blocks), dim3(256), 2 * C * sizeof(float), st, (const uint16_t*)dy,
+                     dy_cstride, (const uint16_t*)y, y_cstride, (uint16_t*)z, bn, slots, slots_prev, dgamma, dbeta, M, C,
+                     1.f / (float)M);
   DTF_CHECK_LAUNCH();
   return 0;
 }

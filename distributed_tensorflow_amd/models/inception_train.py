@@ -96,9 +96,10 @@ class InceptionTrainer:
 
     def __init__(self, num_classes: int, batch_size: int, device="cuda", *, lr: float = 0.01, optimizer: str = "sgd",
                  seed: int = 0, init: Optional[InceptionV3] = None, bn_momentum: float = 0.9997,
-                 double_softmax: bool = False, head_std: float = 0.001):
+                 double_softmax: bool = False, head_std: float = 0.001, async_lds: bool = True):
         from .. import native
         self.lib = native.hip()
+        self.async_lds = async_lds  # second-generation conv core (csrc/hip/igemm2.hip) for forward and backward-data
         self.native = native
         self.device = torch.device(device)
         self.B = batch_size
@@ -146,6 +147,34 @@ class InceptionTrainer:
             self.moving_var[o:o + s.cout].copy_(p["moving_variance"])
         self._alloc()
         self._plan_backward()
+        if self.async_lds:
+            self._alloc_packs()
+
+    def _alloc_packs(self) -> None:
+        """bf16 K-contiguous packings of every conv weight for the async-LDS GEMM core: Wp [Cout][tap*Cin] (forward) and
+        Wq [Cin][tap*Cout] (backward-data), refreshed from the fp32 arena by one kernel launch per step."""
+        import ctypes as C
+
+        class PackDesc(C.Structure):  # csrc/hip/igemm2.hip: struct PackDesc
+            _fields_ = [("w_off", C.c_long), ("p_off", C.c_long), ("q_off", C.c_long), ("taps", C.c_int), ("cin", C.c_int),
+                        ("cout", C.c_int), ("pad", C.c_int)]
+        self.native.check(self.lib.dtf_igemm2_init(), "igemm2_init")
+        descs = (PackDesc * len(self.graph.convs))()
+        self.pack_off: Dict[str, int] = {}
+        off = 0
+        for k, (name, s) in enumerate(self.graph.convs.items()):
+            n = s.kh * s.kw * s.cin * s.cout
+            descs[k] = PackDesc(self.layout.entries[name + "/conv2d_params"][0], off, off, s.kh * s.kw, s.cin, s.cout, 0)
+            self.pack_off[name] = off
+            off += _round_up(n)
+        self.Wp = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
+        self.Wq = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
+        self._pack_descs = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.device)
+
+    def pack_weights(self) -> None:
+        st = torch.cuda.current_stream().cuda_stream
+        self.native.check(self.lib.dtf_pack_conv_weights(self.P.data_ptr(), self._pack_descs.data_ptr(), len(self.graph.convs),
+                                                         self.Wp.data_ptr(), self.Wq.data_ptr(), st), "pack_conv_weights")
 
     # ------------------------------------------------------------------ arena
     def param(self, name: str) -> torch.Tensor:
@@ -199,10 +228,9 @@ class InceptionTrainer:
                 self.argmax[i] = torch.empty(B, ho, wo, op.channels, dtype=torch.uint8, device=dev)
         # statistic accumulators: STAT_SLOTS replicas of [fwd sum|sumsq] and of [bwd s1|s2] per conv (their consumer
         # kernels re-zero them, so no per-step memset), the folded backward sums, and one ticket per conv
-        self.scratch = torch.zeros(2 * STAT_SLOTS * 2 * self.stat_total, dtype=torch.float32, device=dev)
-        self.bsums = torch.zeros(2 * self.stat_total, dtype=torch.float32, device=dev)
-        self.tickets = torch.zeros(len(g.convs), dtype=torch.int32, device=dev)
-        self.conv_index = {name: k for k, name in enumerate(g.convs)}
+        # (block 0 = forward; blocks 1 and 2 = the two alternating backward sets)
+        self.scratch = torch.zeros(3 * STAT_SLOTS * 2 * self.stat_total, dtype=torch.float32, device=dev)
+        self._bwd_parity = 0
         self.bn = torch.zeros(4 * self.stat_total, dtype=torch.float32, device=dev)  # mean, rstd, scale, shift per conv
         self.feat = torch.zeros(B, BOTTLENECK_TENSOR_SIZE, dtype=torch.float32, device=dev)
         self.dfeat = torch.zeros_like(self.feat)
@@ -231,11 +259,9 @@ class InceptionTrainer:
 
     # ------------------------------------------------------------------ forward / backward
     def _stats(self, name: str, which: int) -> int:
-        """Device pointer of the [STAT_SLOTS][2][Cout] accumulator block of conv ``name`` (0 = forward stats, 1 = backward)."""
+        """Device pointer of the [STAT_SLOTS][2][Cout] accumulator block of conv ``name`` (0 = forward statistics,
+        1 / 2 = the backward sums of even / odd steps)."""
         return self.scratch.data_ptr() + 4 * STAT_SLOTS * 2 * (self.stat_total * which + self.stat_off[name])
-
-    def _bsums(self, name: str) -> int:
-        return self.bsums.data_ptr() + 4 * 2 * self.stat_off[name]
 
     def _bn_ptr(self, name: str) -> int:
         return self.bn.data_ptr() + 4 * 4 * self.stat_off[name]
@@ -245,6 +271,8 @@ class InceptionTrainer:
         assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and tuple(x.shape) == (B, 299, 299, INPUT_PAD_CHANNELS)
         st = torch.cuda.current_stream().cuda_stream
         self._x = x
+        if self.async_lds:
+            self.pack_weights()
         for i, op in enumerate(g.ops):
             src = x if op.src == "input" else self.act[op.src]
             _, H, W, Cs = src.shape
@@ -254,9 +282,14 @@ class InceptionTrainer:
                 _, Ho, Wo, Cd = dst.shape
                 z = self.z[s.name]
                 M = B * Ho * Wo
-                chk(lib.dtf_conv_fwd_stats(src.data_ptr(), self.param(s.name + "/conv2d_params").data_ptr(), z.data_ptr(),
-                                           self._stats(s.name, 0), B, H, W, s.cin, Cs, s.cout, s.kh, s.kw, s.stride,
-                                           s.pad[0], s.pad[1], Ho, Wo, st), "conv_fwd_stats " + s.name)
+                if self.async_lds:
+                    chk(lib.dtf_conv_fwd_stats_v2(src.data_ptr(), self.Wp.data_ptr() + 2 * self.pack_off[s.name], z.data_ptr(),
+                                                  self._stats(s.name, 0), B, H, W, s.cin, Cs, s.cout, s.kh, s.kw, s.stride,
+                                                  s.pad[0], s.pad[1], Ho, Wo, st), "conv_fwd_stats_v2 " + s.name)
+                else:
+                    chk(lib.dtf_conv_fwd_stats(src.data_ptr(), self.param(s.name + "/conv2d_params").data_ptr(), z.data_ptr(),
+                                               self._stats(s.name, 0), B, H, W, s.cin, Cs, s.cout, s.kh, s.kw, s.stride,
+                                               s.pad[0], s.pad[1], Ho, Wo, st), "conv_fwd_stats " + s.name)
                 o = self.stat_off[s.name]
                 chk(lib.dtf_bn_finalize(self._stats(s.name, 0), self.param(s.name + "/batchnorm/gamma").data_ptr(),
                                         self.param(s.name + "/batchnorm/beta").data_ptr(),
@@ -298,6 +331,8 @@ class InceptionTrainer:
         g, B, lib, chk = self.graph, self.B, self.lib, self.native.check
         st = torch.cuda.current_stream().cuda_stream
         x = self._x
+        par = self._bwd_parity
+        self._bwd_parity ^= 1
         for i in range(len(g.ops) - 1, -1, -1):
             op = g.ops[i]
             src = x if op.src == "input" else self.act[op.src]
@@ -312,18 +347,22 @@ class InceptionTrainer:
                 z = self.z[s.name]
                 M = B * Ho * Wo
                 dy_p, y_p = ddst.data_ptr() + 2 * op.dst_off, dst.data_ptr() + 2 * op.dst_off
-                chk(lib.dtf_bn_relu_bwd_reduce(dy_p, Cd, y_p, Cd, z.data_ptr(), self._bn_ptr(s.name), self._stats(s.name, 1),
-                                               self._bsums(s.name), self.grad(s.name + "/batchnorm/gamma").data_ptr(),
-                                               self.grad(s.name + "/batchnorm/beta").data_ptr(),
-                                               self.tickets.data_ptr() + 4 * self.conv_index[s.name], M, s.cout, st),
+                cur, prev = self._stats(s.name, 1 + par), self._stats(s.name, 2 - par)
+                chk(lib.dtf_bn_relu_bwd_reduce(dy_p, Cd, y_p, Cd, z.data_ptr(), self._bn_ptr(s.name), cur, M, s.cout, st),
                     "bn_bwd_reduce")
-                chk(lib.dtf_bn_relu_bwd_apply(dy_p, Cd, y_p, Cd, z.data_ptr(), self._bn_ptr(s.name), self._bsums(s.name),
-                                              0, 0, M, s.cout, st), "bn_bwd_apply")
+                chk(lib.dtf_bn_relu_bwd_apply(dy_p, Cd, y_p, Cd, z.data_ptr(), self._bn_ptr(s.name), cur, prev,
+                                              self.grad(s.name + "/batchnorm/gamma").data_ptr(),
+                                              self.grad(s.name + "/batchnorm/beta").data_ptr(), M, s.cout, st), "bn_bwd_apply")
                 K = s.kh * s.kw * s.cin
                 chk(lib.dtf_conv_dw_general(src.data_ptr(), Cs, z.data_ptr(), self.grad(s.name + "/conv2d_params").data_ptr(),
                                             B, H, W, s.cin, s.cout, s.kh, s.kw, s.stride, s.pad[0], s.pad[1], Ho, Wo,
                                             self._dw_splits(K, s.cout, M), st), "conv_dw " + s.name)
-                if op.src != "input":
+                if op.src != "input" and self.async_lds:
+                    chk(lib.dtf_conv_bwd_data_v2(z.data_ptr(), self.Wq.data_ptr() + 2 * self.pack_off[s.name],
+                                                 self.dact[op.src].data_ptr(), B, H, W, s.cin, Cs, s.cout, s.kh, s.kw, s.stride,
+                                                 s.pad[0], s.pad[1], Ho, Wo, int(self.accumulate[i]), st),
+                        "conv_bwd_data_v2 " + s.name)
+                elif op.src != "input":
                     chk(lib.dtf_conv_bwd_data(z.data_ptr(), self.param(s.name + "/conv2d_params").data_ptr(),
                                               self.dact[op.src].data_ptr(), B, H, W, s.cin, Cs, s.cout, s.kh, s.kw, s.stride,
                                               s.pad[0], s.pad[1], Ho, Wo, int(self.accumulate[i]), st), "conv_bwd_data " + s.name)

@@ -106,12 +106,17 @@ def hip() -> C.CDLL:
         _sig(lib, "dtf_conv_dw_general", I, [P, I, P, P] + [I] * 13 + [P])
         _sig(lib, "dtf_bn_finalize", I, [P, P, P, P, P, P, I, L, F, F, P])
         _sig(lib, "dtf_bn_relu_fwd", I, [P, P, P, L, I, I, P])
-        _sig(lib, "dtf_bn_relu_bwd_reduce", I, [P, I, P, I, P, P, P, P, P, P, P, L, I, P])
-        _sig(lib, "dtf_bn_relu_bwd_apply", I, [P, I, P, I, P, P, P, P, P, L, I, P])
+        _sig(lib, "dtf_bn_relu_bwd_reduce", I, [P, I, P, I, P, P, P, L, I, P])
+        _sig(lib, "dtf_bn_relu_bwd_apply", I, [P, I, P, I, P, P, P, P, P, P, L, I, P])
         _sig(lib, "dtf_maxpool3x3_arg", I, [P, P, P] + [I] * 7 + [P])
         _sig(lib, "dtf_maxpool3x3_bwd", I, [P, I, P, P, I] + [I] * 6 + [P])
         _sig(lib, "dtf_avgpool3x3_same_bwd", I, [P, I, P, I] + [I] * 5 + [P])
         _sig(lib, "dtf_global_avgpool_bwd", I, [P, P, I, I, I, P])
+        _sig(lib, "dtf_igemm2_init", I, [])
+        _sig(lib, "dtf_conv_fwd_stats_v2", I, [P, P, P, P] + [I] * 13 + [P])
+        _sig(lib, "dtf_conv_bias_relu_v2", I, [P, P, P, P] + [I] * 15 + [P])
+        _sig(lib, "dtf_conv_bwd_data_v2", I, [P, P, P] + [I] * 14 + [P])
+        _sig(lib, "dtf_pack_conv_weights", I, [P, P, I, P, P, P])
         _sig(lib, "dtf_conv2_bwd_lds_init", I, [])
         _sig(lib, "dtf_conv2_bwd_lds", I, [P, P, P, P, P, P, P, P, I, I, P])
         _sig(lib, "dtf_conv_bias_relu_pool", I, [P, P, P, P, P, I, I, I, I, I, I, I, P])

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--optimizer", default="sgd")
     ap.add_argument("--eager", action="store_true", help="also time the PyTorch eager (MIOpen, bf16 autocast-free fp32/bf16) step")
     ap.add_argument("--eager-dtype", default="bf16")
+    ap.add_argument("--v1", action="store_true", help="first-generation (register-staged) conv core")
     args = ap.parse_args()
     from distributed_tensorflow_amd.models.inception_train import InceptionTrainer, torch_forward_train
     from distributed_tensorflow_amd.models.inception_v3 import graph_flops
@@ -33,7 +34,7 @@ def main():
     x[..., :3] = torch.randn(B, 299, 299, 3, device="cuda")
     x = x.to(torch.bfloat16)
     labels = torch.randint(0, args.classes, (B,), device="cuda", dtype=torch.int32)
-    tr = InceptionTrainer(args.classes, B, "cuda", lr=0.01, optimizer=args.optimizer, seed=1)
+    tr = InceptionTrainer(args.classes, B, "cuda", lr=0.01, optimizer=args.optimizer, seed=1, async_lds=not args.v1)
     for _ in range(args.warmup):
         tr.train_step(x, labels)
     torch.cuda.synchronize()
