@@ -27,6 +27,7 @@ eager baseline in ``scripts/bench_inception_train.py``).
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -96,10 +97,20 @@ class InceptionTrainer:
 
     def __init__(self, num_classes: int, batch_size: int, device="cuda", *, lr: float = 0.01, optimizer: str = "sgd",
                  seed: int = 0, init: Optional[InceptionV3] = None, bn_momentum: float = 0.9997,
-                 double_softmax: bool = False, head_std: float = 0.001, async_lds: bool = True):
+                 double_softmax: bool = False, head_std: float = 0.001, conv_core: str = "auto",
+                 async_lds: Optional[bool] = None):
         from .. import native
         self.lib = native.hip()
-        self.async_lds = async_lds  # second-generation conv core (csrc/hip/igemm2.hip) for forward and backward-data
+        # conv GEMM core per layer and pass: "v1" = register-staged 128x64 tiles (gemm_core.h: small LDS footprint, 4-5
+        # workgroups per CU hide the short K loops of this network), "v2" = async global->LDS ring with 256-row tiles
+        # (igemm2.hip: wins where one M tile has many K-steps and the grid is large), "auto" = time both once per layer
+        # at start-up and keep the faster (measure, don't guess: at B=64 v2 wins 20-30 of the 281 kernels).
+        if async_lds is not None:
+            conv_core = "v2" if async_lds else "v1"
+        if conv_core not in ("v1", "v2", "auto"):
+            raise ValueError("conv_core must be v1, v2 or auto")
+        self.conv_core = conv_core
+        self.async_lds = conv_core != "v1"
         self.native = native
         self.device = torch.device(device)
         self.B = batch_size
@@ -147,8 +158,12 @@ class InceptionTrainer:
             self.moving_var[o:o + s.cout].copy_(p["moving_variance"])
         self._alloc()
         self._plan_backward()
+        pick = 2 if conv_core == "v2" else 1
+        self.core: Dict[str, Dict[str, int]] = {name: {"fwd": pick, "bwd": pick, "dw": pick} for name in g.convs}
         if self.async_lds:
             self._alloc_packs()
+        if conv_core == "auto":
+            self._autotune()
 
     def _alloc_packs(self) -> None:
         """bf16 K-contiguous packings of every conv weight for the async-LDS GEMM core: Wp [Cout][tap*Cin] (forward) and
@@ -158,7 +173,7 @@ class InceptionTrainer:
         class PackDesc(C.Structure):  # csrc/hip/igemm2.hip: struct PackDesc
             _fields_ = [("w_off", C.c_long), ("p_off", C.c_long), ("q_off", C.c_long), ("taps", C.c_int), ("cin", C.c_int),
                         ("cout", C.c_int), ("pad", C.c_int)]
-        self.native.check(self.lib.dtf_igemm2_init(), "igemm2_init")
+        self.native.check(self.lib.dtf_igemm2_init() or self.lib.dtf_igemm2_dw_init(), "igemm2_init")
         descs = (PackDesc * len(self.graph.convs))()
         self.pack_off: Dict[str, int] = {}
         off = 0
@@ -266,6 +281,97 @@ class InceptionTrainer:
     def _bn_ptr(self, name: str) -> int:
         return self.bn.data_ptr() + 4 * 4 * self.stat_off[name]
 
+    # ------------------------------------------------------------------ conv kernels (core 1 = gemm_core.h, 2 = igemm2.hip)
+    def _conv_fwd(self, op, src, core: int, st: int) -> None:
+        s, lib = op.conv, self.lib
+        B, H, W, Cs = src.shape
+        _, Ho, Wo, _ = self.act[op.dst].shape
+        z = self.z[s.name]
+        if core == 2:
+            rc = lib.dtf_conv_fwd_stats_v2(src.data_ptr(), self.Wp.data_ptr() + 2 * self.pack_off[s.name], z.data_ptr(),
+                                           self._stats(s.name, 0), B, H, W, s.cin, Cs, s.cout, s.kh, s.kw, s.stride,
+                                           s.pad[0], s.pad[1], Ho, Wo, st)
+        else:
+            rc = lib.dtf_conv_fwd_stats(src.data_ptr(), self.param(s.name + "/conv2d_params").data_ptr(), z.data_ptr(),
+                                        self._stats(s.name, 0), B, H, W, s.cin, Cs, s.cout, s.kh, s.kw, s.stride,
+                                        s.pad[0], s.pad[1], Ho, Wo, st)
+        self.native.check(rc, "conv_fwd_stats(core %d) %s" % (core, s.name))
+
+    def _conv_dw(self, op, src, core: int, st: int) -> None:
+        s, lib = op.conv, self.lib
+        B, H, W, Cs = src.shape
+        _, Ho, Wo, _ = self.act[op.dst].shape
+        z, dW = self.z[s.name], self.grad(s.name + "/conv2d_params")
+        if core == 2:
+            rc = lib.dtf_conv_dw_v2(src.data_ptr(), Cs, z.data_ptr(), dW.data_ptr(), B, H, W, s.cin, s.cout, s.kh, s.kw,
+                                    s.stride, s.pad[0], s.pad[1], Ho, Wo, self._dw2_splits(s, B * Ho * Wo), st)
+        else:
+            rc = lib.dtf_conv_dw_general(src.data_ptr(), Cs, z.data_ptr(), dW.data_ptr(), B, H, W, s.cin, s.cout, s.kh, s.kw,
+                                         s.stride, s.pad[0], s.pad[1], Ho, Wo,
+                                         self._dw_splits(s.kh * s.kw * s.cin, s.cout, B * Ho * Wo), st)
+        self.native.check(rc, "conv_dw(core %d) %s" % (core, s.name))
+
+    def _conv_bwd_data(self, op, src, core: int, accumulate: int, st: int) -> None:
+        s, lib = op.conv, self.lib
+        B, H, W, Cs = src.shape
+        _, Ho, Wo, _ = self.act[op.dst].shape
+        z, dx = self.z[s.name], self.dact[op.src]
+        if core == 2:
+            rc = lib.dtf_conv_bwd_data_v2(z.data_ptr(), self.Wq.data_ptr() + 2 * self.pack_off[s.name], dx.data_ptr(), B, H, W,
+                                          s.cin, Cs, s.cout, s.kh, s.kw, s.stride, s.pad[0], s.pad[1], Ho, Wo, accumulate, st)
+        else:
+            rc = lib.dtf_conv_bwd_data(z.data_ptr(), self.param(s.name + "/conv2d_params").data_ptr(), dx.data_ptr(), B, H, W,
+                                       s.cin, Cs, s.cout, s.kh, s.kw, s.stride, s.pad[0], s.pad[1], Ho, Wo, accumulate, st)
+        self.native.check(rc, "conv_bwd_data(core %d) %s" % (core, s.name))
+
+    def _autotune(self, reps: int = 3) -> None:
+        """Time both conv cores on every layer's real buffers (contents irrelevant) and keep the faster per pass.
+        Leaves the accumulators it touched (BN statistic slots, gradient arena) zeroed again."""
+        st = torch.cuda.current_stream().cuda_stream
+        x = torch.zeros(self.B, 299, 299, INPUT_PAD_CHANNELS, dtype=torch.bfloat16, device=self.device)
+        self.pack_weights()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+        def timed(fn) -> float:
+            fn()  # warm-up (code object load)
+            best = float("inf")
+            for _ in range(reps):
+                ev[0].record()
+                fn()
+                ev[1].record()
+                ev[1].synchronize()
+                best = min(best, ev[0].elapsed_time(ev[1]))
+            return best
+
+        self.tuning: Dict[str, Dict[str, Tuple[float, float]]] = {}
+        for op in self.graph.ops:
+            if op.kind != "conv":
+                continue
+            src = x if op.src == "input" else self.act[op.src]
+            name = op.conv.name
+            res = {}
+            res["fwd"] = tuple(timed(lambda c=c: self._conv_fwd(op, src, c, st)) for c in (1, 2))
+            res["dw"] = tuple(timed(lambda c=c: self._conv_dw(op, src, c, st)) for c in (1, 2))
+            if op.src != "input":
+                res["bwd"] = tuple(timed(lambda c=c: self._conv_bwd_data(op, src, c, 0, st)) for c in (1, 2))
+            self.tuning[name] = res
+            for k, (t1, t2) in res.items():
+                self.core[name][k] = 2 if t2 < 0.97 * t1 else 1
+        torch.cuda.synchronize()
+        self.scratch.zero_()
+        self.G.zero_()
+
+    def tuning_summary(self) -> str:
+        if not getattr(self, "tuning", None):
+            return "conv core: %s everywhere" % self.conv_core
+        out = []
+        for k in ("fwd", "bwd", "dw"):
+            rows = [r[k] for r in self.tuning.values() if k in r]
+            n2 = sum(1 for name, r in self.tuning.items() if k in r and self.core[name][k] == 2)
+            out.append("%s: v2 on %d/%d layers, v1 %.2f ms, v2 %.2f ms, chosen %.2f ms" % (
+                k, n2, len(rows), sum(a for a, _ in rows), sum(b for _, b in rows), sum(min(a, b) for a, b in rows)))
+        return "; ".join(out)
+
     def forward(self, x: torch.Tensor, training: bool = True) -> torch.Tensor:
         g, B, lib, chk = self.graph, self.B, self.lib, self.native.check
         assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and tuple(x.shape) == (B, 299, 299, INPUT_PAD_CHANNELS)
@@ -282,14 +388,7 @@ class InceptionTrainer:
                 _, Ho, Wo, Cd = dst.shape
                 z = self.z[s.name]
                 M = B * Ho * Wo
-                if self.async_lds:
-                    chk(lib.dtf_conv_fwd_stats_v2(src.data_ptr(), self.Wp.data_ptr() + 2 * self.pack_off[s.name], z.data_ptr(),
-                                                  self._stats(s.name, 0), B, H, W, s.cin, Cs, s.cout, s.kh, s.kw, s.stride,
-                                                  s.pad[0], s.pad[1], Ho, Wo, st), "conv_fwd_stats_v2 " + s.name)
-                else:
-                    chk(lib.dtf_conv_fwd_stats(src.data_ptr(), self.param(s.name + "/conv2d_params").data_ptr(), z.data_ptr(),
-                                               self._stats(s.name, 0), B, H, W, s.cin, Cs, s.cout, s.kh, s.kw, s.stride,
-                                               s.pad[0], s.pad[1], Ho, Wo, st), "conv_fwd_stats " + s.name)
+                self._conv_fwd(op, src, self.core[s.name]["fwd"], st)
                 o = self.stat_off[s.name]
                 chk(lib.dtf_bn_finalize(self._stats(s.name, 0), self.param(s.name + "/batchnorm/gamma").data_ptr(),
                                         self.param(s.name + "/batchnorm/beta").data_ptr(),
@@ -325,6 +424,17 @@ class InceptionTrainer:
         want = max(1, 1536 // blocks)
         return max(1, min(want, npos // 512 if npos >= 512 else 1))
 
+    @staticmethod
+    def _dw2_splits(s, npos: int) -> int:
+        """Split-K factor of the filter-gradient kernel.  Every split adds its whole tile to dW with fp32 atomics, and
+        those — not the MFMAs — bound the kernel (measured: 1024 workgroups x 16K atomics = 80 us per conv), so use the
+        fewest splits that still put one resident workgroup on every CU (96 KB of LDS: one 128-tile workgroup per CU,
+        three 64-tile ones)."""
+        bt = 128 if (s.cin > 64 and s.cout > 64) else 64
+        tiles = s.kh * s.kw * ((s.cin + bt - 1) // bt) * ((s.cout + bt - 1) // bt)
+        target = int(os.environ.get("DTF_DW_BLOCKS", "0")) or (256 if bt == 128 else 768)
+        return max(1, min((target + tiles - 1) // tiles, npos // 256 if npos >= 256 else 1))
+
     def backward(self, on_conv_done=None) -> None:
         """Runs the backward program; ``on_conv_done(name)`` is called after the kernels that finalise conv ``name``'s
         arena segment have been enqueued (the DP trainer launches bucket all-reduces from it)."""
@@ -353,19 +463,9 @@ class InceptionTrainer:
                 chk(lib.dtf_bn_relu_bwd_apply(dy_p, Cd, y_p, Cd, z.data_ptr(), self._bn_ptr(s.name), cur, prev,
                                               self.grad(s.name + "/batchnorm/gamma").data_ptr(),
                                               self.grad(s.name + "/batchnorm/beta").data_ptr(), M, s.cout, st), "bn_bwd_apply")
-                K = s.kh * s.kw * s.cin
-                chk(lib.dtf_conv_dw_general(src.data_ptr(), Cs, z.data_ptr(), self.grad(s.name + "/conv2d_params").data_ptr(),
-                                            B, H, W, s.cin, s.cout, s.kh, s.kw, s.stride, s.pad[0], s.pad[1], Ho, Wo,
-                                            self._dw_splits(K, s.cout, M), st), "conv_dw " + s.name)
-                if op.src != "input" and self.async_lds:
-                    chk(lib.dtf_conv_bwd_data_v2(z.data_ptr(), self.Wq.data_ptr() + 2 * self.pack_off[s.name],
-                                                 self.dact[op.src].data_ptr(), B, H, W, s.cin, Cs, s.cout, s.kh, s.kw, s.stride,
-                                                 s.pad[0], s.pad[1], Ho, Wo, int(self.accumulate[i]), st),
-                        "conv_bwd_data_v2 " + s.name)
-                elif op.src != "input":
-                    chk(lib.dtf_conv_bwd_data(z.data_ptr(), self.param(s.name + "/conv2d_params").data_ptr(),
-                                              self.dact[op.src].data_ptr(), B, H, W, s.cin, Cs, s.cout, s.kh, s.kw, s.stride,
-                                              s.pad[0], s.pad[1], Ho, Wo, int(self.accumulate[i]), st), "conv_bwd_data " + s.name)
+                self._conv_dw(op, src, self.core[s.name]["dw"], st)
+                if op.src != "input":
+                    self._conv_bwd_data(op, src, self.core[s.name]["bwd"], int(self.accumulate[i]), st)
                 if on_conv_done is not None:
                     on_conv_done(s.name)
             elif op.kind == "maxpool":

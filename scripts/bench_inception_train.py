@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--optimizer", default="sgd")
     ap.add_argument("--eager", action="store_true", help="also time the PyTorch eager (MIOpen, bf16 autocast-free fp32/bf16) step")
     ap.add_argument("--eager-dtype", default="bf16")
-    ap.add_argument("--v1", action="store_true", help="first-generation (register-staged) conv core")
+    ap.add_argument("--core", default="auto", choices=["auto", "v1", "v2"], help="conv GEMM core selection")
     args = ap.parse_args()
     from distributed_tensorflow_amd.models.inception_train import InceptionTrainer, torch_forward_train
     from distributed_tensorflow_amd.models.inception_v3 import graph_flops
@@ -34,7 +34,8 @@ def main():
     x[..., :3] = torch.randn(B, 299, 299, 3, device="cuda")
     x = x.to(torch.bfloat16)
     labels = torch.randint(0, args.classes, (B,), device="cuda", dtype=torch.int32)
-    tr = InceptionTrainer(args.classes, B, "cuda", lr=0.01, optimizer=args.optimizer, seed=1, async_lds=not args.v1)
+    tr = InceptionTrainer(args.classes, B, "cuda", lr=0.01, optimizer=args.optimizer, seed=1, conv_core=args.core)
+    print(tr.tuning_summary(), flush=True)
     for _ in range(args.warmup):
         tr.train_step(x, labels)
     torch.cuda.synchronize()
@@ -45,7 +46,7 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
     fl = 3.0 * graph_flops(tr.graph) * B
     print(json.dumps({"engine": "native", "batch": B, "ms_per_step": round(dt * 1e3, 2), "images_per_sec": round(B / dt, 1),
-                      "model_tflops": round(fl / dt / 1e12, 1), "loss": tr.metrics()[0], "optimizer": args.optimizer,
+                      "model_tflops": round(fl / dt / 1e12, 1), "loss": tr.metrics()[0], "optimizer": args.optimizer, "conv_core": args.core,
                       "activation_gb": round(tr.activation_bytes() / 1e9, 2), "params": tr.num_params}), flush=True)
     if args.eager:
         dt_ = torch.bfloat16 if args.eager_dtype == "bf16" else torch.float32

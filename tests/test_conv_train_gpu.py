@@ -85,7 +85,7 @@ def test_async_lds_igemm_matches_reference(geom):
     backward-data (store and accumulate) against PyTorch on the same bf16 operands."""
     import ctypes as C
     lib, chk = _lib()
-    chk(lib.dtf_igemm2_init(), "init")
+    chk(lib.dtf_igemm2_init() or lib.dtf_igemm2_dw_init(), "init")
     H, W, Cin, Cout, KH, KW, s, ph, pw = geom
     B = 5
     torch.manual_seed(H + Cout)
@@ -123,6 +123,13 @@ def test_async_lds_igemm_matches_reference(geom):
     assert _relerr(ybuf[..., 8:].permute(0, 3, 1, 2), F.relu(ref + bias.view(1, -1, 1, 1))) < 1e-2
     assert float(ybuf[..., :8].float().abs().max()) == 0.0
     dz = torch.randn(B, Ho, Wo, Cout, device="cuda").to(BF)
+    wl = wt.clone().requires_grad_(True)
+    (gw,) = torch.autograd.grad(F.conv2d(x.detach(), wl, stride=s, padding=(ph, pw)), wl, dz.float().permute(0, 3, 1, 2))
+    for splits in (1, 7):
+        dW = torch.zeros(KH, KW, Cin, Cout, device="cuda")
+        chk(lib.dtf_conv_dw_v2(xfull.data_ptr() + 2 * 8, Ctot, dz.data_ptr(), dW.data_ptr(), B, H, W, Cin, Cout, KH, KW, s, ph, pw,
+                               Ho, Wo, splits, _st()), "dw2")
+        assert _relerr(dW, gw.permute(2, 3, 1, 0)) < 5e-3, splits
     (gx,) = torch.autograd.grad(ref, x, dz.float().permute(0, 3, 1, 2))
     dxfull = torch.full((B, H, W, Ctot), 7.0, dtype=BF, device="cuda")
     for acc in (0, 1):
