@@ -113,6 +113,9 @@ def run(FLAGS, distributed: bool) -> int:
         sv.prepare_or_wait_for_session()
         sv.start_standard_services()
 
+    if FLAGS.profile:
+        from ..utils import trace
+        _log(rank, "profiling: roctx ranges %s" % ("on" if trace.enable(True) else "unavailable (libroctx64 not found)"))
     start_step = engine.global_step
     flushed = start_step
     start_time = time.time()
@@ -137,6 +140,8 @@ def run(FLAGS, distributed: bool) -> int:
                 else:
                     train_acc = float("nan")
                 _log(rank, "Iter " + str(last) + ", test_acc: " + str(test_acc) + ", train_acc = " + str(train_acc))
+                if FLAGS.check_replicas and not trainer.replicas_in_sync():
+                    raise RuntimeError("replica parameter checksums diverged at step %d" % last)
                 if writer is not None:
                     s = Summary().scalar("eval/test_accuracy", test_acc).scalar("eval/train_accuracy", train_acc)
                     if FLAGS.variable_summaries:

@@ -67,6 +67,8 @@ def add_framework_flags(p: argparse.ArgumentParser) -> None:
                    help="Supervisor autosave period (demo2/train.py:172)")
     p.add_argument("--fault_inject_step", type=int, default=-1,
                    help="raise inside the training loop at this step (failure-recovery tests)")
+    p.add_argument("--check_replicas", type="bool", nargs="?", const=True, default=False,
+                   help="debug: verify after every eval interval that all replicas hold identical parameters")
     p.add_argument("--profile", type="bool", nargs="?", const=True, default=False,
                    help="emit roctx ranges / step timing breakdown")
 

@@ -25,6 +25,8 @@ from typing import Optional, Tuple
 import torch
 import torch.distributed as dist
 
+from ..utils import trace
+
 
 def init_process_group(backend: str = "auto", rank: Optional[int] = None, world: Optional[int] = None,
                        master_addr: Optional[str] = None, master_port: Optional[int] = None,
@@ -174,18 +176,23 @@ class DataParallelTrainer:
             return
         if self._native:
             with torch.cuda.stream(e.stream):
-                e.launch("part1")
+                with trace.range("fwd+head+fc_dW (graph part1)"):
+                    e.launch("part1")
                 if self.overlap:
-                    wa = self._reduce(self._bucket_a, async_op=True)
-                    e.launch("part2")
-                    wb = self._reduce(self._bucket_b, async_op=True)
-                    if wa is not None:
-                        wa.wait()
-                        wb.wait()
+                    with trace.range("all-reduce bucket A (fc grads) || conv backward (graph part2)"):
+                        wa = self._reduce(self._bucket_a, async_op=True)
+                        e.launch("part2")
+                    with trace.range("all-reduce bucket B (conv grads)"):
+                        wb = self._reduce(self._bucket_b, async_op=True)
+                        if wa is not None:
+                            wa.wait()
+                            wb.wait()
                 else:
-                    e.launch("part2")
-                    self._reduce(e.G)
-                e.launch("apply")
+                    with trace.range("conv backward (graph part2) + all-reduce"):
+                        e.launch("part2")
+                        self._reduce(e.G)
+                with trace.range("fused Adam (graph apply)"):
+                    e.launch("apply")
         else:
             e.fwd_bwd(3)
             dist.all_reduce(e.G, group=self.group)

@@ -161,3 +161,26 @@ def test_bottleneck_text_codec():
     assert lib.dtf_parse_floats(ref.encode(), len(ref), out.ctypes.data_as(C.c_void_p), 2048) == 16
     assert np.allclose(out[:16], vals[:16], rtol=1e-6)
     assert lib.dtf_parse_floats(b"1.0,abc", 7, out.ctypes.data_as(C.c_void_p), 2048) == -1
+
+
+def test_trace_ranges_and_step_timer():
+    from distributed_tensorflow_amd.utils import trace
+    with trace.range("disabled"):  # no-op when not enabled
+        pass
+    avail = trace.enable(True)
+    assert avail in (True, False)
+    with trace.range("outer"):
+        trace.mark("m")
+        with trace.range("inner"):
+            pass
+    trace.enable(False)
+    t = trace.StepTimer()
+    for _ in range(3):
+        with t.phase("a"):
+            pass
+        with t.phase("b"):
+            pass
+        t.add_images(100)
+    s = t.summary()
+    assert "images/sec" in s and "a " in s and "x3" in s
+    assert trace.format_table([("k", 2, 1.0, 500.0)]).count("\n") == 1
