@@ -40,6 +40,8 @@ def parse():
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-overlap", action="store_true")
     p.add_argument("--backend", type=str, default="auto", help="auto (nccl==RCCL on GPUs) | gloo (functional tests)")
+    p.add_argument("--comm", type=str, default="auto", choices=["auto", "ipc", "rccl"],
+                   help="gradient transport: direct IPC/xGMI all-reduce, RCCL collectives, or auto (ipc if its self-test passes)")
     p.add_argument("--train-size", type=int, default=55000)
     p.add_argument("--dp-path", action="store_true",
                    help="diagnostic: with --gpus 1, create a 1-rank RCCL group and take the multi-rank step path")
@@ -88,7 +90,7 @@ def main():
     dd = mnist.DeviceDataset(train, device, rank=rank, world=world, seed=1)
     eng = make_engine(args.engine, dd, batch_size=args.batch, lr=1e-4, keep_prob=0.7, double_softmax=True,
                       seed=1234, device=device, use_graph=not args.no_graph)
-    trainer = DataParallelTrainer(eng, sync=True, overlap=not args.no_overlap, force_collectives=args.dp_path)
+    trainer = DataParallelTrainer(eng, sync=True, overlap=not args.no_overlap, force_collectives=args.dp_path, comm=args.comm)
 
     def sync():
         if world > 1:
@@ -140,7 +142,7 @@ def main():
             "config": {"model": "demo2 MNIST CNN (conv5x5x32-pool-conv5x5x64-pool-fc1024-dropout-fc10), Adam 1e-4",
                        "global_batch": global_batch, "seq_len": None, "parallelism": "dp%d" % world,
                        "per_gpu_batch": args.batch, "engine": args.engine, "hipgraph": not args.no_graph,
-                       "overlap_allreduce": not args.no_overlap},
+                       "overlap_allreduce": not args.no_overlap, "gradient_transport": trainer.comm},
             "final_test_accuracy": None if test_acc is None else round(float(test_acc), 4),
             "final_train_loss": last_loss,
             "replicas_in_sync": in_sync,

@@ -45,6 +45,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // MODE 1: backward-data gather (row = input position, tap shifts into the output gradient; stride 1 or 2)
 template <int BN, int MODE, class EP>
 __global__ __launch_bounds__(BN == 64 ? 256 : 512) void igemm2_kernel(const IG2Params q) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the buffer-resource builtins do not exist in the host pass)
   constexpr int BM = 256, BK = 64, S = 3;
   constexpr int NW = BN == 64 ? 4 : 8;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -177,8 +178,9 @@ __global__ __launch_bounds__(BN == 64 ? 256 : 512) void igemm2_kernel(const IG2P
         for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
     }
   }
-  wait_vmcnt<0>();  // drain the zero-page prefetches before the LDS is released
+  wait_vmcnt<0>();  // drain the out-of-range prefetches before the LDS is released
   EP::template run<2, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, 0);
+#endif
 }
 
 template <int BN, int MODE, class EP>

@@ -121,6 +121,7 @@ class NativeMnistEngine(_EngineBase):
             setattr(s, k, self.ws[k].data_ptr())
         self.cfg = s
         self._graphs = {}
+        self.grad_hook = None
         torch.cuda.synchronize(self.device)  # allocations/zero-fills ran on the default stream
         self.init_params(seed)
 
@@ -196,21 +197,33 @@ class NativeMnistEngine(_EngineBase):
         st = self.stream.cuda_stream
         self.stream.synchronize()
         native.check(self.lib.dtf_graph_begin(st), "graph begin")
-        rc = 0
-        if key == "full":
-            rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 3, st) or self.lib.dtf_mnist_apply(C.byref(self.cfg), st)
-        elif key == "part1":
-            rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 1, st)
-        elif key == "part2":
-            rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 2, st)
-        elif key == "apply":
-            rc = self.lib.dtf_mnist_apply(C.byref(self.cfg), st)
-        else:
-            rc = -22
+        rc = self._enqueue(key, st)
         h = C.c_void_p()
         rc2 = self.lib.dtf_graph_end(st, C.byref(h))
         native.check(rc or rc2, "graph capture (%s)" % key)
         self._graphs[key] = h
+
+    def _enqueue(self, key: str, st: int) -> int:
+        """Enqueue the kernels of one step segment on stream ``st`` (directly or under capture)."""
+        if key == "full":
+            rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 3, st)
+            if rc == 0 and self.grad_hook is not None:
+                # in-stream gradient collective (the IPC all-reduce: plain kernels, so it is captured into the
+                # same hipGraph and the whole data-parallel step stays ONE graph launch)
+                self.grad_hook(st)
+            return rc or self.lib.dtf_mnist_apply(C.byref(self.cfg), st)
+        if key == "part1":
+            return self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 1, st)
+        if key == "part2":
+            return self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 2, st)
+        if key == "apply":
+            return self.lib.dtf_mnist_apply(C.byref(self.cfg), st)
+        return -22
+
+    def set_grad_hook(self, hook) -> None:
+        """``hook(stream_ptr)`` runs between backward and optimizer inside the ``full`` segment."""
+        self.grad_hook = hook
+        self._drop_graph()
 
     def launch(self, key: str) -> None:
         """Run a step segment (graph replay when ``use_graph``).  ``apply``/``full`` advance the step."""
@@ -221,16 +234,7 @@ class NativeMnistEngine(_EngineBase):
                 self._capture(key)
             native.check(self.lib.dtf_graph_launch(self._graphs[key], self.stream.cuda_stream), "graph launch")
         else:
-            st = self.stream.cuda_stream
-            if key == "full":
-                rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 3, st) or self.lib.dtf_mnist_apply(C.byref(self.cfg), st)
-            elif key == "part1":
-                rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 1, st)
-            elif key == "part2":
-                rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 2, st)
-            else:
-                rc = self.lib.dtf_mnist_apply(C.byref(self.cfg), st)
-            native.check(rc, "mnist " + key)
+            native.check(self._enqueue(key, self.stream.cuda_stream), "mnist " + key)
         if key in ("full", "apply"):
             self._steps_done += 1
 

@@ -61,7 +61,7 @@ class DataParallelTrainer:
     """Drives an engine (native or eager) under synchronous or emulated-async data parallelism."""
 
     def __init__(self, engine, *, sync: bool = True, async_period: int = 8, group=None, overlap: bool = True,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, comm: str = "auto"):
         self.engine = engine
         # force_collectives: take the multi-rank code path even with one rank (lets a 1-GPU box exercise the
         # RCCL stream/event choreography of the overlapped step end to end)
@@ -83,6 +83,46 @@ class DataParallelTrainer:
         self._multi = self.world > 1 or self._force
         if self._multi:
             self.broadcast_state()
+        # gradient transport: "ipc" = direct two-shot all-reduce over IPC-mapped peer memory (all xGMI links at once, and
+        # plain kernels on the engine's stream, so the whole step is one hipGraph), "rccl" = torch.distributed
+        # collectives overlapped with the conv backward, "auto" = ipc when every rank is on this host, the engine is
+        # native and the start-up self-test against the process group's own all-reduce passes, else rccl.
+        self.comm = "rccl"
+        self.ipc = None
+        if comm not in ("auto", "ipc", "rccl"):
+            raise ValueError("comm must be auto, ipc or rccl")
+        if self._multi and self._native and sync and comm in ("auto", "ipc"):
+            self._try_ipc(required=(comm == "ipc"))
+
+    def _try_ipc(self, required: bool) -> None:
+        import socket
+        hosts = [None] * self.world
+        dist.all_gather_object(hosts, socket.gethostname(), group=self.group)
+        ok = len(set(hosts)) == 1 and self.world <= 8
+        err = "ranks span several hosts or more than 8 ranks"
+        if ok:
+            try:
+                from .ipc_comm import IpcAllReduce
+                self.ipc = IpcAllReduce(self.engine.G.numel(), self.engine.device, group=self.group)
+                ok = self.ipc.self_test()
+                err = "self-test against the process group's all-reduce failed"
+            except Exception as e:  # noqa: BLE001 - any failure here means: use RCCL
+                ok, err = False, repr(e)
+            votes = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                                 device="cpu" if dist.get_backend(self.group) == "gloo" else self.engine.device)
+            dist.all_reduce(votes, op=dist.ReduceOp.MIN, group=self.group)
+            ok = bool(int(votes.item()))
+        if ok:
+            e = self.engine
+            ipc = self.ipc
+            e.set_grad_hook(lambda st: ipc.all_reduce(e.G, stream=st))
+            self.comm = "ipc"
+        else:
+            self.ipc = None
+            if required:
+                raise RuntimeError("IPC all-reduce unavailable: " + err)
+            if self.rank == 0:
+                print("IPC all-reduce not used (%s); gradients go through %s" % (err, dist.get_backend(self.group)), flush=True)
 
     # ------------------------------------------------------------------ collectives
     def _ctx(self):
@@ -173,6 +213,10 @@ class DataParallelTrainer:
                 with self._ctx():
                     self._reduce(e.P)
                     e.P.div_(self.world)
+            return
+        if self.comm == "ipc":
+            with trace.range("fwd+bwd | IPC all-reduce | Adam (one graph)"):
+                e.launch("full")
             return
         if self._native:
             with torch.cuda.stream(e.stream):

@@ -1,0 +1,121 @@
+"""Python side of the direct xGMI / HIP-IPC all-reduce (``csrc/hip/ipc_allreduce.hip``).
+
+``IpcAllReduce`` allocates this rank's fine-grained exchange buffer, swaps IPC handles with the other ranks through
+the already-initialised ``torch.distributed`` group (any backend: the handles are 64-byte blobs), maps the peers and
+then reduces with three kernel launches on the caller's stream — no host round trip, capturable into the step's
+hipGraph.  ``self_test`` compares a few reductions of random data against ``torch.distributed.all_reduce`` and
+agrees on the verdict across ranks, so a box where peer mapping misbehaves falls back to RCCL instead of training on
+wrong sums.  Needs ``HSA_ENABLE_IPC_MODE_LEGACY=0`` (dmabuf IPC) on this pool.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .. import native
+
+MAX_RANKS = 8
+
+
+class _IpcCommStruct(C.Structure):  # csrc/hip/ipc_allreduce.hip: struct IpcComm
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("n_max", C.c_long), ("base", C.c_void_p * MAX_RANKS),
+                ("epoch", C.c_void_p), ("error", C.c_void_p), ("timeout_ticks", C.c_ulonglong)]
+
+
+def _signatures(lib) -> None:
+    if getattr(lib, "_dtf_ipc_sigs", False):
+        return
+    P, I, L = C.c_void_p, C.c_int, C.c_long
+    lib.dtf_ipc_alloc.argtypes, lib.dtf_ipc_alloc.restype = [L, C.POINTER(P)], I
+    lib.dtf_ipc_free.argtypes, lib.dtf_ipc_free.restype = [P], I
+    lib.dtf_ipc_get_handle.argtypes, lib.dtf_ipc_get_handle.restype = [P, P], I
+    lib.dtf_ipc_open_handle.argtypes, lib.dtf_ipc_open_handle.restype = [P, C.POINTER(P)], I
+    lib.dtf_ipc_close_handle.argtypes, lib.dtf_ipc_close_handle.restype = [P], I
+    lib.dtf_ipc_allreduce.argtypes, lib.dtf_ipc_allreduce.restype = [P, P, P, L, I, P], I
+    lib._dtf_ipc_sigs = True
+
+
+class IpcAllReduce:
+    def __init__(self, n_max: int, device, group=None, timeout_s: float = 2.0, blocks: int = 64):
+        if not dist.is_initialized():
+            raise RuntimeError("IpcAllReduce needs an initialised torch.distributed group for the handle exchange")
+        self.lib = native.hip()
+        _signatures(self.lib)
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if self.world > MAX_RANKS:
+            raise ValueError("the IPC all-reduce serves one node (<= %d ranks)" % MAX_RANKS)
+        self.device = torch.device(device)
+        self.n_max = (int(n_max) + 3) // 4 * 4
+        self.blocks = blocks
+        torch.cuda.set_device(self.device)
+        own = C.c_void_p()
+        native.check(self.lib.dtf_ipc_alloc(self.n_max, C.byref(own)), "ipc_alloc")
+        self._own = own.value
+        hbuf = (C.c_char * 64)()
+        native.check(0 if self.lib.dtf_ipc_get_handle(self._own, hbuf) > 0 else -1, "hipIpcGetMemHandle")
+        handles: List[Optional[bytes]] = [None] * self.world
+        dist.all_gather_object(handles, bytes(hbuf), group=group)
+        self._mapped: List[int] = []
+        bases = (C.c_void_p * MAX_RANKS)()
+        for p in range(self.world):
+            if p == self.rank:
+                bases[p] = self._own
+                continue
+            ptr = C.c_void_p()
+            native.check(self.lib.dtf_ipc_open_handle(C.create_string_buffer(handles[p], 64), C.byref(ptr)),
+                         "hipIpcOpenMemHandle (rank %d -> %d)" % (self.rank, p))
+            bases[p] = ptr.value
+            self._mapped.append(ptr.value)
+        self._words = torch.zeros(2, dtype=torch.int32, device=self.device)  # epoch, error
+        self.comm = _IpcCommStruct(self.rank, self.world, self.n_max, bases, self._words.data_ptr(),
+                                   self._words.data_ptr() + 4, int(timeout_s * 100e6))
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=group)  # every rank has mapped every peer before the first flag is written
+
+    def all_reduce(self, src: torch.Tensor, dst: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> None:
+        """dst <- sum over ranks of src (fp32, numel % 4 == 0, <= n_max); in place when ``dst`` is None."""
+        dst = src if dst is None else dst
+        assert src.is_cuda and src.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous()
+        assert src.numel() == dst.numel() and src.numel() % 4 == 0 and src.numel() <= self.n_max
+        st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        native.check(self.lib.dtf_ipc_allreduce(C.byref(self.comm), src.data_ptr(), dst.data_ptr(), src.numel(), self.blocks, st),
+                     "ipc_allreduce")
+
+    def errors(self) -> int:
+        """Number of waits that timed out so far (synchronises)."""
+        return int(self._words[1].item())
+
+    def self_test(self, n: int = 0, rounds: int = 3) -> bool:
+        """Reduce random data ``rounds`` times and compare with the process group's own all-reduce; all ranks get the
+        same verdict."""
+        n = self.n_max if n <= 0 else min(self.n_max, (n + 3) // 4 * 4)
+        gen = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
+        ok = True
+        staged = dist.get_backend(self.group) == "gloo"
+        for r in range(rounds):
+            x = torch.randn(n, generator=gen).to(self.device)
+            ref = x.cpu() if staged else x.clone()
+            dist.all_reduce(ref, group=self.group)
+            y = x.clone()
+            self.all_reduce(y)
+            torch.cuda.synchronize(self.device)
+            ok = ok and bool(torch.allclose(y.cpu(), ref.cpu(), rtol=1e-5, atol=1e-5)) and self.errors() == 0
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        if not staged:
+            flag = flag.to(self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag.item()))
+
+    def close(self) -> None:
+        if getattr(self, "_own", None):
+            torch.cuda.synchronize(self.device)
+            if dist.is_initialized():
+                dist.barrier(group=self.group)
+            for p in self._mapped:
+                self.lib.dtf_ipc_close_handle(p)
+            self.lib.dtf_ipc_free(self._own)
+            self._own = None

@@ -108,23 +108,27 @@ def test_training_reaches_high_accuracy_on_synthetic():
     assert acc2 > 0.8, (loss2, acc2)
 
 
-def test_native_data_parallel_path_two_ranks_one_gpu(tmp_path):
-    """The multi-GPU step (part1 graph -> bucket-A all-reduce || part2 graph -> bucket-B all-reduce -> Adam graph)
-    exercised with 2 ranks sharing the single test GPU over gloo (RCCL refuses duplicate devices)."""
+@pytest.mark.parametrize("comm", ["ipc", "rccl"])
+def test_native_data_parallel_path_two_ranks_one_gpu(tmp_path, comm):
+    """The multi-GPU step with 2 ranks sharing the single test GPU (RCCL refuses duplicate devices, so the process
+    group is gloo): ``ipc`` = fwd+bwd | direct IPC all-reduce | Adam as one hipGraph; ``rccl`` = the collective path
+    (part1 graph -> bucket-A all-reduce || part2 graph -> bucket-B all-reduce -> Adam graph), host-staged for gloo."""
     import json
     import os
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_PORT="29577")
+    port = "29577" if comm == "ipc" else "29578"
+    env = dict(os.environ, MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29577", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5",
-           "--backend", "gloo", "--train-size", "4000"]
+           "--master-port", port, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5",
+           "--backend", "gloo", "--train-size", "4000", "--comm", comm]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 200 and out["replicas_in_sync"] is True
+    assert out["config"]["gradient_transport"] == comm
     assert out["final_train_loss"] < 2.35 and out["value"] > 0
 
 

@@ -1,0 +1,64 @@
+"""Direct HIP-IPC all-reduce (csrc/hip/ipc_allreduce.hip): N ranks sharing the single test GPU (RCCL refuses duplicate
+devices; this backend does not care which device a peer's memory lives on)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+_WORKER = r"""
+import os, sys, json, time
+sys.path.insert(0, sys.argv[1])
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch, torch.distributed as dist
+from distributed_tensorflow_amd.parallel.ipc_comm import IpcAllReduce
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n = 3274688  # the MNIST CNN gradient arena
+comm = IpcAllReduce(n, "cuda:0", timeout_s=5.0)
+ok = comm.self_test(rounds=3)
+# in-place reduction of distinct per-rank data, repeated (epochs advance on the device), odd sizes
+res = {"self_test": ok}
+x = torch.full((n,), float(rank + 1), device="cuda")
+for it in range(5):
+    y = x.clone()
+    comm.all_reduce(y)
+    torch.cuda.synchronize()
+    res["it%d" % it] = bool((y == world * (world + 1) / 2).all())
+small = torch.arange(1000, dtype=torch.float32, device="cuda") * (rank + 1)
+comm.all_reduce(small)
+torch.cuda.synchronize()
+res["small"] = bool(torch.equal(small, torch.arange(1000, dtype=torch.float32, device="cuda") * (world * (world + 1) / 2)))
+torch.cuda.synchronize(); dist.barrier()
+t0 = time.perf_counter()
+for _ in range(50):
+    comm.all_reduce(x.clone() if False else x)  # values grow; only timing matters
+torch.cuda.synchronize()
+res["us_per_allreduce"] = (time.perf_counter() - t0) / 50 * 1e6
+res["errors"] = comm.errors()
+if rank == 0:
+    print(json.dumps(res), flush=True)
+dist.barrier()
+comm.close()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ipc_allreduce_ranks_sharing_one_gpu(tmp_path, world):
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "ipc_worker.py"
+    script.write_text(_WORKER)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + world), str(script), repo]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print(out)
+    assert out["self_test"] is True and out["errors"] == 0 and out["small"] is True
+    assert all(out["it%d" % i] for i in range(5))
