@@ -151,6 +151,7 @@ def run(FLAGS, distributed: bool) -> int:
         from ..models.inception_v3 import InceptionV3
         pb = maybe_download_and_extract(FLAGS.model_dir)
         net = InceptionV3(device, seed=seed)
+        need_calibration = False
         npz = os.path.join(FLAGS.model_dir, "inception_v3_weights.npz")
         if pb is not None:
             # the reference's own artefact (retrain1/retrain.py:66-74), parsed without TensorFlow
@@ -168,10 +169,17 @@ def run(FLAGS, distributed: bool) -> int:
             _log(rank, "loaded Inception-v3 weights from " + npz)
         else:
             _log(rank, "Inception-v3 backbone: random-init weights (no pretrained artefact offline)")
+            need_calibration = True
         backbone = net.forward
     else:
         backbone = TinyBackbone(device, seed=seed)
     preproc = ImagePreprocessor(device)
+    if backbone_kind == "inception" and need_calibration and index.num_images > 0:
+        # random-init only: BatchNorm statistics from one batch of this dataset (same images on every rank)
+        from ..models.inception_train import calibrate_batchnorm
+        pick = np.random.RandomState(seed).permutation(index.num_images)[:min(32, index.num_images)]
+        calibrate_batchnorm(net, preproc.load([index.paths[i] for i in sorted(pick)]))
+        _log(rank, "calibrated BatchNorm statistics of the random-init backbone on %d images" % len(pick))
 
     head = RetrainHead(class_count, device, learning_rate=FLAGS.learning_rate, double_softmax=FLAGS.double_softmax,
                        seed=seed, final_tensor_name=FLAGS.final_tensor_name)

@@ -629,6 +629,17 @@ class EagerInceptionTrainer:
         return float(self.last_loss), float(self.last_correct) / self.B
 
 
+def calibrate_batchnorm(model: InceptionV3, x: torch.Tensor) -> None:
+    """Data-dependent initialisation of a *random-init* backbone: set every conv's BatchNorm moving statistics to the
+    batch statistics of one calibration batch (bf16 NHWC ``[B,299,299,8]``).  Without pretrained weights the folded
+    identity statistics let activation scale drift over 47 layers and the 2048-d features stop separating images;
+    with calibrated statistics random convolutional features are informative enough for the retrain demo."""
+    tr = InceptionTrainer(2, x.shape[0], x.device, init=model, bn_momentum=0.0, conv_core="v1")
+    tr.forward(x.contiguous(), training=True)  # momentum 0: moving statistics := batch statistics
+    torch.cuda.synchronize()
+    tr.export_to(model)
+
+
 def make_inception_trainer(kind: str, *args, **kw):
     if kind == "native":
         return InceptionTrainer(*args, **kw)
