@@ -146,6 +146,7 @@ def main():
             "final_test_accuracy": None if test_acc is None else round(float(test_acc), 4),
             "final_train_loss": last_loss,
             "replicas_in_sync": in_sync,
+            "ipc_wait_timeouts": trainer.ipc.errors() if trainer.ipc is not None else None,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -101,23 +101,20 @@ class DataParallelTrainer:
         ok = len(set(hosts)) == 1 and self.world <= 8
         err = "ranks span several hosts or more than 8 ranks"
         if ok:
-            try:
-                from .ipc_comm import IpcAllReduce
-                self.ipc = IpcAllReduce(self.engine.G.numel(), self.engine.device, group=self.group)
-                ok = self.ipc.self_test()
-                err = "self-test against the process group's all-reduce failed"
-            except Exception as e:  # noqa: BLE001 - any failure here means: use RCCL
-                ok, err = False, repr(e)
-            votes = torch.tensor([1 if ok else 0], dtype=torch.int32,
-                                 device="cpu" if dist.get_backend(self.group) == "gloo" else self.engine.device)
-            dist.all_reduce(votes, op=dist.ReduceOp.MIN, group=self.group)
-            ok = bool(int(votes.item()))
+            # (IpcAllReduce and self_test keep every rank on the same sequence of collectives even when a local HIP
+            # call fails, and self_test's verdict is already agreed across ranks)
+            from .ipc_comm import IpcAllReduce
+            self.ipc = IpcAllReduce(self.engine.G.numel(), self.engine.device, group=self.group)
+            ok = self.ipc.self_test()
+            err = self.ipc.failure or "self-test against the process group's all-reduce failed on some rank"
         if ok:
             e = self.engine
             ipc = self.ipc
             e.set_grad_hook(lambda st: ipc.all_reduce(e.G, stream=st))
             self.comm = "ipc"
         else:
+            if self.ipc is not None:
+                self.ipc.close()  # (collective: the verdict is the same on every rank)
             self.ipc = None
             if required:
                 raise RuntimeError("IPC all-reduce unavailable: " + err)

@@ -51,34 +51,52 @@ class IpcAllReduce:
         self.device = torch.device(device)
         self.n_max = (int(n_max) + 3) // 4 * 4
         self.blocks = blocks
-        torch.cuda.set_device(self.device)
-        own = C.c_void_p()
-        native.check(self.lib.dtf_ipc_alloc(self.n_max, C.byref(own)), "ipc_alloc")
-        self._own = own.value
-        hbuf = (C.c_char * 64)()
-        native.check(0 if self.lib.dtf_ipc_get_handle(self._own, hbuf) > 0 else -1, "hipIpcGetMemHandle")
-        handles: List[Optional[bytes]] = [None] * self.world
-        dist.all_gather_object(handles, bytes(hbuf), group=group)
+        self._own = None
         self._mapped: List[int] = []
-        bases = (C.c_void_p * MAX_RANKS)()
-        for p in range(self.world):
-            if p == self.rank:
-                bases[p] = self._own
-                continue
-            ptr = C.c_void_p()
-            native.check(self.lib.dtf_ipc_open_handle(C.create_string_buffer(handles[p], 64), C.byref(ptr)),
-                         "hipIpcOpenMemHandle (rank %d -> %d)" % (self.rank, p))
-            bases[p] = ptr.value
-            self._mapped.append(ptr.value)
-        self._words = torch.zeros(2, dtype=torch.int32, device=self.device)  # epoch, error
-        self.comm = _IpcCommStruct(self.rank, self.world, self.n_max, bases, self._words.data_ptr(),
-                                   self._words.data_ptr() + 4, int(timeout_s * 100e6))
-        torch.cuda.synchronize(self.device)
+        self.comm = None
+        # Every rank walks through the SAME sequence of collectives (handle all-gather, barrier) whether or not its
+        # local HIP calls succeed: a rank that bailed out early would leave its peers blocked in a collective.
+        self.failure: Optional[str] = None
+        hbytes = b"\0" * 64
+        try:
+            torch.cuda.set_device(self.device)
+            own = C.c_void_p()
+            native.check(self.lib.dtf_ipc_alloc(self.n_max, C.byref(own)), "ipc_alloc")
+            self._own = own.value
+            hbuf = (C.c_char * 64)()
+            native.check(0 if self.lib.dtf_ipc_get_handle(self._own, hbuf) > 0 else -1, "hipIpcGetMemHandle")
+            hbytes = bytes(hbuf)
+        except Exception as e:  # noqa: BLE001
+            self.failure = repr(e)
+        handles: List[Optional[tuple]] = [None] * self.world
+        dist.all_gather_object(handles, (hbytes, self.failure is None), group=group)
+        if self.failure is None and not all(ok for _h, ok in handles):
+            self.failure = "a peer could not allocate/export its exchange buffer"
+        if self.failure is None:
+            try:
+                bases = (C.c_void_p * MAX_RANKS)()
+                for p in range(self.world):
+                    if p == self.rank:
+                        bases[p] = self._own
+                        continue
+                    ptr = C.c_void_p()
+                    native.check(self.lib.dtf_ipc_open_handle(C.create_string_buffer(handles[p][0], 64), C.byref(ptr)),
+                                 "hipIpcOpenMemHandle (rank %d -> %d)" % (self.rank, p))
+                    bases[p] = ptr.value
+                    self._mapped.append(ptr.value)
+                self._words = torch.zeros(2, dtype=torch.int32, device=self.device)  # epoch, error
+                self.comm = _IpcCommStruct(self.rank, self.world, self.n_max, bases, self._words.data_ptr(),
+                                           self._words.data_ptr() + 4, int(timeout_s * 100e6))
+                torch.cuda.synchronize(self.device)
+            except Exception as e:  # noqa: BLE001
+                self.failure = repr(e)
         dist.barrier(group=group)  # every rank has mapped every peer before the first flag is written
 
     def all_reduce(self, src: torch.Tensor, dst: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> None:
         """dst <- sum over ranks of src (fp32, numel % 4 == 0, <= n_max); in place when ``dst`` is None."""
         dst = src if dst is None else dst
+        if self.comm is None:
+            raise RuntimeError("IPC all-reduce is not usable on this rank: %s" % self.failure)
         assert src.is_cuda and src.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous()
         assert src.numel() == dst.numel() and src.numel() % 4 == 0 and src.numel() <= self.n_max
         st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
@@ -96,6 +114,14 @@ class IpcAllReduce:
         gen = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
         ok = True
         staged = dist.get_backend(self.group) == "gloo"
+        # first agree that every rank mapped its peers: a kernel waiting for a rank that never signals would only
+        # end by timeout
+        usable = torch.tensor([1 if self.comm is not None else 0], dtype=torch.int32)
+        if not staged:
+            usable = usable.to(self.device)
+        dist.all_reduce(usable, op=dist.ReduceOp.MIN, group=self.group)
+        if not int(usable.item()):
+            return False
         for r in range(rounds):
             x = torch.randn(n, generator=gen).to(self.device)
             ref = x.cpu() if staged else x.clone()
@@ -117,5 +143,7 @@ class IpcAllReduce:
                 dist.barrier(group=self.group)
             for p in self._mapped:
                 self.lib.dtf_ipc_close_handle(p)
+            self._mapped = []
             self.lib.dtf_ipc_free(self._own)
             self._own = None
+            self.comm = None
