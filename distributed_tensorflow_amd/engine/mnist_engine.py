@@ -206,11 +206,19 @@ class NativeMnistEngine(_EngineBase):
     def _enqueue(self, key: str, st: int) -> int:
         """Enqueue the kernels of one step segment on stream ``st`` (directly or under capture)."""
         if key == "full":
-            rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 3, st)
-            if rc == 0 and self.grad_hook is not None:
-                # in-stream gradient collective (the IPC all-reduce: plain kernels, so it is captured into the
-                # same hipGraph and the whole data-parallel step stays ONE graph launch)
-                self.grad_hook(st)
+            hook = self.grad_hook
+            if hook is None:
+                rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 3, st)
+            else:
+                # in-stream gradient collective (the IPC all-reduce is plain kernels, so it is captured into the same
+                # hipGraph and the whole data-parallel step stays ONE graph launch): the fc gradients are reduced on a
+                # forked stream while the conv backward runs, the conv gradients after it
+                rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 1, st)
+                if rc == 0:
+                    hook.after_part1(self.stream)
+                    rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 2, st)
+                if rc == 0:
+                    hook.after_part2(self.stream)
             return rc or self.lib.dtf_mnist_apply(C.byref(self.cfg), st)
         if key == "part1":
             return self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 1, st)
@@ -221,7 +229,8 @@ class NativeMnistEngine(_EngineBase):
         return -22
 
     def set_grad_hook(self, hook) -> None:
-        """``hook(stream_ptr)`` runs between backward and optimizer inside the ``full`` segment."""
+        """``hook.after_part1(stream)`` / ``hook.after_part2(stream)`` run inside the ``full`` segment after the fc
+        gradients resp. all gradients have been enqueued (``stream`` is the engine's torch stream)."""
         self.grad_hook = hook
         self._drop_graph()
 

@@ -57,6 +57,35 @@ def init_process_group(backend: str = "auto", rank: Optional[int] = None, world:
     return rank, world
 
 
+class _IpcGradHook:
+    """Gradient all-reduce of the native MNIST step over the IPC transport.  With ``overlap`` the fc bucket (12.9 MB,
+    final after step part 1) is reduced on a forked stream while the conv backward (part 2) runs on the main one —
+    event fork/join, so it also becomes a parallel branch of the captured hipGraph — and only the 0.2 MB conv bucket
+    is reduced after it."""
+
+    def __init__(self, ipc, bucket_a: torch.Tensor, bucket_b: torch.Tensor, whole: torch.Tensor, overlap: bool):
+        self.ipc, self.a, self.b, self.whole, self.overlap = ipc, bucket_a, bucket_b, whole, overlap
+        if overlap:
+            self.side = torch.cuda.Stream(device=whole.device)
+            self.ev_fork = torch.cuda.Event()
+            self.ev_join = torch.cuda.Event()
+
+    def after_part1(self, stream) -> None:
+        if not self.overlap:
+            return
+        self.ev_fork.record(stream)
+        self.side.wait_event(self.ev_fork)
+        self.ipc.all_reduce(self.a, stream=self.side.cuda_stream)
+        self.ev_join.record(self.side)
+
+    def after_part2(self, stream) -> None:
+        if not self.overlap:
+            self.ipc.all_reduce(self.whole, stream=stream.cuda_stream)
+            return
+        stream.wait_event(self.ev_join)
+        self.ipc.all_reduce(self.b, stream=stream.cuda_stream)
+
+
 class DataParallelTrainer:
     """Drives an engine (native or eager) under synchronous or emulated-async data parallelism."""
 
@@ -96,9 +125,14 @@ class DataParallelTrainer:
 
     def _try_ipc(self, required: bool) -> None:
         import socket
-        hosts = [None] * self.world
-        dist.all_gather_object(hosts, socket.gethostname(), group=self.group)
-        ok = len(set(hosts)) == 1 and self.world <= 8
+        where = [None] * self.world
+        dev = self.engine.device
+        dist.all_gather_object(where, (socket.gethostname(), dev.index if dev.index is not None else torch.cuda.current_device()),
+                               group=self.group)
+        ok = len(set(h for h, _d in where)) == 1 and self.world <= 8
+        # ranks sharing one GPU (functional tests): a forked stream whose kernels spin on a peer that needs the same
+        # CUs only slows both down (measured 0.51 vs 0.27 ms/step for 2 ranks on one GPU), so no overlap there
+        shared_gpu = len(set(where)) < self.world
         err = "ranks span several hosts or more than 8 ranks"
         if ok:
             # (IpcAllReduce and self_test keep every rank on the same sequence of collectives even when a local HIP
@@ -108,9 +142,8 @@ class DataParallelTrainer:
             ok = self.ipc.self_test()
             err = self.ipc.failure or "self-test against the process group's all-reduce failed on some rank"
         if ok:
-            e = self.engine
-            ipc = self.ipc
-            e.set_grad_hook(lambda st: ipc.all_reduce(e.G, stream=st))
+            self.engine.set_grad_hook(_IpcGradHook(self.ipc, self._bucket_a, self._bucket_b, self.engine.G,
+                                                   self.overlap and not shared_gpu))
             self.comm = "ipc"
         else:
             if self.ipc is not None:
