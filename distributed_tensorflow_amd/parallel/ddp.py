@@ -132,7 +132,7 @@ class DataParallelTrainer:
         ok = len(set(h for h, _d in where)) == 1 and self.world <= 8
         # ranks sharing one GPU (functional tests): a forked stream whose kernels spin on a peer that needs the same
         # CUs only slows both down (measured 0.51 vs 0.27 ms/step for 2 ranks on one GPU), so no overlap there
-        shared_gpu = len(set(where)) < self.world
+        shared_gpu = len(set(where)) < self.world and not os.environ.get("DTF_IPC_FORCE_OVERLAP")
         err = "ranks span several hosts or more than 8 ranks"
         if ok:
             # (IpcAllReduce and self_test keep every rank on the same sequence of collectives even when a local HIP

@@ -108,7 +108,7 @@ def test_training_reaches_high_accuracy_on_synthetic():
     assert acc2 > 0.8, (loss2, acc2)
 
 
-@pytest.mark.parametrize("comm", ["ipc", "rccl"])
+@pytest.mark.parametrize("comm", ["ipc", "ipc-overlap", "rccl"])
 def test_native_data_parallel_path_two_ranks_one_gpu(tmp_path, comm):
     """The multi-GPU step with 2 ranks sharing the single test GPU (RCCL refuses duplicate devices, so the process
     group is gloo): ``ipc`` = fwd+bwd | direct IPC all-reduce | Adam as one hipGraph; ``rccl`` = the collective path
@@ -118,8 +118,11 @@ def test_native_data_parallel_path_two_ranks_one_gpu(tmp_path, comm):
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = "29577" if comm == "ipc" else "29578"
+    port = {"ipc": "29577", "ipc-overlap": "29579", "rccl": "29578"}[comm]
     env = dict(os.environ, MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if comm == "ipc-overlap":  # the forked-stream graph variant used when every rank owns a GPU
+        env["DTF_IPC_FORCE_OVERLAP"] = "1"
+        comm = "ipc"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", port, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5",
            "--backend", "gloo", "--train-size", "4000", "--comm", comm]
