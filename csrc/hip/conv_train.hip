@@ -169,11 +169,12 @@ DTF_API int dtf_bn_relu_fwd(const void* z, const float* bn, void* y, long M, int
 }
 
 // slots[DTF_STAT_SLOTS][2][C] += (sum g, sum g*xhat) with g = dy * (y > 0), xhat = (z - mean) * rstd.
+// The ReLU mask is recomputed from z (y > 0  <=>  z*scale + shift > 0) instead of re-reading the stored activation:
+// one third less traffic in both backward passes.
 // Workgroups accumulate into DTF_STAT_SLOTS replicas (atomic contention, see EpBf16Stats).  No fence / ticket here:
 // an agent-scope release on this multi-XCD part writes back the whole L2 (measured ~18 us per launch); the apply
 // kernel that follows folds the replicas itself.
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const uint16_t* __restrict__ dy, int dy_cs,
-                                                                 const uint16_t* __restrict__ y, int y_cs,
                                                                  const uint16_t* __restrict__ z, const float* __restrict__ bn,
                                                                  float* __restrict__ slots, long M, int C, int rows_per_block) {
   __shared__ float red[256 * 16];
@@ -186,28 +187,29 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const uint16_t*
 #pragma unroll
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
   if (active) {
-    float mean[8], rstd[8];
+    float mean[8], rstd[8], sc[8], sf[8];
     ld8f(bn + c0, mean);
     ld8f(bn + C + c0, rstd);
+    ld8f(bn + 2 * C + c0, sc);
+    ld8f(bn + 3 * C + c0, sf);
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
     for (long r = r0 + ry; r < r1; r += 4L * rpb) {  // four rows in flight per lane (clamped address + select)
-      uint4 gv[4], yv[4], zv[4];
+      uint4 gv[4], zv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long rr = r + (long)u * rpb < r1 ? r + (long)u * rpb : r;
         gv[u] = *reinterpret_cast<const uint4*>(dy + rr * dy_cs + c0);
-        yv[u] = *reinterpret_cast<const uint4*>(y + rr * y_cs + c0);
         zv[u] = *reinterpret_cast<const uint4*>(z + rr * C + c0);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const bool ok = r + (long)u * rpb < r1;
-        float g[8], yy[8], zz[8];
-        unpack8(gv[u], g); unpack8(yv[u], yy); unpack8(zv[u], zz);
+        float g[8], zz[8];
+        unpack8(gv[u], g); unpack8(zv[u], zz);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float gj = (ok && yy[j] > 0.f) ? g[j] : 0.f;
+          const float gj = (ok && zz[j] * sc[j] + sf[j] > 0.f) ? g[j] : 0.f;
           s1[j] += gj;
           s2[j] += gj * (zz[j] - mean[j]) * rstd[j];
         }
@@ -236,14 +238,14 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const uint16_t*
   }
 }
 
-DTF_API int dtf_bn_relu_bwd_reduce(const void* dy, int dy_cstride, const void* y, int y_cstride, const void* z,
-                                   const float* bn, float* slots, long M, int C, hipStream_t st) {
-  if (M <= 0 || C <= 0 || C % 8 || C > 2048 || dy_cstride % 8 || y_cstride % 8) return ERR_SHAPE;
+DTF_API int dtf_bn_relu_bwd_reduce(const void* dy, int dy_cstride, const void* z, const float* bn, float* slots, long M,
+                                   int C, hipStream_t st) {
+  if (M <= 0 || C <= 0 || C % 8 || C > 2048 || dy_cstride % 8) return ERR_SHAPE;
   const int rpb = 256 / (C / 8);
   long rows = (M + 1023) / 1024;
   if (rows < 4L * rpb) rows = 4L * rpb;
   hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(dtf_cdiv(M, rows)), dim3(256), 0, st, (const uint16_t*)dy, dy_cstride,
-                     (const uint16_t*)y, y_cstride, (const uint16_t*)z, bn, slots, M, C, (int)rows);
+                     (const uint16_t*)z, bn, slots, M, C, (int)rows);
   DTF_CHECK_LAUNCH();
   return 0;
 }
@@ -252,7 +254,6 @@ DTF_API int dtf_bn_relu_bwd_reduce(const void* dy, int dy_cstride, const void* y
 // (s1, s2) into LDS (2C x 16 L2-resident floats); workgroup 0 also emits dbeta = s1, dgamma = s2 and clears
 // `slots_prev` — the replica set the previous step used (the two sets alternate, so nobody is reading it any more).
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const uint16_t* __restrict__ dy, int dy_cs,
-                                                                const uint16_t* __restrict__ y, int y_cs,
                                                                 uint16_t* __restrict__ z, const float* __restrict__ bn,
                                                                 const float* __restrict__ slots, float* __restrict__ slots_prev,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, long M,
@@ -279,16 +280,16 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const uint16_t* 
   for (long gi = (long)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (long)gridDim.x * 256) {
     const int c0 = (int)(gi % c8n) * 8;
     const long m = gi / c8n;
-    float g[8], yy[8], zz[8], mean[8], rstd[8], sc[8];
+    float g[8], zz[8], mean[8], rstd[8], sc[8], sf[8];
     unpack8(*reinterpret_cast<const uint4*>(dy + m * dy_cs + c0), g);
-    unpack8(*reinterpret_cast<const uint4*>(y + m * y_cs + c0), yy);
     unpack8(*reinterpret_cast<const uint4*>(z + m * C + c0), zz);
     ld8f(bn + c0, mean);
     ld8f(bn + C + c0, rstd);
     ld8f(bn + 2 * C + c0, sc);
+    ld8f(bn + 3 * C + c0, sf);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float gj = yy[j] > 0.f ? g[j] : 0.f;
+      const float gj = zz[j] * sc[j] + sf[j] > 0.f ? g[j] : 0.f;
       const float xh = (zz[j] - mean[j]) * rstd[j];
       zz[j] = sc[j] * (gj - sm[c0 + j] * inv_m - xh * sm[C + c0 + j] * inv_m);
     }
@@ -296,14 +297,12 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const uint16_t* 
   }
 }
 
-DTF_API int dtf_bn_relu_bwd_apply(const void* dy, int dy_cstride, const void* y, int y_cstride, void* z, const float* bn,
-                                  const float* slots, float* slots_prev, float* dgamma, float* dbeta, long M, int C,
-                                  hipStream_t st) {
-  if (M <= 0 || C <= 0 || C % 8 || C > 2048 || dy_cstride % 8 || y_cstride % 8) return ERR_SHAPE;
+DTF_API int dtf_bn_relu_bwd_apply(const void* dy, int dy_cstride, void* z, const float* bn, const float* slots,
+                                  float* slots_prev, float* dgamma, float* dbeta, long M, int C, hipStream_t st) {
+  if (M <= 0 || C <= 0 || C % 8 || C > 2048 || dy_cstride % 8) return ERR_SHAPE;
   int blocks = ew_blocks(M * (C / 8) / 4, 2048);  // >= 4 elements-of-8 per lane amortise the fold
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(blocks), dim3(256), 2 * C * sizeof(float), st, (const uint16_t*)dy,
-                     dy_cstride, (const uint16_t*)y, y_cstride, (uint16_t*)z, bn, slots, slots_prev, dgamma, dbeta, M, C,
-                     1.f / (float)M);
+                     dy_cstride, (uint16_t*)z, bn, slots, slots_prev, dgamma, dbeta, M, C, 1.f / (float)M);
   DTF_CHECK_LAUNCH();
   return 0;
 }

@@ -456,11 +456,11 @@ class InceptionTrainer:
                 s = op.conv
                 z = self.z[s.name]
                 M = B * Ho * Wo
-                dy_p, y_p = ddst.data_ptr() + 2 * op.dst_off, dst.data_ptr() + 2 * op.dst_off
+                dy_p = ddst.data_ptr() + 2 * op.dst_off
                 cur, prev = self._stats(s.name, 1 + par), self._stats(s.name, 2 - par)
-                chk(lib.dtf_bn_relu_bwd_reduce(dy_p, Cd, y_p, Cd, z.data_ptr(), self._bn_ptr(s.name), cur, M, s.cout, st),
+                chk(lib.dtf_bn_relu_bwd_reduce(dy_p, Cd, z.data_ptr(), self._bn_ptr(s.name), cur, M, s.cout, st),
                     "bn_bwd_reduce")
-                chk(lib.dtf_bn_relu_bwd_apply(dy_p, Cd, y_p, Cd, z.data_ptr(), self._bn_ptr(s.name), cur, prev,
+                chk(lib.dtf_bn_relu_bwd_apply(dy_p, Cd, z.data_ptr(), self._bn_ptr(s.name), cur, prev,
                                               self.grad(s.name + "/batchnorm/gamma").data_ptr(),
                                               self.grad(s.name + "/batchnorm/beta").data_ptr(), M, s.cout, st), "bn_bwd_apply")
                 self._conv_dw(op, src, self.core[s.name]["dw"], st)

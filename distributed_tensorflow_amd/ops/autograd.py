@@ -124,14 +124,14 @@ class _ConvBNReLU(torch.autograd.Function):
         chk(lib.dtf_bn_finalize(stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), native.ptr(moving_mean),
                                 native.ptr(moving_var), bn.data_ptr(), Cout, M, BN_EPS, momentum, _st()), "bn_finalize")
         chk(lib.dtf_bn_relu_fwd(z.data_ptr(), bn.data_ptr(), y.data_ptr(), M, Cout, Cout, _st()), "bn_relu_fwd")
-        ctx.save_for_backward(xb, wc, z, y, bn)
+        ctx.save_for_backward(xb, wc, z, bn)
         ctx.geom = (stride, pad)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib, chk = native.hip(), native.check
-        x, w, z, y, bn = ctx.saved_tensors
+        x, w, z, bn = ctx.saved_tensors
         stride, pad = ctx.geom
         B, H, W, Cin = x.shape
         KH, KW, _, Cout = w.shape
@@ -142,9 +142,9 @@ class _ConvBNReLU(torch.autograd.Function):
         slots = torch.zeros(STAT_SLOTS, 2, Cout, device=dev)
         dgamma, dbeta = torch.empty(Cout, device=dev), torch.empty(Cout, device=dev)
         dz = z.clone()  # the kernels turn z into dz in place; keep the saved tensor intact for double backward calls
-        chk(lib.dtf_bn_relu_bwd_reduce(dyb.data_ptr(), Cout, y.data_ptr(), Cout, dz.data_ptr(), bn.data_ptr(), slots.data_ptr(), M,
-                                       Cout, _st()), "bn_bwd_reduce")
-        chk(lib.dtf_bn_relu_bwd_apply(dyb.data_ptr(), Cout, y.data_ptr(), Cout, dz.data_ptr(), bn.data_ptr(), slots.data_ptr(), 0,
+        chk(lib.dtf_bn_relu_bwd_reduce(dyb.data_ptr(), Cout, dz.data_ptr(), bn.data_ptr(), slots.data_ptr(), M, Cout, _st()),
+            "bn_bwd_reduce")
+        chk(lib.dtf_bn_relu_bwd_apply(dyb.data_ptr(), Cout, dz.data_ptr(), bn.data_ptr(), slots.data_ptr(), 0,
                                       dgamma.data_ptr(), dbeta.data_ptr(), M, Cout, _st()), "bn_bwd_apply")
         dw = None
         if ctx.needs_input_grad[1]:

@@ -173,10 +173,10 @@ def test_batchnorm_relu_forward_backward(M, C):
     slots = torch.zeros(16, 2, C, device="cuda")
     prev = torch.ones(16, 2, C, device="cuda")  # the other step parity's accumulators: cleared by the apply kernel
     dgamma, dbeta = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
-    chk(lib.dtf_bn_relu_bwd_reduce(dybuf.data_ptr() + 2 * 16, Cd, ybuf.data_ptr() + 2 * 16, Cd, z.data_ptr(), bn.data_ptr(),
-                                   slots.data_ptr(), M, C, _st()), "reduce")
-    chk(lib.dtf_bn_relu_bwd_apply(dybuf.data_ptr() + 2 * 16, Cd, ybuf.data_ptr() + 2 * 16, Cd, z.data_ptr(), bn.data_ptr(),
-                                  slots.data_ptr(), prev.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), M, C, _st()), "apply")
+    chk(lib.dtf_bn_relu_bwd_reduce(dybuf.data_ptr() + 2 * 16, Cd, z.data_ptr(), bn.data_ptr(), slots.data_ptr(), M, C, _st()),
+        "reduce")
+    chk(lib.dtf_bn_relu_bwd_apply(dybuf.data_ptr() + 2 * 16, Cd, z.data_ptr(), bn.data_ptr(), slots.data_ptr(), prev.data_ptr(),
+                                  dgamma.data_ptr(), dbeta.data_ptr(), M, C, _st()), "apply")
     assert float(prev.abs().max()) == 0.0
     assert _relerr(dbeta, gb) < 2e-3 and _relerr(dgamma, gg) < 5e-3
     assert _relerr(z, gz) < 2e-2  # z now holds dz
