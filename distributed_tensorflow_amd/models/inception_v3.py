@@ -203,8 +203,10 @@ def graph_flops(g: _Builder) -> float:
 class InceptionV3:
     """Weights + native batched executor."""
 
-    def __init__(self, device="cuda", seed: Optional[int] = 0):
+    def __init__(self, device="cuda", seed: Optional[int] = 0, conv_core: str = "auto"):
         self.graph = build_graph()
+        self.conv_core = conv_core       # "v1" | "v2" | "auto" (time both GEMM cores per layer and batch size once)
+        self._core: Dict[int, Dict[str, int]] = {}
         self.device = torch.device(device)
         self.params: "OrderedDict[str, Dict[str, torch.Tensor]]" = OrderedDict()
         gen = torch.Generator(device="cpu")
@@ -280,7 +282,8 @@ class InceptionV3:
                 s = op.conv
                 wp, b = self.packed(s.name)
                 hip_ops.conv_bias_relu(src, wp, b, Cin=s.cin, KH=s.kh, KW=s.kw, stride=s.stride, pad=s.pad, relu=True,
-                                       out=bufs[op.dst], out_channel_offset=op.dst_off, in_channel_offset=op.src_off)
+                                       out=bufs[op.dst], out_channel_offset=op.dst_off, in_channel_offset=op.src_off,
+                                       core=self._core.get(B, {}).get(s.name, 1))
             elif op.kind == "maxpool":
                 dst = bufs[op.dst]
                 _, H, W, Cs = src.shape
@@ -296,11 +299,47 @@ class InceptionV3:
                 native.check(lib.dtf_global_avgpool(src.data_ptr(), bufs["pool_3"].data_ptr(), B, H * W, Cs, st), "gap")
         return bufs["pool_3"]
 
+    def _select_cores(self, x: torch.Tensor, bufs: Dict[str, torch.Tensor]) -> None:
+        """Per-layer choice between the two conv GEMM cores for this batch size (measured once, best of 3)."""
+        from ..ops import hip_ops
+        B = x.shape[0]
+        if self.conv_core == "v1":
+            self._core[B] = {}
+            return
+        hip_ops.igemm2_init()
+        if self.conv_core == "v2":
+            self._core[B] = {name: 2 for name in self.graph.convs}
+            return
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        choice: Dict[str, int] = {}
+        for op in self.graph.ops:
+            if op.kind != "conv":
+                continue
+            s = op.conv
+            src = x if op.src == "input" else bufs[op.src]
+            wp, b = self.packed(s.name)
+            t = {}
+            for core in (1, 2):
+                best = float("inf")
+                for rep in range(4):
+                    ev0.record()
+                    hip_ops.conv_bias_relu(src, wp, b, Cin=s.cin, KH=s.kh, KW=s.kw, stride=s.stride, pad=s.pad, relu=True,
+                                           out=bufs[op.dst], out_channel_offset=op.dst_off, in_channel_offset=op.src_off, core=core)
+                    ev1.record()
+                    ev1.synchronize()
+                    if rep:
+                        best = min(best, ev0.elapsed_time(ev1))
+                t[core] = best
+            choice[s.name] = 2 if t[2] < 0.97 * t[1] else 1
+        self._core[B] = choice
+
     def forward(self, x: torch.Tensor, use_graph: bool = True) -> torch.Tensor:
         """bf16 NHWC ``[B,299,299,8]`` -> fp32 bottlenecks ``[B,2048]`` (a fresh tensor)."""
         assert x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1:] == (299, 299, INPUT_PAD_CHANNELS) and x.is_contiguous()
         B = x.shape[0]
         bufs = self._alloc(B)
+        if B not in self._core:
+            self._select_cores(x, bufs)
         if not use_graph:
             return self._run_ops(x, bufs).clone()
         if B not in self._graphs:

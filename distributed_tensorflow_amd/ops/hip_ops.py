@@ -172,9 +172,10 @@ def conv2_backward_lds(dpool2: torch.Tensor, pool2: torch.Tensor, amax2: torch.T
 def conv_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, *, Cin: int, KH: int, KW: int,
                    stride: int = 1, pad: Tuple[int, int] = (0, 0), relu: bool = True,
                    out: Optional[torch.Tensor] = None, out_channel_offset: int = 0,
-                   in_channel_offset: int = 0) -> torch.Tensor:
+                   in_channel_offset: int = 0, core: int = 1) -> torch.Tensor:
     """Inference conv (+folded BN bias, ReLU): bf16 NHWC in (optionally a channel slice), bf16 packed
-    ``[Cout, KH*KW*Cin]`` weights, bf16 NHWC out written into ``out[..., off:off+Cout]`` (concat by slice write)."""
+    ``[Cout, KH*KW*Cin]`` weights, bf16 NHWC out written into ``out[..., off:off+Cout]`` (concat by slice write).
+    ``core``: 1 = register-staged GEMM core (gemm_core.h), 2 = async-LDS core (igemm2.hip; needs ``igemm2_init()``)."""
     _chk(x, torch.bfloat16, "x")
     _chk(w_packed, torch.bfloat16, "w_packed")
     _chk(bias, torch.float32, "bias")
@@ -189,10 +190,15 @@ def conv_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, 
     assert out.shape[:3] == (B, Ho, Wo) and out_channel_offset + Cout <= out.shape[3]
     xp = x.data_ptr() + 2 * in_channel_offset
     op = out.data_ptr() + 2 * out_channel_offset
-    native.check(native.hip().dtf_conv_bias_relu(xp, w_packed.data_ptr(), bias.data_ptr(), op, B, H, W, Cin, Ctot, Cout,
-                                                 out.shape[3], KH, KW, stride, pad[0], pad[1], Ho, Wo, int(relu), _st()),
-                 "conv_bias_relu")
+    fn = native.hip().dtf_conv_bias_relu_v2 if core == 2 else native.hip().dtf_conv_bias_relu
+    native.check(fn(xp, w_packed.data_ptr(), bias.data_ptr(), op, B, H, W, Cin, Ctot, Cout, out.shape[3], KH, KW, stride,
+                    pad[0], pad[1], Ho, Wo, int(relu), _st()), "conv_bias_relu(core %d)" % core)
     return out
+
+
+def igemm2_init() -> None:
+    """One-time setup of the async-LDS conv core (raises its dynamic-LDS limits; not capturable)."""
+    native.check(native.hip().dtf_igemm2_init() or native.hip().dtf_igemm2_dw_init(), "igemm2_init")
 
 
 def adam_tf_(P: torch.Tensor, G: torch.Tensor, M: torch.Tensor, V: torch.Tensor, step: torch.Tensor,
