@@ -118,10 +118,31 @@ class DataParallelTrainer:
         # native and the start-up self-test against the process group's own all-reduce passes, else rccl.
         self.comm = "rccl"
         self.ipc = None
+        self.transport_us = None
         if comm not in ("auto", "ipc", "rccl"):
             raise ValueError("comm must be auto, ipc or rccl")
         if self._multi and self._native and sync and comm in ("auto", "ipc"):
             self._try_ipc(required=(comm == "ipc"))
+
+    def _time_transports(self, iters: int = 8):
+        """(ipc, process-group) microseconds per all-reduce of the gradient arena, max over ranks."""
+        import time
+        e = self.engine
+        buf = torch.zeros_like(e.G)
+        out = []
+        for fn in (lambda: self.ipc.all_reduce(buf), lambda: self._reduce(buf)):
+            with self._ctx():
+                fn()
+                e.stream.synchronize()
+                dist.barrier(group=self.group)
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    fn()
+                e.stream.synchronize()
+            out.append((time.perf_counter() - t0) / iters * 1e6)
+        t = torch.tensor(out, dtype=torch.float64, device="cpu" if self._stage_host else e.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t[0]), float(t[1])
 
     def _try_ipc(self, required: bool) -> None:
         import socket
@@ -141,6 +162,12 @@ class DataParallelTrainer:
             self.ipc = IpcAllReduce(self.engine.G.numel(), self.engine.device, group=self.group)
             ok = self.ipc.self_test()
             err = self.ipc.failure or "self-test against the process group's all-reduce failed on some rank"
+            if ok and not required:
+                # measure, don't guess: keep the process group's collectives if they reduce the arena clearly faster
+                t_ipc, t_pg = self._time_transports()
+                self.transport_us = {"ipc": round(t_ipc, 1), "process_group": round(t_pg, 1)}
+                if t_ipc > 1.5 * t_pg:
+                    ok, err = False, "IPC all-reduce slower than the process group's (%.0f vs %.0f us)" % (t_ipc, t_pg)
         if ok:
             self.engine.set_grad_hook(_IpcGradHook(self.ipc, self._bucket_a, self._bucket_b, self.engine.G,
                                                    self.overlap and not shared_gpu))
