@@ -272,6 +272,7 @@ def bind_device(rank: int, device_flag: str = "auto"):
     if device_flag == "cpu" or not torch.cuda.is_available():
         return torch.device("cpu")
     n = torch.cuda.device_count()
-    local = int(os.environ.get("LOCAL_RANK", rank % max(1, n)))
+    # more local ranks than GPUs (functional runs on a small box): ranks wrap around and share devices
+    local = int(os.environ.get("LOCAL_RANK", rank)) % max(1, n)
     torch.cuda.set_device(local)
     return torch.device("cuda", local)
