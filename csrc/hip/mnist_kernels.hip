@@ -293,10 +293,17 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
   int it = 0;
   for (int row = blockIdx.x; row < p.B; row += gridDim.x, ++it) {
     float4 h = b1;
-#pragma unroll 4
-    for (int s = 0; s < p.nslab; ++s) {
-      const float4 v = *reinterpret_cast<const float4*>(p.slabs + (long)s * p.slab_stride + (long)row * HID + k);
-      h.x += v.x; h.y += v.y; h.z += v.z; h.w += v.w;
+    // all split-K slabs of this row in flight at once (clamped index + select: one L2 round trip instead of nslab/4)
+    for (int s0 = 0; s0 < p.nslab; s0 += 16) {
+      f32x4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int s = s0 + u < p.nslab ? s0 + u : p.nslab - 1;
+        v[u] = *reinterpret_cast<const f32x4*>(p.slabs + (long)s * p.slab_stride + (long)row * HID + k);
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (s0 + u < p.nslab) { h.x += v[u][0]; h.y += v[u][1]; h.z += v[u][2]; h.w += v[u][3]; }
     }
     float hv[4] = {fmaxf(h.x, 0.f), fmaxf(h.y, 0.f), fmaxf(h.z, 0.f), fmaxf(h.w, 0.f)};
     bool keep[4] = {true, true, true, true};
