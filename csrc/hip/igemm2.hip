@@ -43,11 +43,17 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // MODE 0: forward gather (row = output position, tap shifts into the input)
 // MODE 1: backward-data gather (row = input position, tap shifts into the output gradient; stride 1 or 2)
-template <int BN, int MODE, class EP>
-__global__ __launch_bounds__(BN == 64 ? 256 : 512) void igemm2_kernel(const IG2Params q) {
+// Tile variants: BM x BN x stages.  256-row tiles keep one workgroup per CU (120-144 KB of LDS) and pay off when an M
+// tile has many K-steps; 128-row tiles (72 / 64 KB) put two workgroups on a CU, whose prologues and epilogues then
+// overlap — the better shape for the short K loops (K = 192..800) that dominate this network.
+template <int BM, int BN, int S, int MODE, class EP>
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm2_kernel(const IG2Params q) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the buffer-resource builtins do not exist in the host pass)
-  constexpr int BM = 256, BK = 64, S = 3;
-  constexpr int NW = BN == 64 ? 4 : 8;
+  constexpr int BK = 64;
+  constexpr int WN = BN / 64, NW = (BM / 64) * WN;
+  static_assert(S == 2 || S == 3, "ring depth");
+  static_assert(((BM / 8) % NW) == 0 && ((BN / 8) % NW) == 0 && (((BM / 8) / NW) % 2) == 0 && (((BN / 8) / NW) % 2) == 0,
+                "every wave issues an even number of 8-row load instructions per operand (swizzle parity = i & 1)");
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int A_PER = (BM / 8) / NW, B_PER = (BN / 8) / NW, LPS = A_PER + B_PER;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -149,19 +155,19 @@ __global__ __launch_bounds__(BN == 64 ? 256 : 512) void igemm2_kernel(const IG2P
 
   const int nsteps = (p.K + BK - 1) / BK;
   issue(0, 0);
-  issue(1, 1);  // steps >= nsteps only fetch the zero page (k >= K)
+  if (S == 3) issue(1, 1);  // steps >= nsteps only fetch out-of-range zeros (k >= K)
 
   const int r = lane & 31, h = lane >> 5;
-  const int wm = BN == 64 ? wave : (wave >> 1), wn = BN == 64 ? 0 : (wave & 1);
+  const int wm = wave / WN, wn = wave % WN;
   const int sw = (r >> 1) & 7;  // fragment rows start at multiples of 32: (R >> 1) & 7 == (r >> 1) & 7
   for (int t = 0; t < nsteps; ++t) {
-    wait_vmcnt<LPS>();  // this wave's loads of stage t have landed (stage t+1 may still be in flight)
+    wait_vmcnt<(S - 2) * LPS>();  // this wave's loads of stage t have landed (with S == 3 stage t+1 stays in flight)
     // Bare s_barrier, not __syncthreads(): the latter's fence makes hipcc emit s_waitcnt vmcnt(0), which would drain
     // the stage that is supposed to stay in flight.  After it everyone's stage-t data is in LDS and everyone is done
     // reading the stage consumed at step t-1 (its ds_reads were waited on before the MFMAs that used them).
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    issue(t + 2, (t + 2) % S);
+    issue(t + S - 1, (t + S - 1) % S);
     const unsigned char* As = smem + (t % S) * STAGE;
     const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
@@ -183,22 +189,34 @@ __global__ __launch_bounds__(BN == 64 ? 256 : 512) void igemm2_kernel(const IG2P
 #endif
 }
 
-template <int BN, int MODE, class EP>
-int launch_igemm2(IG2Params& q, hipStream_t st) {
-  constexpr int NTHREADS = BN == 64 ? 256 : 512;
-  constexpr int LDS = 3 * (256 * 128 + BN * 128);
-  q.mtiles = dtf_cdiv(q.gp.M, 256);
+template <int BM, int BN, int S, int MODE, class EP>
+int launch_one(IG2Params& q, hipStream_t st) {
+  constexpr int NTHREADS = (BM / 64) * (BN / 64) * 64;
+  constexpr int LDS = S * (BM * 128 + BN * 128);
+  q.mtiles = dtf_cdiv(q.gp.M, BM);
   q.ntiles = dtf_cdiv(q.gp.N, BN);
   const int mt8 = (q.mtiles + 7) / 8 * 8;
-  hipLaunchKernelGGL((igemm2_kernel<BN, MODE, EP>), dim3(mt8 * q.ntiles), dim3(NTHREADS), LDS, st, q);
+  hipLaunchKernelGGL((igemm2_kernel<BM, BN, S, MODE, EP>), dim3(mt8 * q.ntiles), dim3(NTHREADS), LDS, st, q);
   DTF_CHECK_LAUNCH();
   return 0;
 }
 
+// variant 0: 256-row tiles, 3 stages; variant 1: 128-row tiles (3 stages at BN = 64, 2 at BN = 128): two workgroups / CU
+template <int BN, int MODE, class EP>
+int launch_igemm2(IG2Params& q, int variant, hipStream_t st) {
+  if (variant == 1) return launch_one<128, BN, (BN == 64 ? 3 : 2), MODE, EP>(q, st);
+  if (variant != 0) return ERR_SHAPE;
+  return launch_one<256, BN, 3, MODE, EP>(q, st);
+}
+
+template <int BM, int BN, int S, int MODE, class EP>
+bool raise_one() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, S, MODE, EP>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, S * (BM * 128 + BN * 128)) == hipSuccess;
+}
 template <int BN, int MODE, class EP>
 bool raise_lds_limit() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BN, MODE, EP>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 * 128 + BN * 128)) == hipSuccess;
+  return raise_one<256, BN, 3, MODE, EP>() && raise_one<128, BN, (BN == 64 ? 3 : 2), MODE, EP>();
 }
 
 uint16_t* g_zero_page = nullptr;
@@ -241,38 +259,38 @@ DTF_API int dtf_igemm2_init() {
 // z[B,Ho,Wo,Cout] (bf16 dense) = conv(x, Wp) + BN statistics (see EpBf16Stats); Wp = bf16 [Cout][KH*KW*Cin]
 DTF_API int dtf_conv_fwd_stats_v2(const void* x, const void* Wp, void* z, float* stats, int B, int H, int W, int Cin,
                                   int in_cstride, int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int Ho,
-                                  int Wo, hipStream_t st) {
+                                  int Wo, int variant, hipStream_t st) {
   IG2Params q;
   const int rc = fill(q, x, Wp, z, B * Ho * Wo, Cout, KH * KW * Cin, Cout, H, W, Cin, in_cstride, Ho, Wo, KH, KW, stride, pad_h, pad_w);
   if (rc) return rc;
   q.gp.aux_out = stats;
-  if (Cout > 64) return launch_igemm2<128, 0, EpBf16Stats>(q, st);
-  return launch_igemm2<64, 0, EpBf16Stats>(q, st);
+  if (Cout > 64) return launch_igemm2<128, 0, EpBf16Stats>(q, variant, st);
+  return launch_igemm2<64, 0, EpBf16Stats>(q, variant, st);
 }
 
 // Inference conv: out = bf16(relu(conv(x, Wp) + bias)) written at channel stride out_cstride (concat slice)
 DTF_API int dtf_conv_bias_relu_v2(const void* x, const void* Wp, const float* bias, void* out, int B, int H, int W, int Cin,
                                   int in_cstride, int Cout, int out_cstride, int KH, int KW, int stride, int pad_h, int pad_w,
-                                  int Ho, int Wo, int relu, hipStream_t st) {
+                                  int Ho, int Wo, int relu, int variant, hipStream_t st) {
   IG2Params q;
   const int rc = fill(q, x, Wp, out, B * Ho * Wo, Cout, KH * KW * Cin, out_cstride, H, W, Cin, in_cstride, Ho, Wo, KH, KW, stride, pad_h, pad_w);
   if (rc) return rc;
   q.gp.bias = bias;
   q.gp.relu = relu;
-  if (Cout > 64) return launch_igemm2<128, 0, EpBiasReluBf16>(q, st);
-  return launch_igemm2<64, 0, EpBiasReluBf16>(q, st);
+  if (Cout > 64) return launch_igemm2<128, 0, EpBiasReluBf16>(q, variant, st);
+  return launch_igemm2<64, 0, EpBiasReluBf16>(q, variant, st);
 }
 
 // dx[B,H,W,Cin] (bf16 at channel stride dx_cstride) (+)= conv^T(dz, Wq); Wq = bf16 [Cin][KH*KW*Cout]
 DTF_API int dtf_conv_bwd_data_v2(const void* dz, const void* Wq, void* dx, int B, int H, int W, int Cin, int dx_cstride,
                                  int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int Ho, int Wo, int accumulate,
-                                 hipStream_t st) {
+                                 int variant, hipStream_t st) {
   IG2Params q;
   const int rc = fill(q, dz, Wq, dx, B * H * W, Cin, KH * KW * Cout, dx_cstride, H, W, Cout, Cout, Ho, Wo, KH, KW, stride, pad_h, pad_w);
   if (rc) return rc;
   q.gp.accumulate = accumulate;
-  if (Cin > 64) return launch_igemm2<128, 1, EpBf16Acc>(q, st);
-  return launch_igemm2<64, 1, EpBf16Acc>(q, st);
+  if (Cin > 64) return launch_igemm2<128, 1, EpBf16Acc>(q, variant, st);
+  return launch_igemm2<64, 1, EpBf16Acc>(q, variant, st);
 }
 
 // ---------------------------------------------------------------------------------------------- weight packing

@@ -158,7 +158,7 @@ class InceptionTrainer:
             self.moving_var[o:o + s.cout].copy_(p["moving_variance"])
         self._alloc()
         self._plan_backward()
-        pick = 2 if conv_core == "v2" else 1
+        pick = 2 if conv_core == "v2" else 1  # (the autotuner also considers 3 = the 128-row-tile variant of v2)
         self.core: Dict[str, Dict[str, int]] = {name: {"fwd": pick, "bwd": pick, "dw": pick} for name in g.convs}
         if self.async_lds:
             self._alloc_packs()
@@ -287,10 +287,10 @@ class InceptionTrainer:
         B, H, W, Cs = src.shape
         _, Ho, Wo, _ = self.act[op.dst].shape
         z = self.z[s.name]
-        if core == 2:
+        if core >= 2:  # 2 / 3 = async-LDS core with 256- / 128-row tiles
             rc = lib.dtf_conv_fwd_stats_v2(src.data_ptr(), self.Wp.data_ptr() + 2 * self.pack_off[s.name], z.data_ptr(),
                                            self._stats(s.name, 0), B, H, W, s.cin, Cs, s.cout, s.kh, s.kw, s.stride,
-                                           s.pad[0], s.pad[1], Ho, Wo, st)
+                                           s.pad[0], s.pad[1], Ho, Wo, core - 2, st)
         else:
             rc = lib.dtf_conv_fwd_stats(src.data_ptr(), self.param(s.name + "/conv2d_params").data_ptr(), z.data_ptr(),
                                         self._stats(s.name, 0), B, H, W, s.cin, Cs, s.cout, s.kh, s.kw, s.stride,
@@ -316,9 +316,10 @@ class InceptionTrainer:
         B, H, W, Cs = src.shape
         _, Ho, Wo, _ = self.act[op.dst].shape
         z, dx = self.z[s.name], self.dact[op.src]
-        if core == 2:
+        if core >= 2:
             rc = lib.dtf_conv_bwd_data_v2(z.data_ptr(), self.Wq.data_ptr() + 2 * self.pack_off[s.name], dx.data_ptr(), B, H, W,
-                                          s.cin, Cs, s.cout, s.kh, s.kw, s.stride, s.pad[0], s.pad[1], Ho, Wo, accumulate, st)
+                                          s.cin, Cs, s.cout, s.kh, s.kw, s.stride, s.pad[0], s.pad[1], Ho, Wo, accumulate,
+                                          core - 2, st)
         else:
             rc = lib.dtf_conv_bwd_data(z.data_ptr(), self.param(s.name + "/conv2d_params").data_ptr(), dx.data_ptr(), B, H, W,
                                        s.cin, Cs, s.cout, s.kh, s.kw, s.stride, s.pad[0], s.pad[1], Ho, Wo, accumulate, st)
@@ -350,13 +351,14 @@ class InceptionTrainer:
             src = x if op.src == "input" else self.act[op.src]
             name = op.conv.name
             res = {}
-            res["fwd"] = tuple(timed(lambda c=c: self._conv_fwd(op, src, c, st)) for c in (1, 2))
+            res["fwd"] = tuple(timed(lambda c=c: self._conv_fwd(op, src, c, st)) for c in (1, 2, 3))
             res["dw"] = tuple(timed(lambda c=c: self._conv_dw(op, src, c, st)) for c in (1, 2))
             if op.src != "input":
-                res["bwd"] = tuple(timed(lambda c=c: self._conv_bwd_data(op, src, c, 0, st)) for c in (1, 2))
+                res["bwd"] = tuple(timed(lambda c=c: self._conv_bwd_data(op, src, c, 0, st)) for c in (1, 2, 3))
             self.tuning[name] = res
-            for k, (t1, t2) in res.items():
-                self.core[name][k] = 2 if t2 < 0.97 * t1 else 1
+            for k, ts in res.items():
+                best = min(range(len(ts)), key=lambda i: ts[i])
+                self.core[name][k] = best + 1 if ts[best] < 0.97 * ts[0] else 1
         torch.cuda.synchronize()
         self.scratch.zero_()
         self.G.zero_()
@@ -367,9 +369,11 @@ class InceptionTrainer:
         out = []
         for k in ("fwd", "bwd", "dw"):
             rows = [r[k] for r in self.tuning.values() if k in r]
-            n2 = sum(1 for name, r in self.tuning.items() if k in r and self.core[name][k] == 2)
-            out.append("%s: v2 on %d/%d layers, v1 %.2f ms, v2 %.2f ms, chosen %.2f ms" % (
-                k, n2, len(rows), sum(a for a, _ in rows), sum(b for _, b in rows), sum(min(a, b) for a, b in rows)))
+            counts = [sum(1 for name, r in self.tuning.items() if k in r and self.core[name][k] == c + 1)
+                      for c in range(len(rows[0]))]
+            sums = [sum(r[c] for r in rows) for c in range(len(rows[0]))]
+            out.append("%s: layers per core %s, ms per core %s, chosen %.2f ms" % (
+                k, counts, ["%.2f" % v for v in sums], sum(min(r) for r in rows)))
         return "; ".join(out)
 
     def forward(self, x: torch.Tensor, training: bool = True) -> torch.Tensor:

@@ -113,9 +113,9 @@ def hip() -> C.CDLL:
         _sig(lib, "dtf_avgpool3x3_same_bwd", I, [P, I, P, I] + [I] * 5 + [P])
         _sig(lib, "dtf_global_avgpool_bwd", I, [P, P, I, I, I, P])
         _sig(lib, "dtf_igemm2_init", I, [])
-        _sig(lib, "dtf_conv_fwd_stats_v2", I, [P, P, P, P] + [I] * 13 + [P])
-        _sig(lib, "dtf_conv_bias_relu_v2", I, [P, P, P, P] + [I] * 15 + [P])
-        _sig(lib, "dtf_conv_bwd_data_v2", I, [P, P, P] + [I] * 14 + [P])
+        _sig(lib, "dtf_conv_fwd_stats_v2", I, [P, P, P, P] + [I] * 14 + [P])
+        _sig(lib, "dtf_conv_bias_relu_v2", I, [P, P, P, P] + [I] * 16 + [P])
+        _sig(lib, "dtf_conv_bwd_data_v2", I, [P, P, P] + [I] * 15 + [P])
         _sig(lib, "dtf_pack_conv_weights", I, [P, P, I, P, P, P])
         _sig(lib, "dtf_igemm2_dw_init", I, [])
         _sig(lib, "dtf_conv_dw_v2", I, [P, I, P, P] + [I] * 13 + [P])

@@ -175,7 +175,8 @@ def conv_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, 
                    in_channel_offset: int = 0, core: int = 1) -> torch.Tensor:
     """Inference conv (+folded BN bias, ReLU): bf16 NHWC in (optionally a channel slice), bf16 packed
     ``[Cout, KH*KW*Cin]`` weights, bf16 NHWC out written into ``out[..., off:off+Cout]`` (concat by slice write).
-    ``core``: 1 = register-staged GEMM core (gemm_core.h), 2 = async-LDS core (igemm2.hip; needs ``igemm2_init()``)."""
+    ``core``: 1 = register-staged GEMM core (gemm_core.h), 2 / 3 = async-LDS core with 256- / 128-row tiles (igemm2.hip;
+    needs ``igemm2_init()``)."""
     _chk(x, torch.bfloat16, "x")
     _chk(w_packed, torch.bfloat16, "w_packed")
     _chk(bias, torch.float32, "bias")
@@ -190,9 +191,13 @@ def conv_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, 
     assert out.shape[:3] == (B, Ho, Wo) and out_channel_offset + Cout <= out.shape[3]
     xp = x.data_ptr() + 2 * in_channel_offset
     op = out.data_ptr() + 2 * out_channel_offset
-    fn = native.hip().dtf_conv_bias_relu_v2 if core == 2 else native.hip().dtf_conv_bias_relu
-    native.check(fn(xp, w_packed.data_ptr(), bias.data_ptr(), op, B, H, W, Cin, Ctot, Cout, out.shape[3], KH, KW, stride,
-                    pad[0], pad[1], Ho, Wo, int(relu), _st()), "conv_bias_relu(core %d)" % core)
+    args = (xp, w_packed.data_ptr(), bias.data_ptr(), op, B, H, W, Cin, Ctot, Cout, out.shape[3], KH, KW, stride, pad[0], pad[1],
+            Ho, Wo, int(relu))
+    if core >= 2:  # 2 / 3: async-LDS core with 256- / 128-row tiles
+        rc = native.hip().dtf_conv_bias_relu_v2(*args, core - 2, _st())
+    else:
+        rc = native.hip().dtf_conv_bias_relu(*args, _st())
+    native.check(rc, "conv_bias_relu(core %d)" % core)
     return out
 
 

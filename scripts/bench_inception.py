@@ -28,4 +28,4 @@ dt = (time.perf_counter() - t0) / iters
 fl = iv3.graph_flops(net.graph) * B
 print(json.dumps({"metric": "inception_v3 bottleneck extraction", "batch": B, "ms_per_batch": round(dt * 1e3, 3),
                   "images_per_sec": round(B / dt, 1), "tflops": round(fl / dt / 1e12, 2), "hipgraph": use_graph,
-                  "conv_core": core, "v2_layers": sum(1 for v in net._core.get(B, {}).values() if v == 2)}))
+                  "conv_core": core, "v2_layers": sum(1 for v in net._core.get(B, {}).values() if v >= 2)}))

@@ -105,23 +105,24 @@ def test_async_lds_igemm_matches_reference(geom):
     chk(lib.dtf_pack_conv_weights(w.data_ptr(), dbuf.data_ptr(), 1, Wp.data_ptr(), Wq.data_ptr(), _st()), "pack")
     assert torch.equal(Wp, w.permute(3, 0, 1, 2).reshape(Cout, K).to(BF))
     assert torch.equal(Wq, w.permute(2, 0, 1, 3).reshape(Cin, KH * KW * Cout).to(BF))
-    z = torch.empty(B, Ho, Wo, Cout, dtype=BF, device="cuda")
-    stats = torch.zeros(16, 2, Cout, device="cuda")
-    chk(lib.dtf_conv_fwd_stats_v2(xfull.data_ptr() + 2 * 8, Wp.data_ptr(), z.data_ptr(), stats.data_ptr(), B, H, W, Cin, Ctot, Cout,
-                                  KH, KW, s, ph, pw, Ho, Wo, _st()), "fwd2")
     x = xfull[..., 8:8 + Cin].float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
     wt = _r(w).permute(3, 2, 0, 1).contiguous()
     ref = F.conv2d(x, wt, stride=s, padding=(ph, pw))
-    assert _relerr(z.permute(0, 3, 1, 2), ref) < 1e-2
-    zf = z.float()
-    st_ = stats.sum(0)
-    assert _relerr(st_[0], zf.sum((0, 1, 2))) < 1e-4 * max(1.0, (B * Ho * Wo) ** 0.5) and _relerr(st_[1], (zf * zf).sum((0, 1, 2))) < 1e-4
     bias = torch.randn(Cout, device="cuda")
-    ybuf = torch.zeros(B, Ho, Wo, Cout + 8, dtype=BF, device="cuda")
-    chk(lib.dtf_conv_bias_relu_v2(xfull.data_ptr() + 2 * 8, Wp.data_ptr(), bias.data_ptr(), ybuf.data_ptr() + 2 * 8, B, H, W, Cin,
-                                  Ctot, Cout, Cout + 8, KH, KW, s, ph, pw, Ho, Wo, 1, _st()), "inf2")
-    assert _relerr(ybuf[..., 8:].permute(0, 3, 1, 2), F.relu(ref + bias.view(1, -1, 1, 1))) < 1e-2
-    assert float(ybuf[..., :8].float().abs().max()) == 0.0
+    for variant in (0, 1):  # 256-row / 128-row tiles
+        z = torch.empty(B, Ho, Wo, Cout, dtype=BF, device="cuda")
+        stats = torch.zeros(16, 2, Cout, device="cuda")
+        chk(lib.dtf_conv_fwd_stats_v2(xfull.data_ptr() + 2 * 8, Wp.data_ptr(), z.data_ptr(), stats.data_ptr(), B, H, W, Cin, Ctot,
+                                      Cout, KH, KW, s, ph, pw, Ho, Wo, variant, _st()), "fwd2")
+        assert _relerr(z.permute(0, 3, 1, 2), ref) < 1e-2, variant
+        zf = z.float()
+        st_ = stats.sum(0)
+        assert _relerr(st_[0], zf.sum((0, 1, 2))) < 1e-4 * max(1.0, (B * Ho * Wo) ** 0.5) and _relerr(st_[1], (zf * zf).sum((0, 1, 2))) < 1e-4
+        ybuf = torch.zeros(B, Ho, Wo, Cout + 8, dtype=BF, device="cuda")
+        chk(lib.dtf_conv_bias_relu_v2(xfull.data_ptr() + 2 * 8, Wp.data_ptr(), bias.data_ptr(), ybuf.data_ptr() + 2 * 8, B, H, W, Cin,
+                                      Ctot, Cout, Cout + 8, KH, KW, s, ph, pw, Ho, Wo, 1, variant, _st()), "inf2")
+        assert _relerr(ybuf[..., 8:].permute(0, 3, 1, 2), F.relu(ref + bias.view(1, -1, 1, 1))) < 1e-2, variant
+        assert float(ybuf[..., :8].float().abs().max()) == 0.0
     dz = torch.randn(B, Ho, Wo, Cout, device="cuda").to(BF)
     wl = wt.clone().requires_grad_(True)
     (gw,) = torch.autograd.grad(F.conv2d(x.detach(), wl, stride=s, padding=(ph, pw)), wl, dz.float().permute(0, 3, 1, 2))
@@ -131,12 +132,13 @@ def test_async_lds_igemm_matches_reference(geom):
                                Ho, Wo, splits, _st()), "dw2")
         assert _relerr(dW, gw.permute(2, 3, 1, 0)) < 5e-3, splits
     (gx,) = torch.autograd.grad(ref, x, dz.float().permute(0, 3, 1, 2))
-    dxfull = torch.full((B, H, W, Ctot), 7.0, dtype=BF, device="cuda")
-    for acc in (0, 1):
-        chk(lib.dtf_conv_bwd_data_v2(dz.data_ptr(), Wq.data_ptr(), dxfull.data_ptr() + 2 * 8, B, H, W, Cin, Ctot, Cout, KH, KW, s,
-                                     ph, pw, Ho, Wo, acc, _st()), "bwd2")
-        assert _relerr(dxfull[..., 8:8 + Cin].float(), gx.permute(0, 2, 3, 1) * (acc + 1)) < 2e-2, acc
-    assert float((dxfull[..., :8].float() - 7.0).abs().max()) == 0.0 and float((dxfull[..., 8 + Cin:].float() - 7.0).abs().max()) == 0.0
+    for variant in (0, 1):
+        dxfull = torch.full((B, H, W, Ctot), 7.0, dtype=BF, device="cuda")
+        for acc in (0, 1):
+            chk(lib.dtf_conv_bwd_data_v2(dz.data_ptr(), Wq.data_ptr(), dxfull.data_ptr() + 2 * 8, B, H, W, Cin, Ctot, Cout, KH, KW,
+                                         s, ph, pw, Ho, Wo, acc, variant, _st()), "bwd2")
+            assert _relerr(dxfull[..., 8:8 + Cin].float(), gx.permute(0, 2, 3, 1) * (acc + 1)) < 2e-2, (acc, variant)
+        assert float((dxfull[..., :8].float() - 7.0).abs().max()) == 0.0 and float((dxfull[..., 8 + Cin:].float() - 7.0).abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("M,C", [(3 * 17 * 17, 192), (2 * 35 * 35, 48), (5 * 8 * 8, 448), (700, 32)])
