@@ -347,10 +347,12 @@ struct DW2Params {
   const uint16_t* zeros;
   ConvGeom g;  // H, W, Cin, cstride (of x), Ho, Wo, KH, KW, stride, pad
   int Cout, K, kchunk, nit, nct, taps;
+  int rw, rh, qh;  // 64 positions = (qh*Ho + rh) rows + rw columns
 };
 
 template <int BT>
 __global__ __launch_bounds__(256) void dw2_kernel(const DW2Params q) {
+#if defined(__HIP_DEVICE_COMPILE__)
   constexpr int KP = 64, S = 3;
   constexpr int ROWB = BT * 2, CH = ROWB / 16, RPI = 64 / CH;
   constexpr int TILE_BYTES = KP * ROWB, STAGE = 2 * TILE_BYTES;
@@ -374,21 +376,45 @@ __global__ __launch_bounds__(256) void dw2_kernel(const DW2Params q) {
   const int cofs = (pch ^ (BT == 128 ? 4 * (lrow & 3) : 4 * ((lrow >> 1) & 1))) * 8;
   const bool xc_ok = ci0 + cofs < g.Cin, zc_ok = co0 + cofs < q.Cout;
   const int npos = g.Ho * g.Wo;
+  // Issuing a K-step must stay well below the MFMA time of the step (one wave per SIMD): the (image, row, column) of
+  // each of this lane's positions is decoded with real divisions ONCE and then advanced by 64 positions per step with
+  // carries only (64 = qw*Wo + rw, qw = qh*Ho + rh, host-computed); loads go through buffer descriptors whose range
+  // check returns zeros for the out-of-range offset given to padding taps / tile overhang / positions >= kend.
+  const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(q.x), 0, 0x80000000, 0x00020000);
+  const auto rsrcZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(q.dz), 0, 0x80000000, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  int pb[PER], ph[PER], pw[PER], ppos[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int pos = kbeg + (wave * PER + i) * RPI + lrow;
+    ppos[i] = pos;
+    pb[i] = pos / npos;
+    const int rem = pos - pb[i] * npos;
+    ph[i] = rem / g.Wo;
+    pw[i] = rem - ph[i] * g.Wo;
+  }
+  const unsigned xcol = (unsigned)(ci0 + cofs) * 2u, zcol = (unsigned)(co0 + cofs) * 2u;
 
-  auto issue = [&](int step, int sb) {
+  // loads of the step the decoded positions currently stand at, then advance them by KP
+  auto issue = [&](int sb) {
     unsigned char* xb = smem + sb * STAGE + wave * PER * 1024;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int pos = kbeg + step * KP + (wave * PER + i) * RPI + lrow;
-      const bool ok = pos < kend;
-      const int b = pos / npos, rem = pos - b * npos;
-      const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
-      const int hi = ho * g.stride + dy, wi = wo * g.stride + dx;
+      const bool ok = ppos[i] < kend;
+      const int hi = ph[i] * g.stride + dy, wi = pw[i] * g.stride + dx;
       const bool okx = ok && xc_ok && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-      const uint16_t* xs = okx ? q.x + ((long)(b * g.H + hi) * g.W + wi) * g.cstride + ci0 + cofs : q.zeros;
-      const uint16_t* zs = (ok && zc_ok) ? q.dz + (long)pos * q.Cout + co0 + cofs : q.zeros;
-      __builtin_amdgcn_global_load_lds(xs, (lds_ptr_t)(xb + i * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(zs, (lds_ptr_t)(xb + TILE_BYTES + i * 1024), 16, 0, 0);
+      const unsigned xo = okx ? (unsigned)(((pb[i] * g.H + hi) * g.W + wi) * g.cstride) * 2u + xcol : OOB;
+      const unsigned zo = (ok && zc_ok) ? (unsigned)ppos[i] * (unsigned)q.Cout * 2u + zcol : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_ptr_t)(xb + i * 1024), 16, xo, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcZ, (lds_ptr_t)(xb + TILE_BYTES + i * 1024), 16, zo, 0, 0, 0);
+      ppos[i] += KP;
+      pw[i] += q.rw;
+      const int c1 = pw[i] >= g.Wo ? 1 : 0;
+      pw[i] -= c1 * g.Wo;
+      ph[i] += q.rh + c1;
+      const int c2 = ph[i] >= g.Ho ? 1 : 0;
+      ph[i] -= c2 * g.Ho;
+      pb[i] += q.qh + c2;
     }
   };
 
@@ -401,8 +427,8 @@ __global__ __launch_bounds__(256) void dw2_kernel(const DW2Params q) {
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
   const int nsteps = (kend - kbeg + KP - 1) / KP;
-  issue(0, 0);
-  issue(1, 1);
+  issue(0);
+  issue(1);
   const int wm = wave >> 1, wn = wave & 1;
   // transposing-read lane roles: 16-lane group gq, row q and column quad p inside the group
   const int gq = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
@@ -421,7 +447,7 @@ __global__ __launch_bounds__(256) void dw2_kernel(const DW2Params q) {
     wait_vmcnt<LPS>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    issue(t + 2, (t + 2) % S);
+    issue((t + 2) % S);
     const unsigned char* st = smem + (t % S) * STAGE;
 #pragma unroll
     for (int k16 = 0; k16 < KP / 16; ++k16) {
@@ -459,6 +485,7 @@ __global__ __launch_bounds__(256) void dw2_kernel(const DW2Params q) {
         if (ci < g.Cin && co < q.Cout) atomicAdd(&q.dW[((long)tap * g.Cin + ci) * q.Cout + co], acc[a][b][i]);
       }
     }
+#endif
 }
 
 template <int BT>
@@ -481,6 +508,10 @@ DTF_API int dtf_conv_dw_v2(const void* x, int in_cstride, const void* dz, float*
   q.g.H = H; q.g.W = W; q.g.Cin = Cin; q.g.cstride = in_cstride; q.g.Ho = Ho; q.g.Wo = Wo;
   q.g.KH = KH; q.g.KW = KW; q.g.stride = stride; q.g.pad_h = pad_h; q.g.pad_w = pad_w;
   q.Cout = Cout; q.K = B * Ho * Wo; q.taps = KH * KW;
+  q.rw = 64 % Wo;
+  q.rh = (64 / Wo) % Ho;
+  q.qh = (64 / Wo) / Ho;
+  if ((long)B * H * W * in_cstride * 2 >= 0x7fffffffL || (long)q.K * Cout * 2 >= 0x7fffffffL) return ERR_SHAPE;
   const int ksteps = dtf_cdiv(q.K, 64);
   q.kchunk = dtf_cdiv(ksteps, splits) * 64;
   const int nz = dtf_cdiv(q.K, q.kchunk);
