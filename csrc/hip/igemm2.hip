@@ -201,12 +201,18 @@ int launch_one(IG2Params& q, hipStream_t st) {
   return 0;
 }
 
-// variant 0: 256-row tiles, 3 stages; variant 1: 128-row tiles (3 stages at BN = 64, 2 at BN = 128): two workgroups / CU
+// variant bit 0: 128-row tiles (3 stages at BN = 64, 2 at BN = 128: two workgroups per CU) instead of 256-row tiles;
+// variant bit 1: 64-column tiles even when N > 64 (N = 160 or 192 fills 64-wide tiles far better than 128-wide ones)
 template <int BN, int MODE, class EP>
 int launch_igemm2(IG2Params& q, int variant, hipStream_t st) {
-  if (variant == 1) return launch_one<128, BN, (BN == 64 ? 3 : 2), MODE, EP>(q, st);
-  if (variant != 0) return ERR_SHAPE;
+  if (variant & 1) return launch_one<128, BN, (BN == 64 ? 3 : 2), MODE, EP>(q, st);
   return launch_one<256, BN, 3, MODE, EP>(q, st);
+}
+template <int MODE, class EP>
+int launch_igemm2_n(IG2Params& q, int variant, hipStream_t st) {
+  if (variant < 0 || variant > 3) return ERR_SHAPE;
+  if (q.gp.N > 64 && !(variant & 2)) return launch_igemm2<128, MODE, EP>(q, variant, st);
+  return launch_igemm2<64, MODE, EP>(q, variant, st);
 }
 
 template <int BM, int BN, int S, int MODE, class EP>
@@ -264,8 +270,7 @@ DTF_API int dtf_conv_fwd_stats_v2(const void* x, const void* Wp, void* z, float*
   const int rc = fill(q, x, Wp, z, B * Ho * Wo, Cout, KH * KW * Cin, Cout, H, W, Cin, in_cstride, Ho, Wo, KH, KW, stride, pad_h, pad_w);
   if (rc) return rc;
   q.gp.aux_out = stats;
-  if (Cout > 64) return launch_igemm2<128, 0, EpBf16Stats>(q, variant, st);
-  return launch_igemm2<64, 0, EpBf16Stats>(q, variant, st);
+  return launch_igemm2_n<0, EpBf16Stats>(q, variant, st);
 }
 
 // Inference conv: out = bf16(relu(conv(x, Wp) + bias)) written at channel stride out_cstride (concat slice)
@@ -277,8 +282,7 @@ DTF_API int dtf_conv_bias_relu_v2(const void* x, const void* Wp, const float* bi
   if (rc) return rc;
   q.gp.bias = bias;
   q.gp.relu = relu;
-  if (Cout > 64) return launch_igemm2<128, 0, EpBiasReluBf16>(q, variant, st);
-  return launch_igemm2<64, 0, EpBiasReluBf16>(q, variant, st);
+  return launch_igemm2_n<0, EpBiasReluBf16>(q, variant, st);
 }
 
 // dx[B,H,W,Cin] (bf16 at channel stride dx_cstride) (+)= conv^T(dz, Wq); Wq = bf16 [Cin][KH*KW*Cout]
@@ -289,8 +293,7 @@ DTF_API int dtf_conv_bwd_data_v2(const void* dz, const void* Wq, void* dx, int B
   const int rc = fill(q, dz, Wq, dx, B * H * W, Cin, KH * KW * Cout, dx_cstride, H, W, Cout, Cout, Ho, Wo, KH, KW, stride, pad_h, pad_w);
   if (rc) return rc;
   q.gp.accumulate = accumulate;
-  if (Cin > 64) return launch_igemm2<128, 1, EpBf16Acc>(q, variant, st);
-  return launch_igemm2<64, 1, EpBf16Acc>(q, variant, st);
+  return launch_igemm2_n<1, EpBf16Acc>(q, variant, st);
 }
 
 // ---------------------------------------------------------------------------------------------- weight packing
@@ -498,7 +501,8 @@ bool raise_dw_lds_limit() {
 DTF_API int dtf_igemm2_dw_init() { return (raise_dw_lds_limit<64>() && raise_dw_lds_limit<128>()) ? 0 : -3; }
 
 DTF_API int dtf_conv_dw_v2(const void* x, int in_cstride, const void* dz, float* dW, int B, int H, int W, int Cin, int Cout,
-                           int KH, int KW, int stride, int pad_h, int pad_w, int Ho, int Wo, int splits, hipStream_t st) {
+                           int KH, int KW, int stride, int pad_h, int pad_w, int Ho, int Wo, int splits, int variant,
+                           hipStream_t st) {
   if (!g_zero_page) return -2;
   if (B <= 0 || Cin % 8 || Cout % 8 || in_cstride % 8 || splits < 1 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || stride < 1)
     return ERR_SHAPE;
@@ -515,7 +519,7 @@ DTF_API int dtf_conv_dw_v2(const void* x, int in_cstride, const void* dz, float*
   const int ksteps = dtf_cdiv(q.K, 64);
   q.kchunk = dtf_cdiv(ksteps, splits) * 64;
   const int nz = dtf_cdiv(q.K, q.kchunk);
-  const bool big = Cin > 64 && Cout > 64;
+  const bool big = Cin > 64 && Cout > 64 && !(variant & 1);  // variant 1: 64-wide tiles regardless
   const int BT = big ? 128 : 64;
   q.nit = dtf_cdiv(Cin, BT);
   q.nct = dtf_cdiv(Cout, BT);

@@ -287,7 +287,7 @@ class InceptionTrainer:
         B, H, W, Cs = src.shape
         _, Ho, Wo, _ = self.act[op.dst].shape
         z = self.z[s.name]
-        if core >= 2:  # 2 / 3 = async-LDS core with 256- / 128-row tiles
+        if core >= 2:  # 2..5 = async-LDS core, variant = core - 2 (bit 0: 128-row tiles, bit 1: 64-column tiles)
             rc = lib.dtf_conv_fwd_stats_v2(src.data_ptr(), self.Wp.data_ptr() + 2 * self.pack_off[s.name], z.data_ptr(),
                                            self._stats(s.name, 0), B, H, W, s.cin, Cs, s.cout, s.kh, s.kw, s.stride,
                                            s.pad[0], s.pad[1], Ho, Wo, core - 2, st)
@@ -302,9 +302,9 @@ class InceptionTrainer:
         B, H, W, Cs = src.shape
         _, Ho, Wo, _ = self.act[op.dst].shape
         z, dW = self.z[s.name], self.grad(s.name + "/conv2d_params")
-        if core == 2:
+        if core >= 2:  # 2 = 128-wide tiles when both channel counts exceed 64, 3 = 64-wide tiles
             rc = lib.dtf_conv_dw_v2(src.data_ptr(), Cs, z.data_ptr(), dW.data_ptr(), B, H, W, s.cin, s.cout, s.kh, s.kw,
-                                    s.stride, s.pad[0], s.pad[1], Ho, Wo, self._dw2_splits(s, B * Ho * Wo), st)
+                                    s.stride, s.pad[0], s.pad[1], Ho, Wo, self._dw2_splits(s, B * Ho * Wo, core - 2), core - 2, st)
         else:
             rc = lib.dtf_conv_dw_general(src.data_ptr(), Cs, z.data_ptr(), dW.data_ptr(), B, H, W, s.cin, s.cout, s.kh, s.kw,
                                          s.stride, s.pad[0], s.pad[1], Ho, Wo,
@@ -344,21 +344,25 @@ class InceptionTrainer:
                 best = min(best, ev[0].elapsed_time(ev[1]))
             return best
 
-        self.tuning: Dict[str, Dict[str, Tuple[float, float]]] = {}
+        self.tuning: Dict[str, Dict[str, Dict[int, float]]] = {}
         for op in self.graph.ops:
             if op.kind != "conv":
                 continue
             src = x if op.src == "input" else self.act[op.src]
             name = op.conv.name
             res = {}
-            res["fwd"] = tuple(timed(lambda c=c: self._conv_fwd(op, src, c, st)) for c in (1, 2, 3))
-            res["dw"] = tuple(timed(lambda c=c: self._conv_dw(op, src, c, st)) for c in (1, 2))
+            s_ = op.conv
+            wide_n = (2, 3, 4, 5) if s_.cout > 64 else (2, 3)  # the 64-column variants only differ when N > 64
+            wide_k = (2, 3, 4, 5) if s_.cin > 64 else (2, 3)
+            res["fwd"] = {c: timed(lambda c=c: self._conv_fwd(op, src, c, st)) for c in (1,) + wide_n}
+            res["dw"] = {c: timed(lambda c=c: self._conv_dw(op, src, c, st))
+                         for c in ((1, 2, 3) if (s_.cin > 64 and s_.cout > 64) else (1, 2))}
             if op.src != "input":
-                res["bwd"] = tuple(timed(lambda c=c: self._conv_bwd_data(op, src, c, 0, st)) for c in (1, 2, 3))
+                res["bwd"] = {c: timed(lambda c=c: self._conv_bwd_data(op, src, c, 0, st)) for c in (1,) + wide_k}
             self.tuning[name] = res
             for k, ts in res.items():
-                best = min(range(len(ts)), key=lambda i: ts[i])
-                self.core[name][k] = best + 1 if ts[best] < 0.97 * ts[0] else 1
+                best = min(ts, key=ts.get)
+                self.core[name][k] = best if ts[best] < 0.97 * ts[1] else 1
         torch.cuda.synchronize()
         self.scratch.zero_()
         self.G.zero_()
@@ -368,12 +372,13 @@ class InceptionTrainer:
             return "conv core: %s everywhere" % self.conv_core
         out = []
         for k in ("fwd", "bwd", "dw"):
-            rows = [r[k] for r in self.tuning.values() if k in r]
-            counts = [sum(1 for name, r in self.tuning.items() if k in r and self.core[name][k] == c + 1)
-                      for c in range(len(rows[0]))]
-            sums = [sum(r[c] for r in rows) for c in range(len(rows[0]))]
-            out.append("%s: layers per core %s, ms per core %s, chosen %.2f ms" % (
-                k, counts, ["%.2f" % v for v in sums], sum(min(r) for r in rows)))
+            rows = {name: r[k] for name, r in self.tuning.items() if k in r}
+            counts: Dict[int, int] = {}
+            for name in rows:
+                counts[self.core[name][k]] = counts.get(self.core[name][k], 0) + 1
+            out.append("%s: layers per core %s, core 1 everywhere %.2f ms, chosen %.2f ms" % (
+                k, dict(sorted(counts.items())), sum(r[1] for r in rows.values()),
+                sum(r[self.core[name][k]] for name, r in rows.items())))
         return "; ".join(out)
 
     def forward(self, x: torch.Tensor, training: bool = True) -> torch.Tensor:
@@ -429,15 +434,17 @@ class InceptionTrainer:
         return max(1, min(want, npos // 512 if npos >= 512 else 1))
 
     @staticmethod
-    def _dw2_splits(s, npos: int) -> int:
+    def _dw2_splits(s, npos: int, variant: int = 0) -> int:
         """Split-K factor of the filter-gradient kernel.  Every split adds its whole tile to dW with fp32 atomics, and
         those — not the MFMAs — bound the kernel (measured: 1024 workgroups x 16K atomics = 80 us per conv), so use the
         fewest splits that still put one resident workgroup on every CU (96 KB of LDS: one 128-tile workgroup per CU,
         three 64-tile ones)."""
-        bt = 128 if (s.cin > 64 and s.cout > 64) else 64
+        bt = 128 if (s.cin > 64 and s.cout > 64 and not variant) else 64
         tiles = s.kh * s.kw * ((s.cin + bt - 1) // bt) * ((s.cout + bt - 1) // bt)
         target = int(os.environ.get("DTF_DW_BLOCKS", "0")) or (256 if bt == 128 else 768)
-        return max(1, min((target + tiles - 1) // tiles, npos // 256 if npos >= 256 else 1))
+        # round DOWN: one workgroup more than fits at once costs a whole extra round (measured: 280 workgroups of a
+        # 256-slot grid took 2 x 37 us)
+        return max(1, min(target // tiles, npos // 256 if npos >= 256 else 1))
 
     def backward(self, on_conv_done=None) -> None:
         """Runs the backward program; ``on_conv_done(name)`` is called after the kernels that finalise conv ``name``'s

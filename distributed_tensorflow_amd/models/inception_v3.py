@@ -319,7 +319,7 @@ class InceptionV3:
             src = x if op.src == "input" else bufs[op.src]
             wp, b = self.packed(s.name)
             t = {}
-            for core in (1, 2, 3):
+            for core in ((1, 2, 3, 4, 5) if s.cout > 64 else (1, 2, 3)):
                 best = float("inf")
                 for rep in range(4):
                     ev0.record()

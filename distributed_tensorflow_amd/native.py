@@ -118,7 +118,7 @@ def hip() -> C.CDLL:
         _sig(lib, "dtf_conv_bwd_data_v2", I, [P, P, P] + [I] * 15 + [P])
         _sig(lib, "dtf_pack_conv_weights", I, [P, P, I, P, P, P])
         _sig(lib, "dtf_igemm2_dw_init", I, [])
-        _sig(lib, "dtf_conv_dw_v2", I, [P, I, P, P] + [I] * 13 + [P])
+        _sig(lib, "dtf_conv_dw_v2", I, [P, I, P, P] + [I] * 14 + [P])
         _sig(lib, "dtf_conv2_bwd_lds_init", I, [])
         _sig(lib, "dtf_conv2_bwd_lds", I, [P, P, P, P, P, P, P, P, I, I, P])
         _sig(lib, "dtf_conv_bias_relu_pool", I, [P, P, P, P, P, I, I, I, I, I, I, I, P])

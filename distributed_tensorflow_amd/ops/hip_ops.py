@@ -175,7 +175,7 @@ def conv_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, 
                    in_channel_offset: int = 0, core: int = 1) -> torch.Tensor:
     """Inference conv (+folded BN bias, ReLU): bf16 NHWC in (optionally a channel slice), bf16 packed
     ``[Cout, KH*KW*Cin]`` weights, bf16 NHWC out written into ``out[..., off:off+Cout]`` (concat by slice write).
-    ``core``: 1 = register-staged GEMM core (gemm_core.h), 2 / 3 = async-LDS core with 256- / 128-row tiles (igemm2.hip;
+    ``core``: 1 = register-staged GEMM core (gemm_core.h), 2..5 = async-LDS core variants (igemm2.hip;
     needs ``igemm2_init()``)."""
     _chk(x, torch.bfloat16, "x")
     _chk(w_packed, torch.bfloat16, "w_packed")
@@ -193,7 +193,7 @@ def conv_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, 
     op = out.data_ptr() + 2 * out_channel_offset
     args = (xp, w_packed.data_ptr(), bias.data_ptr(), op, B, H, W, Cin, Ctot, Cout, out.shape[3], KH, KW, stride, pad[0], pad[1],
             Ho, Wo, int(relu))
-    if core >= 2:  # 2 / 3: async-LDS core with 256- / 128-row tiles
+    if core >= 2:  # async-LDS core, variant = core - 2 (bit 0: 128-row tiles, bit 1: 64-column tiles)
         rc = native.hip().dtf_conv_bias_relu_v2(*args, core - 2, _st())
     else:
         rc = native.hip().dtf_conv_bias_relu(*args, _st())

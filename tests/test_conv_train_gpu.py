@@ -109,7 +109,7 @@ def test_async_lds_igemm_matches_reference(geom):
     wt = _r(w).permute(3, 2, 0, 1).contiguous()
     ref = F.conv2d(x, wt, stride=s, padding=(ph, pw))
     bias = torch.randn(Cout, device="cuda")
-    for variant in (0, 1):  # 256-row / 128-row tiles
+    for variant in (0, 1, 2, 3):  # bit 0: 128-row tiles, bit 1: 64-column tiles
         z = torch.empty(B, Ho, Wo, Cout, dtype=BF, device="cuda")
         stats = torch.zeros(16, 2, Cout, device="cuda")
         chk(lib.dtf_conv_fwd_stats_v2(xfull.data_ptr() + 2 * 8, Wp.data_ptr(), z.data_ptr(), stats.data_ptr(), B, H, W, Cin, Ctot,
@@ -126,13 +126,13 @@ def test_async_lds_igemm_matches_reference(geom):
     dz = torch.randn(B, Ho, Wo, Cout, device="cuda").to(BF)
     wl = wt.clone().requires_grad_(True)
     (gw,) = torch.autograd.grad(F.conv2d(x.detach(), wl, stride=s, padding=(ph, pw)), wl, dz.float().permute(0, 3, 1, 2))
-    for splits in (1, 7):
+    for splits, variant in ((1, 0), (7, 0), (3, 1)):
         dW = torch.zeros(KH, KW, Cin, Cout, device="cuda")
         chk(lib.dtf_conv_dw_v2(xfull.data_ptr() + 2 * 8, Ctot, dz.data_ptr(), dW.data_ptr(), B, H, W, Cin, Cout, KH, KW, s, ph, pw,
-                               Ho, Wo, splits, _st()), "dw2")
-        assert _relerr(dW, gw.permute(2, 3, 1, 0)) < 5e-3, splits
+                               Ho, Wo, splits, variant, _st()), "dw2")
+        assert _relerr(dW, gw.permute(2, 3, 1, 0)) < 5e-3, (splits, variant)
     (gx,) = torch.autograd.grad(ref, x, dz.float().permute(0, 3, 1, 2))
-    for variant in (0, 1):
+    for variant in (0, 1, 2, 3):
         dxfull = torch.full((B, H, W, Ctot), 7.0, dtype=BF, device="cuda")
         for acc in (0, 1):
             chk(lib.dtf_conv_bwd_data_v2(dz.data_ptr(), Wq.data_ptr(), dxfull.data_ptr() + 2 * 8, B, H, W, Cin, Ctot, Cout, KH, KW,
