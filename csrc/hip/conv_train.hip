@@ -168,6 +168,70 @@ DTF_API int dtf_bn_relu_fwd(const void* z, const float* bn, void* y, long M, int
   return 0;
 }
 
+// Finalize + normalise + ReLU in one launch (saves the 94 one-workgroup finalize launches of a step): every workgroup
+// folds the DTF_STAT_SLOTS statistic replicas into LDS scale/shift itself (2C x 16 L2-resident floats); workgroup 0
+// also stores bn[4][C] for the backward, updates the moving statistics and clears `stats_prev`, the replica set of the
+// previous step (the two sets alternate, so no workgroup of this launch reads it).
+__global__ __launch_bounds__(256) void bn_finalize_relu_fwd_kernel(const float* __restrict__ stats, float* __restrict__ stats_prev,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float* __restrict__ mmean, float* __restrict__ mvar,
+                                                                   float* __restrict__ bn, const uint16_t* __restrict__ z,
+                                                                   uint16_t* __restrict__ y, long M, int C, int y_cs,
+                                                                   float inv_count, float eps, float momentum) {
+  extern __shared__ float sm[];  // scale[C], shift[C]
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < DTF_STAT_SLOTS; ++k) {
+      s += stats[(2 * k) * C + c];
+      ss += stats[(2 * k + 1) * C + c];
+    }
+    const float mean = s * inv_count;
+    const float var = fmaxf(ss * inv_count - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    const float scale = gamma[c] * rstd, shift = beta[c] - mean * scale;
+    sm[c] = scale;
+    sm[C + c] = shift;
+    if (blockIdx.x == 0) {
+      bn[c] = mean;
+      bn[C + c] = rstd;
+      bn[2 * C + c] = scale;
+      bn[3 * C + c] = shift;
+      if (mmean) {
+        mmean[c] = momentum * mmean[c] + (1.f - momentum) * mean;
+        mvar[c] = momentum * mvar[c] + (1.f - momentum) * var;
+      }
+      if (stats_prev)
+#pragma unroll
+        for (int k = 0; k < 2 * DTF_STAT_SLOTS; ++k) stats_prev[k * C + c] = 0.f;
+    }
+  }
+  __syncthreads();
+  const int c8n = C >> 3;
+  const long total = M * c8n;
+  for (long gi = (long)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (long)gridDim.x * 256) {
+    const int c0 = (int)(gi % c8n) * 8;
+    const long m = gi / c8n;
+    float f[8];
+    unpack8(*reinterpret_cast<const uint4*>(z + m * C + c0), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * sm[c0 + j] + sm[C + c0 + j], 0.f);
+    *reinterpret_cast<uint4*>(y + m * y_cs + c0) = pack8(f);
+  }
+}
+
+DTF_API int dtf_bn_finalize_relu_fwd(const float* stats, float* stats_prev, const float* gamma, const float* beta,
+                                     float* moving_mean, float* moving_var, float* bn, const void* z, void* y, long M, int C,
+                                     int y_cstride, float eps, float momentum, hipStream_t st) {
+  if (M <= 0 || C <= 0 || C % 8 || C > 2048 || y_cstride % 8) return ERR_SHAPE;
+  const int blocks = ew_blocks(M * (C / 8) / 4, 1024);  // >= 4 elements-of-8 per lane amortise the fold
+  hipLaunchKernelGGL(bn_finalize_relu_fwd_kernel, dim3(blocks), dim3(256), 2 * C * sizeof(float), st, stats, stats_prev, gamma,
+                     beta, moving_mean, moving_var, bn, (const uint16_t*)z, (uint16_t*)y, M, C, y_cstride, 1.f / (float)M, eps,
+                     momentum);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
 // slots[DTF_STAT_SLOTS][2][C] += (sum g, sum g*xhat) with g = dy * (y > 0), xhat = (z - mean) * rstd.
 // The ReLU mask is recomputed from z (y > 0  <=>  z*scale + shift > 0) instead of re-reading the stored activation:
 // one third less traffic in both backward passes.

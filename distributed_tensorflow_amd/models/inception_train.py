@@ -156,6 +156,7 @@ class InceptionTrainer:
             o = self.stat_off[name]
             self.moving_mean[o:o + s.cout].copy_(p["moving_mean"])
             self.moving_var[o:o + s.cout].copy_(p["moving_variance"])
+        self._fwd_set = 0
         self._alloc()
         self._plan_backward()
         pick = 2 if conv_core == "v2" else 1  # (the autotuner also considers 3 = the 128-row-tile variant of v2)
@@ -243,9 +244,10 @@ class InceptionTrainer:
                 self.argmax[i] = torch.empty(B, ho, wo, op.channels, dtype=torch.uint8, device=dev)
         # statistic accumulators: STAT_SLOTS replicas of [fwd sum|sumsq] and of [bwd s1|s2] per conv (their consumer
         # kernels re-zero them, so no per-step memset), the folded backward sums, and one ticket per conv
-        # (block 0 = forward; blocks 1 and 2 = the two alternating backward sets)
-        self.scratch = torch.zeros(3 * STAT_SLOTS * 2 * self.stat_total, dtype=torch.float32, device=dev)
+        # (blocks 0 and 3 = the two alternating forward sets; blocks 1 and 2 = the backward ones)
+        self.scratch = torch.zeros(4 * STAT_SLOTS * 2 * self.stat_total, dtype=torch.float32, device=dev)
         self._bwd_parity = 0
+        self._fwd_parity = 0
         self.bn = torch.zeros(4 * self.stat_total, dtype=torch.float32, device=dev)  # mean, rstd, scale, shift per conv
         self.feat = torch.zeros(B, BOTTLENECK_TENSOR_SIZE, dtype=torch.float32, device=dev)
         self.dfeat = torch.zeros_like(self.feat)
@@ -274,8 +276,8 @@ class InceptionTrainer:
 
     # ------------------------------------------------------------------ forward / backward
     def _stats(self, name: str, which: int) -> int:
-        """Device pointer of the [STAT_SLOTS][2][Cout] accumulator block of conv ``name`` (0 = forward statistics,
-        1 / 2 = the backward sums of even / odd steps)."""
+        """Device pointer of the [STAT_SLOTS][2][Cout] accumulator block of conv ``name`` (0 / 3 = forward statistics of
+        even / odd steps, 1 / 2 = the backward sums of even / odd steps)."""
         return self.scratch.data_ptr() + 4 * STAT_SLOTS * 2 * (self.stat_total * which + self.stat_off[name])
 
     def _bn_ptr(self, name: str) -> int:
@@ -289,11 +291,11 @@ class InceptionTrainer:
         z = self.z[s.name]
         if core >= 2:  # 2..5 = async-LDS core, variant = core - 2 (bit 0: 128-row tiles, bit 1: 64-column tiles)
             rc = lib.dtf_conv_fwd_stats_v2(src.data_ptr(), self.Wp.data_ptr() + 2 * self.pack_off[s.name], z.data_ptr(),
-                                           self._stats(s.name, 0), B, H, W, s.cin, Cs, s.cout, s.kh, s.kw, s.stride,
+                                           self._stats(s.name, self._fwd_set), B, H, W, s.cin, Cs, s.cout, s.kh, s.kw, s.stride,
                                            s.pad[0], s.pad[1], Ho, Wo, core - 2, st)
         else:
             rc = lib.dtf_conv_fwd_stats(src.data_ptr(), self.param(s.name + "/conv2d_params").data_ptr(), z.data_ptr(),
-                                        self._stats(s.name, 0), B, H, W, s.cin, Cs, s.cout, s.kh, s.kw, s.stride,
+                                        self._stats(s.name, self._fwd_set), B, H, W, s.cin, Cs, s.cout, s.kh, s.kw, s.stride,
                                         s.pad[0], s.pad[1], Ho, Wo, st)
         self.native.check(rc, "conv_fwd_stats(core %d) %s" % (core, s.name))
 
@@ -388,6 +390,9 @@ class InceptionTrainer:
         self._x = x
         if self.async_lds:
             self.pack_weights()
+        fcur, fprev = (3, 0) if self._fwd_parity else (0, 3)
+        self._fwd_parity ^= 1
+        self._fwd_set = fcur
         for i, op in enumerate(g.ops):
             src = x if op.src == "input" else self.act[op.src]
             _, H, W, Cs = src.shape
@@ -399,13 +404,13 @@ class InceptionTrainer:
                 M = B * Ho * Wo
                 self._conv_fwd(op, src, self.core[s.name]["fwd"], st)
                 o = self.stat_off[s.name]
-                chk(lib.dtf_bn_finalize(self._stats(s.name, 0), self.param(s.name + "/batchnorm/gamma").data_ptr(),
-                                        self.param(s.name + "/batchnorm/beta").data_ptr(),
-                                        self.moving_mean.data_ptr() + 4 * o if training else 0,
-                                        self.moving_var.data_ptr() + 4 * o if training else 0,
-                                        self._bn_ptr(s.name), s.cout, M, BN_EPS, self.bn_momentum, st), "bn_finalize")
-                chk(lib.dtf_bn_relu_fwd(z.data_ptr(), self._bn_ptr(s.name), dst.data_ptr() + 2 * op.dst_off, M, s.cout, Cd, st),
-                    "bn_relu_fwd")
+                chk(lib.dtf_bn_finalize_relu_fwd(self._stats(s.name, fcur), self._stats(s.name, fprev),
+                                                 self.param(s.name + "/batchnorm/gamma").data_ptr(),
+                                                 self.param(s.name + "/batchnorm/beta").data_ptr(),
+                                                 self.moving_mean.data_ptr() + 4 * o if training else 0,
+                                                 self.moving_var.data_ptr() + 4 * o if training else 0,
+                                                 self._bn_ptr(s.name), z.data_ptr(), dst.data_ptr() + 2 * op.dst_off, M, s.cout, Cd,
+                                                 BN_EPS, self.bn_momentum, st), "bn_finalize_relu_fwd")
             elif op.kind == "maxpool":
                 dst = self.act[op.dst]
                 chk(lib.dtf_maxpool3x3_arg(src.data_ptr(), dst.data_ptr() + 2 * op.dst_off, self.argmax[i].data_ptr(), B, H, W,

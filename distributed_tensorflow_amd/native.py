@@ -106,6 +106,7 @@ def hip() -> C.CDLL:
         _sig(lib, "dtf_conv_dw_general", I, [P, I, P, P] + [I] * 13 + [P])
         _sig(lib, "dtf_bn_finalize", I, [P, P, P, P, P, P, I, L, F, F, P])
         _sig(lib, "dtf_bn_relu_fwd", I, [P, P, P, L, I, I, P])
+        _sig(lib, "dtf_bn_finalize_relu_fwd", I, [P, P, P, P, P, P, P, P, P, L, I, I, F, F, P])
         _sig(lib, "dtf_bn_relu_bwd_reduce", I, [P, I, P, P, P, L, I, P])
         _sig(lib, "dtf_bn_relu_bwd_apply", I, [P, I, P, P, P, P, P, P, L, I, P])
         _sig(lib, "dtf_maxpool3x3_arg", I, [P, P, P] + [I] * 7 + [P])
