@@ -152,6 +152,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+    trainer.close()
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -5,8 +5,9 @@
 //   C[M, N] = A_gather[M, K] * Wp[N, K]^T          bf16 operands, fp32 accumulate
 //
 // * A is gathered on the fly from a bf16 NHWC tensor (forward: im2col of the input; backward-data: the transposed
-//   gather of the output gradient, stride 1 or 2).  Out-of-image taps, rows >= M and k >= K read a 16-byte zero page
-//   instead of being predicated: every lane always issues its load, so the per-wave vmcnt arithmetic is static.
+//   gather of the output gradient, stride 1 or 2).  Out-of-image taps, rows >= M and k >= K are given an out-of-range
+//   buffer offset (the descriptor's range check returns zeros) instead of being predicated: every lane always issues
+//   its load, so the per-wave vmcnt arithmetic is static.
 // * Wp is a bf16 [N][K] (K contiguous) packing of the fp32 master weights, refreshed once per step by
 //   `dtf_pack_conv_weights` (87 MB read / 87 MB written for all of Inception-v3: ~40 us).
 // * LDS stage = A tile [256 rows][128 B] + B tile [BN rows][128 B]; a row is 8 chunks of 16 B and chunk c of row r is
@@ -29,7 +30,6 @@ constexpr int ERR_SHAPE = -22;
 struct IG2Params {
   GemmParams gp;  // A, C, M, N, K, ldc, bias, relu, aux_*, accumulate, g (geometry)
   const uint16_t* Wp;
-  const uint16_t* zeros;  // >= 16 bytes of zeros
   int mtiles, ntiles;
   unsigned magic_c, magic_kw;  // floor(2^32 / d) + 1 for d = channels per tap, KW
 };
@@ -225,18 +225,17 @@ bool raise_lds_limit() {
   return raise_one<256, BN, 3, MODE, EP>() && raise_one<128, BN, (BN == 64 ? 3 : 2), MODE, EP>();
 }
 
-uint16_t* g_zero_page = nullptr;
+bool g_ready = false;  // dtf_igemm2_init() has raised the dynamic-LDS limits
 
 inline int fill(IG2Params& q, const void* A, const void* Wp, void* C, int M, int N, int K, long ldc, int H, int W, int Cg,
                 int cstride, int Ho, int Wo, int KH, int KW, int stride, int pad_h, int pad_w) {
-  if (!g_zero_page) return -2;  // dtf_igemm2_init() was not called
+  if (!g_ready) return -2;  // dtf_igemm2_init() was not called
   q = IG2Params{};
   GemmParams& p = q.gp;
   p.A = A; p.C = C; p.M = M; p.N = N; p.K = K; p.ldc = ldc;
   p.g.H = H; p.g.W = W; p.g.Cin = Cg; p.g.cstride = cstride; p.g.Ho = Ho; p.g.Wo = Wo;
   p.g.KH = KH; p.g.KW = KW; p.g.stride = stride; p.g.pad_h = pad_h; p.g.pad_w = pad_w;
   q.Wp = reinterpret_cast<const uint16_t*>(Wp);
-  q.zeros = g_zero_page;
   q.magic_c = (unsigned)((1ull << 32) / (unsigned)Cg + 1ull);
   q.magic_kw = KW > 1 ? (unsigned)((1ull << 32) / (unsigned)KW + 1ull) : 0u;
   if ((long)K >= (1L << 21) || KH * KW > 32 || (long)N * K * 2 >= 0x7fffffffL) return ERR_SHAPE;
@@ -249,15 +248,14 @@ inline int fill(IG2Params& q, const void* A, const void* Wp, void* C, int M, int
 }
 }  // namespace
 
-// One-time setup (allocates the zero page, raises the dynamic-LDS limit of every instantiation).  Not capturable.
+// One-time setup (raises the dynamic-LDS limit of every instantiation).  Not capturable.
 DTF_API int dtf_igemm2_init() {
-  if (!g_zero_page) {
-    if (hipMalloc(reinterpret_cast<void**>(&g_zero_page), 256) != hipSuccess) return -1;
-    if (hipMemset(g_zero_page, 0, 256) != hipSuccess) return -1;
+  if (!g_ready) {
     if (!raise_lds_limit<64, 0, EpBf16Stats>() || !raise_lds_limit<128, 0, EpBf16Stats>() ||
         !raise_lds_limit<64, 0, EpBiasReluBf16>() || !raise_lds_limit<128, 0, EpBiasReluBf16>() ||
         !raise_lds_limit<64, 1, EpBf16Acc>() || !raise_lds_limit<128, 1, EpBf16Acc>())
       return -3;
+    g_ready = true;
   }
   return 0;
 }
@@ -347,7 +345,6 @@ struct DW2Params {
   const uint16_t* x;
   const uint16_t* dz;
   float* dW;
-  const uint16_t* zeros;
   ConvGeom g;  // H, W, Cin, cstride (of x), Ho, Wo, KH, KW, stride, pad
   int Cout, K, kchunk, nit, nct, taps;
   int rw, rh, qh;  // 64 positions = (qh*Ho + rh) rows + rw columns
@@ -503,12 +500,12 @@ DTF_API int dtf_igemm2_dw_init() { return (raise_dw_lds_limit<64>() && raise_dw_
 DTF_API int dtf_conv_dw_v2(const void* x, int in_cstride, const void* dz, float* dW, int B, int H, int W, int Cin, int Cout,
                            int KH, int KW, int stride, int pad_h, int pad_w, int Ho, int Wo, int splits, int variant,
                            hipStream_t st) {
-  if (!g_zero_page) return -2;
+  if (!g_ready) return -2;
   if (B <= 0 || Cin % 8 || Cout % 8 || in_cstride % 8 || splits < 1 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || stride < 1)
     return ERR_SHAPE;
   if ((H + 2 * pad_h - KH) / stride + 1 != Ho || (W + 2 * pad_w - KW) / stride + 1 != Wo) return ERR_SHAPE;
   DW2Params q{};
-  q.x = (const uint16_t*)x; q.dz = (const uint16_t*)dz; q.dW = dW; q.zeros = g_zero_page;
+  q.x = (const uint16_t*)x; q.dz = (const uint16_t*)dz; q.dW = dW;
   q.g.H = H; q.g.W = W; q.g.Cin = Cin; q.g.cstride = in_cstride; q.g.Ho = Ho; q.g.Wo = Wo;
   q.g.KH = KH; q.g.KW = KW; q.g.stride = stride; q.g.pad_h = pad_h; q.g.pad_w = pad_w;
   q.Cout = Cout; q.K = B * Ho * Wo; q.taps = KH * KW;

@@ -220,6 +220,14 @@ class DataParallelTrainer:
         else:
             e._steps_done = int(step.item())
 
+    def close(self) -> None:
+        """Release the IPC exchange buffers (collective: every rank calls it, before the process group is destroyed)."""
+        if self.ipc is not None:
+            self.engine.set_grad_hook(None)
+            self.ipc.close()
+            self.ipc = None
+            self.comm = "rccl"
+
     def replicas_in_sync(self) -> bool:
         """Debug invariant: parameter checksums identical on every rank."""
         if not self._multi:
