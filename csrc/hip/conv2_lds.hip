@@ -419,9 +419,11 @@ DTF_API int dtf_conv2_bwd_lds_init() {
 }
 
 // Fused conv2 backward for the MNIST geometry (14x14, 32 -> 64 channels, 5x5 SAME, 2x2 pool behind it).
-DTF_API int dtf_conv2_bwd_lds(const float* dpool2, const void* pool2, const void* amax2, const float* W, const void* pool1,
-                              float* dpool1, float* dW, float* db2, int B, int ipw, hipStream_t st) {
-  if (B <= 0 || ipw <= 0) return ERR_SHAPE;
+// The two kernels are independent of each other (each rebuilds dY from the pooled gradient), so the step
+// executor may issue them on different streams.
+DTF_API int dtf_conv2_bwd_data_lds(const float* dpool2, const void* pool2, const void* amax2, const float* W,
+                                   const void* pool1, float* dpool1, float* db2, int B, hipStream_t st) {
+  if (B <= 0) return ERR_SHAPE;
   if (!g_bwd_attr_set) {
     const int rc = dtf_conv2_bwd_lds_init();
     if (rc) return rc;
@@ -429,8 +431,25 @@ DTF_API int dtf_conv2_bwd_lds(const float* dpool2, const void* pool2, const void
   hipLaunchKernelGGL(conv2_bwd_data_lds_kernel, dim3(B, 2), dim3(256), DIMG_BYTES + WB_BYTES, st, dpool2,
                      (const uint16_t*)pool2, (const uint8_t*)amax2, W, (const uint16_t*)pool1, dpool1, db2);
   DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+DTF_API int dtf_conv2_dw_lds(const float* dpool2, const void* pool2, const void* amax2, const void* pool1, float* dW,
+                             int B, int ipw, hipStream_t st) {
+  if (B <= 0 || ipw <= 0) return ERR_SHAPE;
+  if (!g_bwd_attr_set) {
+    const int rc = dtf_conv2_bwd_lds_init();
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(conv2_dw_lds_kernel, dim3(dtf_cdiv(B, ipw), 5), dim3(320), IMG_BYTES + DIMG_BYTES, st,
                      (const uint16_t*)pool1, dpool2, (const uint16_t*)pool2, (const uint8_t*)amax2, dW, B, ipw);
   DTF_CHECK_LAUNCH();
   return 0;
+}
+
+DTF_API int dtf_conv2_bwd_lds(const float* dpool2, const void* pool2, const void* amax2, const float* W, const void* pool1,
+                              float* dpool1, float* dW, float* db2, int B, int ipw, hipStream_t st) {
+  const int rc = dtf_conv2_bwd_data_lds(dpool2, pool2, amax2, W, pool1, dpool1, db2, B, st);
+  if (rc) return rc;
+  return dtf_conv2_dw_lds(dpool2, pool2, amax2, pool1, dW, B, ipw, st);
 }

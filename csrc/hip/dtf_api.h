@@ -31,6 +31,10 @@ DTF_API int dtf_adam_tf(const OptimParams* p, hipStream_t st);
 DTF_API int dtf_sgd(const OptimParams* p, hipStream_t st);
 DTF_API int dtf_conv2_lds_init();
 DTF_API int dtf_conv2_bwd_lds_init();
+DTF_API int dtf_conv2_bwd_data_lds(const float* dpool2, const void* pool2, const void* amax2, const float* W,
+                                   const void* pool1, float* dpool1, float* db2, int B, hipStream_t st);
+DTF_API int dtf_conv2_dw_lds(const float* dpool2, const void* pool2, const void* amax2, const void* pool1, float* dW,
+                             int B, int ipw, hipStream_t st);
 DTF_API int dtf_conv2_bwd_lds(const float* dpool2, const void* pool2, const void* amax2, const float* W, const void* pool1,
                               float* dpool1, float* dW, float* db2, int B, int ipw, hipStream_t st);
 DTF_API int dtf_tensor_stats(const float* x, long n, const double* pos_limits, int npos, double* sums, unsigned* counts,

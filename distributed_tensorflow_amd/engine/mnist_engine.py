@@ -16,6 +16,8 @@ Reference: ``demo1/train.py:49-165`` (model, loss, Adam 1e-4, keep_prob 0.7, eva
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import math
 from collections import OrderedDict
@@ -68,6 +70,10 @@ class NativeMnistEngine(_EngineBase):
         native.check(self.lib.dtf_conv2_lds_init() or self.lib.dtf_conv2_bwd_lds_init(),
                      "LDS kernel attribute setup")  # before any stream capture
         self.device = torch.device(device)
+        # independent backward branches run as parallel graph branches (csrc/hip/engine.hip); DTF_MNIST_FORK=0
+        # restores the single chain (bit 0: conv2 filter gradient, bit 1: fc filter gradients)
+        with torch.cuda.device(self.device):
+            native.check(self.lib.dtf_mnist_streams_init(int(os.environ.get("DTF_MNIST_FORK", "3"))), "side streams")
         self.dataset = dataset
         self.batch_size = batch_size
         self.double_softmax = double_softmax
