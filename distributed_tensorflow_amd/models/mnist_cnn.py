@@ -75,12 +75,17 @@ def _bf16_round(t: torch.Tensor) -> torch.Tensor:
 
 def forward_logits(params: Dict[str, torch.Tensor], x: torch.Tensor, *, keep_prob: float = 1.0,
                    dropout_mask: Optional[torch.Tensor] = None, training: bool = False,
-                   bf16_sim: bool = False, return_intermediates: bool = False):
+                   bf16_sim: bool = False, return_intermediates: bool = False,
+                   fc1_gate: Optional[torch.Tensor] = None):
     """Plain-PyTorch forward.  ``x`` [B,784] fp32.  Returns logits [B,10].
 
     ``bf16_sim`` rounds the operands of conv2 / fc1 (and the activations the native
     path stores as bf16) so kernel tests can use tight tolerances.
     ``dropout_mask`` [B,1024] of {0,1}: explicit mask (tests); else Bernoulli(keep_prob).
+    ``fc1_gate`` [B,1024] of {0,1}: the combined ReLU-and-dropout gate of another run (tests): fc1 becomes
+    ``pre * gate / keep_prob``, so a pre-activation whose sign is decided by rounding noise cannot flip the
+    ReLU mask between the two implementations (one such element on a high-gradient row moves a whole
+    column of dW_fc1 by >10 %).
     """
     r = _bf16_round if bf16_sim else (lambda t: t)
     B = x.shape[0]
@@ -92,8 +97,9 @@ def forward_logits(params: Dict[str, torch.Tensor], x: torch.Tensor, *, keep_pro
     c2 = F.conv2d(p1, w2, params["b_conv2"], stride=1, padding=2)
     p2 = r(F.max_pool2d(F.relu(c2), 2))
     flat = p2.permute(0, 2, 3, 1).reshape(B, 3136)  # NHWC flatten (K7)
-    h = F.relu(flat @ r(params["W_fc1"]) + params["b_fc1"])
-    if training and keep_prob < 1.0:
+    pre = flat @ r(params["W_fc1"]) + params["b_fc1"]
+    h = F.relu(pre) if fc1_gate is None else pre * fc1_gate / keep_prob
+    if fc1_gate is None and training and keep_prob < 1.0:
         if dropout_mask is None:
             dropout_mask = (torch.rand_like(h) < keep_prob).to(h.dtype)
         h = h * dropout_mask / keep_prob  # tf.nn.dropout scaling (C13)

@@ -17,22 +17,26 @@ def _relerr(a, b):
     return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-12))
 
 
-@pytest.mark.parametrize("double_softmax", [True, False])
-def test_step_gradients_match_oracle(double_softmax):
+@pytest.mark.parametrize("double_softmax,B", [(True, 100), (False, 100), (True, 1), (True, 37), (False, 128),
+                                              (True, 200), (False, 333)])
+def test_step_gradients_match_oracle(double_softmax, B):
+    """One step of the native executor vs autograd on the same batch / dropout mask, for the reference's batch
+    (100), odd batches, and batches beyond 128 (separate fc dW launches instead of the grouped one)."""
     from distributed_tensorflow_amd.engine.mnist_engine import NativeMnistEngine
     from distributed_tensorflow_amd.models import mnist_cnn
     dd = _dataset()
-    eng = NativeMnistEngine(dd, batch_size=100, keep_prob=0.7, double_softmax=double_softmax, seed=3,
+    eng = NativeMnistEngine(dd, batch_size=B, keep_prob=0.7, double_softmax=double_softmax, seed=3,
                             use_graph=False, eval_chunk=500)
     params = {k: v.clone() for k, v in eng.param_views().items()}
     eng.fwd_bwd(3)
     eng.stream.synchronize()
-    idx = dd.batch_indices(0, 100)
+    idx = dd.batch_indices(0, B)
     x, y = dd.gather(idx)
-    h_drop = eng.ws["h_drop"].view(100, 1024).float()
+    h_drop = eng.ws["h_drop"].view(-1, 1024)[:B].float()
     mask = (h_drop != 0).float()
     leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    logits = mnist_cnn.forward_logits(leaf, x, keep_prob=0.7, dropout_mask=mask, training=True, bf16_sim=True)
+    # the executor's own ReLU-and-dropout gate: see forward_logits(fc1_gate=...)
+    logits = mnist_cnn.forward_logits(leaf, x, keep_prob=0.7, fc1_gate=mask, training=True, bf16_sim=True)
     loss, pred = mnist_cnn.softmax_xent(logits, y.long(), double_softmax=double_softmax)
     grads = torch.autograd.grad(loss, list(leaf.values()))
     g_native = eng.param_views(eng.G)
@@ -40,7 +44,7 @@ def test_step_gradients_match_oracle(double_softmax):
     logits_nodrop, inter = mnist_cnn.forward_logits(params, x, bf16_sim=True, return_intermediates=True)
     pos = inter["h_drop"] > 0
     kept = float(((h_drop != 0) & pos).sum()) / float(pos.sum())
-    assert abs(kept - 0.7) < 0.02
+    assert abs(kept - 0.7) < (0.02 if B >= 37 else 0.1)
     lm, acc = eng.read_metrics(0, 1)
     assert abs(float(lm[0]) - float(loss.detach())) < 2e-3 * max(1.0, abs(float(loss.detach())))
     assert abs(float(acc[0]) - float((pred.argmax(1) == y.long()).float().mean())) < 1e-6
