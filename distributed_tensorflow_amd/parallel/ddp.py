@@ -169,6 +169,7 @@ class DataParallelTrainer:
                 if t_ipc > 1.5 * t_pg:
                     ok, err = False, "IPC all-reduce slower than the process group's (%.0f vs %.0f us)" % (t_ipc, t_pg)
         if ok:
+            self.ipc.set_timeout(float(os.environ.get("DTF_IPC_TIMEOUT_S", "30")))
             self.engine.set_grad_hook(_IpcGradHook(self.ipc, self._bucket_a, self._bucket_b, self.engine.G,
                                                    self.overlap and not shared_gpu))
             self.comm = "ipc"
@@ -228,6 +229,15 @@ class DataParallelTrainer:
             self.ipc = None
             self.comm = "rccl"
 
+    def check_transport(self) -> None:
+        """Raise if an in-kernel wait of the IPC all-reduce ever expired (a peer stalled for longer than the bound, so
+        some step used an incomplete gradient sum).  Called at logging points; synchronises."""
+        if self.ipc is not None:
+            n = self.ipc.errors()
+            if n:
+                raise RuntimeError("IPC gradient all-reduce: %d wait(s) timed out on rank %d; a peer stalled or died" %
+                                   (n, self.rank))
+
     def replicas_in_sync(self) -> bool:
         """Debug invariant: parameter checksums identical on every rank."""
         if not self._multi:
@@ -246,6 +256,7 @@ class DataParallelTrainer:
         """Sum a few python floats across ranks (logging points only)."""
         if self.world == 1:
             return [float(v) for v in values]
+        self.check_transport()
         dev = "cpu" if self._stage_host else self.engine.device
         t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
         with self._ctx():

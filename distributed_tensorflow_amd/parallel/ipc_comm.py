@@ -103,6 +103,13 @@ class IpcAllReduce:
         native.check(self.lib.dtf_ipc_allreduce(C.byref(self.comm), src.data_ptr(), dst.data_ptr(), src.numel(), self.blocks, st),
                      "ipc_allreduce")
 
+    def set_timeout(self, timeout_s: float) -> None:
+        """Bound of every in-kernel wait.  The struct is a by-value kernel argument: call this BEFORE the all-reduce is
+        captured into a graph.  (Start-up uses a short bound so a broken mapping fails the self-test quickly; training
+        wants a long one so a peer that pauses for an evaluation or a checkpoint is waited for, not given up on.)"""
+        if self.comm is not None:
+            self.comm.timeout_ticks = int(timeout_s * 100e6)
+
     def errors(self) -> int:
         """Number of waits that timed out so far (synchronises)."""
         return int(self._words[1].item())
