@@ -98,12 +98,11 @@ def main():
         if use_cuda:
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        trainer.train_step()
+    trainer.prepare()  # graph capture only: nothing executes
+    trainer.train_steps(args.warmup)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.train_step()
+    trainer.train_steps(args.steps)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:

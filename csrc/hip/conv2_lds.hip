@@ -14,6 +14,7 @@
 //    ds_read_b64_tr_b16 (two per fragment) — no transposed weight copy has to be maintained.
 //    A 32-lane half reads 4 rows x 64 B = one full 256-B bank row: conflict-free without padding.
 #include "common.h"
+#include "conv1_dw_body.h"
 
 namespace {
 constexpr int ERR_SHAPE = -22;
@@ -314,16 +315,14 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_lds_kernel(const float* __
 
 // ---- conv2 filter gradient.   grid (ceil(B / ipw), 5 tap rows), 320 threads: wave = tap column dx.
 // pool1 bf16 [B,196,32] (the conv input); dW fp32 [25][32][64] accumulated with atomics.
-__global__ __launch_bounds__(320) void conv2_dw_lds_kernel(const uint16_t* __restrict__ pool1,
-                                                           const float* __restrict__ dpool2,
-                                                           const uint16_t* __restrict__ pool2,
-                                                           const uint8_t* __restrict__ amax2, float* __restrict__ dW,
-                                                           int B, int ipw) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void conv2_dw_body(char* __restrict__ smem, const int bx, const int dy,
+                                              const uint16_t* __restrict__ pool1, const float* __restrict__ dpool2,
+                                              const uint16_t* __restrict__ pool2, const uint8_t* __restrict__ amax2,
+                                              float* __restrict__ dW, int B, int ipw) {
   char* ximg = smem;               // 18x18 halo x 32 ch, 80-B pixels
   char* dimg = smem + IMG_BYTES;   // 18x18 halo x 64 ch, 144-B pixels
-  const int tid = threadIdx.x, lane = tid & 63, dx = tid >> 6, dy = blockIdx.y;
-  const int b0 = blockIdx.x * ipw;
+  const int tid = threadIdx.x, lane = tid & 63, dx = tid >> 6;
+  const int b0 = bx * ipw;
   const int nimg = min(ipw, B - b0);
 
   // per-lane LDS offsets of the transposing reads, identical for every image (13 k-steps x 2 reads)
@@ -405,6 +404,36 @@ __global__ __launch_bounds__(320) void conv2_dw_lds_kernel(const uint16_t* __res
     }
 }
 
+__global__ __launch_bounds__(320) void conv2_dw_lds_kernel(const uint16_t* __restrict__ pool1,
+                                                           const float* __restrict__ dpool2,
+                                                           const uint16_t* __restrict__ pool2,
+                                                           const uint8_t* __restrict__ amax2, float* __restrict__ dW,
+                                                           int B, int ipw) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  conv2_dw_body(smem, blockIdx.x, blockIdx.y, pool1, dpool2, pool2, amax2, dW, B, ipw);
+}
+
+// conv2 dW (workgroups [0, n2), id -> (image group id % gx, tap row id / gx)) and conv1 dW/db (the rest) in one launch.
+struct ConvDwDuo {
+  const uint16_t* pool1; const float* dpool2; const uint16_t* pool2; const uint8_t* amax2; float* dW2;
+  int B, ipw, gx, n2;
+  const float* images; const int* perm; const int* step_ptr; int spe;
+  const float* dpool1; const uint8_t* amax1; float* dW1; float* db1;
+  int n1;
+};
+constexpr int DUO_LDS = (IMG_BYTES + DIMG_BYTES) > CONV1_DW_LDS_FLOATS * 4 ? (IMG_BYTES + DIMG_BYTES) : CONV1_DW_LDS_FLOATS * 4;
+
+__global__ __launch_bounds__(320) void conv_dw_duo_kernel(const ConvDwDuo a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int id = blockIdx.x;
+  if (id < a.n2)
+    conv2_dw_body(smem, id % a.gx, id / a.gx, a.pool1, a.dpool2, a.pool2, a.amax2, a.dW2, a.B, a.ipw);
+  else
+    conv1_dw_body(reinterpret_cast<float*>(smem), id - a.n2, a.n1, a.images, a.perm, a.step_ptr, a.spe, a.B, a.dpool1,
+                  a.amax1, a.dW1, a.db1);
+}
+
+
 static bool g_bwd_attr_set = false;
 DTF_API int dtf_conv2_bwd_lds_init() {
   if (g_bwd_attr_set) return 0;
@@ -413,6 +442,9 @@ DTF_API int dtf_conv2_bwd_lds_init() {
   if (e != hipSuccess) return (int)e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_dw_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           IMG_BYTES + DIMG_BYTES);
+  if (e != hipSuccess) return (int)e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dw_duo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          DUO_LDS);
   if (e != hipSuccess) return (int)e;
   g_bwd_attr_set = true;
   return 0;
@@ -443,6 +475,27 @@ DTF_API int dtf_conv2_dw_lds(const float* dpool2, const void* pool2, const void*
   }
   hipLaunchKernelGGL(conv2_dw_lds_kernel, dim3(dtf_cdiv(B, ipw), 5), dim3(320), IMG_BYTES + DIMG_BYTES, st,
                      (const uint16_t*)pool1, dpool2, (const uint16_t*)pool2, (const uint8_t*)amax2, dW, B, ipw);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// Both filter gradients of the conv stack in one launch (see ConvDwDuo): conv2's from (pool1, dpool2, pool2, amax2),
+// conv1's from (images[perm], dpool1, amax1).  dW2 / dW1 / db1 are accumulated with atomics (pre-zeroed).
+DTF_API int dtf_conv_dw_duo(const float* dpool2, const void* pool2, const void* amax2, const void* pool1, float* dW2, int B,
+                            int ipw, const float* images, const int* perm, const int* step_ptr, int spe,
+                            const float* dpool1, const void* amax1, float* dW1, float* db1, hipStream_t st) {
+  if (B <= 0 || ipw <= 0 || (perm && spe <= 0)) return ERR_SHAPE;
+  if (!g_bwd_attr_set) {
+    const int rc = dtf_conv2_bwd_lds_init();
+    if (rc) return rc;
+  }
+  ConvDwDuo a;
+  a.pool1 = (const uint16_t*)pool1; a.dpool2 = dpool2; a.pool2 = (const uint16_t*)pool2; a.amax2 = (const uint8_t*)amax2;
+  a.dW2 = dW2; a.B = B; a.ipw = ipw; a.gx = dtf_cdiv(B, ipw); a.n2 = a.gx * 5;
+  a.images = images; a.perm = perm; a.step_ptr = step_ptr; a.spe = spe;
+  a.dpool1 = dpool1; a.amax1 = (const uint8_t*)amax1; a.dW1 = dW1; a.db1 = db1;
+  a.n1 = B < 128 ? B : 128;
+  hipLaunchKernelGGL(conv_dw_duo_kernel, dim3(a.n2 + a.n1), dim3(320), DUO_LDS, st, a);
   DTF_CHECK_LAUNCH();
   return 0;
 }

@@ -9,6 +9,9 @@ DTF_API int dtf_fc_fwd(const void* X, int x_is_f32, const float* W, float* out, 
                        const float* bias, int relu, hipStream_t st);
 DTF_API int dtf_fc_bwd_data(const void* dY, const float* W, float* dX, int M, int N, int K, int splits, hipStream_t st);
 DTF_API int dtf_fc_dw(const void* X, int x_is_f32, const void* dY, float* dW, int M, int N, int K, int splits, hipStream_t st);
+DTF_API int dtf_fc_bwd_trio(const void* X0, const void* dY0, float* dW0, int M0, int N0, const void* X1, const void* dY1,
+                            float* dW1, int M1, int N1, int K, const void* dYq, const float* Wq, float* dXq, int Mq, int Nq,
+                            int Kq, int splits, hipStream_t st);
 DTF_API int dtf_fc_dw_pair(const void* X0, const void* dY0, float* dW0, int M0, int N0, const void* X1, const void* dY1,
                            float* dW1, int M1, int N1, int K, hipStream_t st);
 DTF_API int dtf_conv_bias_relu_pool(const void* x, const float* Wt, const float* bias, void* out, void* argmax, int B,
@@ -33,6 +36,9 @@ DTF_API int dtf_conv2_lds_init();
 DTF_API int dtf_conv2_bwd_lds_init();
 DTF_API int dtf_conv2_bwd_data_lds(const float* dpool2, const void* pool2, const void* amax2, const float* W,
                                    const void* pool1, float* dpool1, float* db2, int B, hipStream_t st);
+DTF_API int dtf_conv_dw_duo(const float* dpool2, const void* pool2, const void* amax2, const void* pool1, float* dW2, int B,
+                            int ipw, const float* images, const int* perm, const int* step_ptr, int spe,
+                            const float* dpool1, const void* amax1, float* dW1, float* db1, hipStream_t st);
 DTF_API int dtf_conv2_dw_lds(const float* dpool2, const void* pool2, const void* amax2, const void* pool1, float* dW,
                              int B, int ipw, hipStream_t st);
 DTF_API int dtf_conv2_bwd_lds(const float* dpool2, const void* pool2, const void* amax2, const float* W, const void* pool1,

@@ -1,13 +1,13 @@
 // Native step executor for the MNIST CNN: the whole train step — batch gather,
-// forward, fused loss head, backward, optimizer — is a fixed sequence of 12 kernels + 1 memset issued
+// forward, fused loss head, backward, optimizer — is a fixed sequence of 8 kernels issued
 // from C++ on one HIP stream and (normally) replayed as a hipGraph, so the ~100 us step is not bound
 // by Python/launch overhead.  All per-step state that changes (step counter, batch offset, dropout
 // counter, metric slot) lives in device memory, which is what makes the captured graph replayable.
 //
 // The backward is split in two parts so a data-parallel driver can all-reduce the fc gradient bucket
 // (98 % of the bytes) on a communication stream while the conv backward still runs:
-//   part 1: conv1 fwd -> conv2 fwd -> fc1 (split-K) -> head -> fc2 dW -> fc1 dW        [bucket A ready]
-//   part 2: fc1 bwd-data -> unpool2(+db2) -> conv2 bwd-data -> conv2 dW -> conv1 dW/db  [bucket B ready]
+//   part 1: conv1 fwd -> conv2 fwd -> fc1 (split-K) -> head -> [fc1 dW | fc2 dW | fc1 bwd-data]   [bucket A ready]
+//   part 2: conv2 un-pool + bwd-data (+db2) -> [conv2 dW | conv1 dW/db]                           [bucket B ready]
 //   apply : multi-tensor TF-Adam over the flat arena (also zeroes the atomically accumulated grads)
 #include "dtf_api.h"
 #include "dtf_structs.h"
@@ -55,52 +55,16 @@ static int effective_splits(int K, int splits, int BK = 64) {  // mirrors base_p
   return (K + kchunk - 1) / kchunk;
 }
 
-// Branch concurrency: the backward is a small DAG, not a chain — the fc filter gradients only feed the
-// optimizer, and conv2's filter gradient is independent of its data gradient.  With side streams available
-// (dtf_mnist_streams_init) those branches are forked with events, which a stream capture turns into parallel
-// graph branches; each kernel on its own leaves most of the chip idle (one round of <= 256 workgroups).
-//   head -+- fc dW pair ------------------------------+
-//         +- fc1 bwd-data -+- conv2 bwd-data - conv1 dW +- (join) - Adam
-//                          +- conv2 dW ----------------+
-namespace {
-struct SideStreams {
-  hipStream_t s[2];
-  hipEvent_t ev[5];
-  int level;  // bit 0: fork conv2 dW, bit 1: fork the fc dW pair
-};
-SideStreams g_side = {{nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}, 0};
-bool g_side_made = false;
-
-inline int fork_to(hipStream_t from, hipStream_t to, hipEvent_t ev) {
-  hipError_t e = hipEventRecord(ev, from);
-  if (e != hipSuccess) return (int)e;
-  return (int)hipStreamWaitEvent(to, ev, 0);
-}
-}  // namespace
-
-DTF_API int dtf_mnist_streams_init(int level) {
-  if (!g_side_made) {
-    for (auto& s : g_side.s) {
-      hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-      if (e != hipSuccess) return (int)e;
-    }
-    for (auto& ev : g_side.ev) {
-      hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-      if (e != hipSuccess) return (int)e;
-    }
-    g_side_made = true;
-  }
-  g_side.level = level & 3;
-  return 0;
-}
+// The backward is a small DAG, not a chain: the fc filter gradients only feed the optimizer, and the two conv filter
+// gradients are independent of each other.  Running such branches on forked streams (parallel graph branches) was
+// measured and rejected: every cross-queue edge costs 5-10 us on this ~120 us step, as much as the overlap saves.
+// Instead independent kernels are fused HORIZONTALLY into one launch on the single stream:
+//   head -> [fc1 dW | fc2 dW | fc1 bwd-data] -> conv2 bwd-data -> [conv2 dW | conv1 dW] -> Adam
+static bool trio_ok(const MnistEngine* e) { return e->B <= 128 && effective_splits(1024, e->bwd_splits) > 1; }
 
 DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e, int parts, hipStream_t st) {
   const int B = e->B;
   if (B <= 0 || B > e->maxB) return -22;
-  const int level = g_side_made ? g_side.level : 0;
-  // the fc dW branch may only outlive part 1 when part 2 follows in the same call (the join is at its end)
-  const bool fork_fc = (level & 2) && parts == 3;
-  const bool fork_dw = (level & 1) != 0;
   if (parts & 1) {
     DTF_TRY(forward_to_slabs(e, e->images, e->perm, e->step, B, e->fc1_splits, true, st));
     HeadParams hp{};
@@ -132,35 +96,28 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e, int parts, hipStream_t st) {
     DTF_TRY(dtf_head(&hp, e->head_blocks, st));
     // fc1 dW[3136][1024] = pool2^T * dh  (stored: 12.8 MB, the one gradient that is never re-zeroed) and
     // fc2 dW[1024][10] = h_drop^T * dz, as one grouped launch when the batch fits a single K slab
-    hipStream_t sf = st;
-    if (fork_fc) {
-      sf = g_side.s[0];
-      DTF_TRY(fork_to(st, sf, g_side.ev[0]));
-    }
-    if (B <= 128) {
+    if (trio_ok(e)) {
+      // fc1 dW[3136][1024] = pool2^T * dh (stored: 12.8 MB, the one gradient that is never re-zeroed), fc2 dW[1024][10] =
+      // h_drop^T * dz and the split-K fc1 data gradient dpool2 += dh * W_fc1^T as one launch
+      DTF_TRY(dtf_fc_bwd_trio(e->pool2, e->dh, e->G + e->off_Wfc1, 3136, 1024, e->h_drop, e->dz, e->G + e->off_Wfc2, 1024, 10,
+                              B, e->dh, e->P + e->off_Wfc1, e->dpool2, B, 3136, 1024, e->bwd_splits, st));
+    } else if (B <= 128) {
       DTF_TRY(dtf_fc_dw_pair(e->pool2, e->dh, e->G + e->off_Wfc1, 3136, 1024, e->h_drop, e->dz, e->G + e->off_Wfc2,
-                             1024, 10, B, sf));
+                             1024, 10, B, st));
     } else {
-      DTF_TRY(dtf_fc_dw(e->h_drop, 0, e->dz, e->G + e->off_Wfc2, 1024, 10, B, 1, sf));
-      DTF_TRY(dtf_fc_dw(e->pool2, 0, e->dh, e->G + e->off_Wfc1, 3136, 1024, B, 1, sf));
+      DTF_TRY(dtf_fc_dw(e->h_drop, 0, e->dz, e->G + e->off_Wfc2, 1024, 10, B, 1, st));
+      DTF_TRY(dtf_fc_dw(e->pool2, 0, e->dh, e->G + e->off_Wfc1, 3136, 1024, B, 1, st));
     }
   }
   if (parts & 2) {
-    DTF_TRY(dtf_fc_bwd_data(e->dh, e->P + e->off_Wfc1, e->dpool2, B, 3136, 1024, e->bwd_splits, st));
-    // un-pool + conv2 bwd-data (+db2) and conv2 dW as two LDS-resident kernels (conv2_lds.hip)
+    if (!trio_ok(e))  // (otherwise part 1 already produced dpool2)
+      DTF_TRY(dtf_fc_bwd_data(e->dh, e->P + e->off_Wfc1, e->dpool2, B, 3136, 1024, e->bwd_splits, st));
+    // un-pool + conv2 bwd-data (+db2) as one LDS-resident kernel, then both conv filter gradients as one launch
     const int ipw = e->dw2_splits > 0 && e->dw2_splits <= 16 ? e->dw2_splits : 4;
-    hipStream_t sd = st;
-    if (fork_dw) {
-      sd = g_side.s[1];
-      DTF_TRY(fork_to(st, sd, g_side.ev[1]));
-    }
-    DTF_TRY(dtf_conv2_dw_lds(e->dpool2, e->pool2, e->amax2, e->pool1, e->G + e->off_Wc2, B, ipw, sd));
     DTF_TRY(dtf_conv2_bwd_data_lds(e->dpool2, e->pool2, e->amax2, e->P + e->off_Wc2, e->pool1, e->dpool1,
                                    e->G + e->off_bc2, B, st));
-    DTF_TRY(dtf_conv1_dw(e->images, e->perm, e->step, e->spe, B, e->dpool1, e->amax1, e->G + e->off_Wc1,
-                         e->G + e->off_bc1, st));
-    if (fork_dw) DTF_TRY(fork_to(sd, st, g_side.ev[2]));
-    if (fork_fc) DTF_TRY(fork_to(g_side.s[0], st, g_side.ev[3]));
+    DTF_TRY(dtf_conv_dw_duo(e->dpool2, e->pool2, e->amax2, e->pool1, e->G + e->off_Wc2, B, ipw, e->images, e->perm, e->step,
+                            e->spe, e->dpool1, e->amax1, e->G + e->off_Wc1, e->G + e->off_bc1, st));
   }
   return 0;
 }

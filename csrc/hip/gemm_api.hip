@@ -73,6 +73,63 @@ DTF_API int dtf_fc_dw_pair(const void* X0, const void* dY0, float* dW0, int M0, 
   return dtf_launch_gemm_pair<128, 64, 128, 4, 1, LoadColK<uint16_t, 128, 256, 128, true>, LoadColK<uint16_t, 64, 256, 128, false>, EpStoreF32>(p0, p1, st);
 }
 
+// The three GEMMs that follow the loss head in ONE launch: the fc1/fc2 filter gradients (single K pass, K = batch) and
+// the split-K fc1 data gradient.  They are independent, each alone leaves most of the chip idle, and a kernel
+// boundary or a cross-queue dependency costs 5-10 us on this ~120 us step (rocprofv3 timeline).
+namespace {
+struct GemmTrio {
+  GemmPair pair;
+  GemmParams q;             // data gradient: dX[M][N] += dY[M][K] * W[N][K]^T, split over K
+  int nblk_q, q_mt, q_nt;   // its blocks come first: m-tile fastest, then n-tile, then K split
+};
+using TrioDwA = LoadColK<uint16_t, 128, 256, 128, true>;
+using TrioDwB = LoadColK<uint16_t, 64, 256, 128, false>;
+using TrioBdA = LoadRowK<uint16_t, 128, 256, 64, true>;
+using TrioBdB = LoadRowK<float, 64, 256, 64, false>;
+
+__global__ __launch_bounds__(256) void fc_bwd_trio_kernel(const GemmTrio g) {
+  __shared__ __attribute__((aligned(16))) uint16_t smem[(128 + 64) * (128 + 8)];  // the larger instantiation (BK = 128)
+  const int id = blockIdx.x;
+  if (id < g.nblk_q) {
+    const int mt = id % g.q_mt, r = id / g.q_mt;
+    dtf_gemm_body<128, 64, 64, 4, 1, TrioBdA, TrioBdB, EpAtomicF32>(g.q, mt * 128, (r % g.q_nt) * 64, r / g.q_nt, smem,
+                                                                    smem + 128 * (64 + 8));
+  } else {
+    const int j = id - g.nblk_q;
+    const int which = j >= g.pair.nblk0;
+    const int k = which ? j - g.pair.nblk0 : j;
+    const int mt = which ? g.pair.mt1 : g.pair.mt0;
+    dtf_gemm_body<128, 64, 128, 4, 1, TrioDwA, TrioDwB, EpStoreF32>(g.pair.p[which], (k % mt) * 128, (k / mt) * 64, 0, smem,
+                                                                    smem + 128 * (128 + 8));
+  }
+}
+}  // namespace
+
+// dW0 = X0^T dY0, dW1 = X1^T dY1 (as dtf_fc_dw_pair) and dX[Mq][Nq] += dYq[Mq][Kq] * Wq[Nq][Kq]^T (as dtf_fc_bwd_data with
+// splits > 1: dX pre-zeroed) in one launch.
+DTF_API int dtf_fc_bwd_trio(const void* X0, const void* dY0, float* dW0, int M0, int N0, const void* X1, const void* dY1,
+                            float* dW1, int M1, int N1, int K, const void* dYq, const float* Wq, float* dXq, int Mq, int Nq,
+                            int Kq, int splits, hipStream_t st) {
+  if (M0 <= 0 || N0 <= 0 || M1 <= 0 || N1 <= 0 || K <= 0 || K > 128 || M0 % 2 || N0 % 2 || M1 % 2 || N1 % 2) return ERR_SHAPE;
+  if (Mq <= 0 || Nq <= 0 || Kq <= 0 || Kq % 8 || splits < 2) return ERR_SHAPE;
+  GemmTrio g;
+  g.pair.p[0] = base_params(X0, dY0, dW0, M0, N0, K, M0, N0, N0, 1, 128);
+  g.pair.p[1] = base_params(X1, dY1, dW1, M1, N1, K, M1, N1, N1, 1, 128);
+  g.pair.mt0 = dtf_cdiv(M0, 128);
+  g.pair.mt1 = dtf_cdiv(M1, 128);
+  g.pair.nblk0 = g.pair.mt0 * dtf_cdiv(N0, 64);
+  const int npair = g.pair.nblk0 + g.pair.mt1 * dtf_cdiv(N1, 64);
+  g.q = base_params(dYq, Wq, dXq, Mq, Nq, Kq, Kq, Kq, Nq, splits, 64);
+  const int s = eff_splits(g.q);
+  if (s < 2) return ERR_SHAPE;  // the atomic epilogue is the only one instantiated here
+  g.q_mt = dtf_cdiv(Mq, 128);
+  g.q_nt = dtf_cdiv(Nq, 64);
+  g.nblk_q = g.q_mt * g.q_nt * s;
+  hipLaunchKernelGGL(fc_bwd_trio_kernel, dim3(g.nblk_q + npair), dim3(256), 0, st, g);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
 static inline int fill_geom(GemmParams& p, int H, int W, int Cin, int cstride, int Ho, int Wo, int KH, int KW,
                             int stride, int pad_h, int pad_w) {
   p.g.H = H; p.g.W = W; p.g.Cin = Cin; p.g.cstride = cstride; p.g.Ho = Ho; p.g.Wo = Wo;

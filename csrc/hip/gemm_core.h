@@ -545,11 +545,12 @@ struct EpBiasReluPool {
 
 // ------------------------------------------------------------------ the kernel
 template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP>
-__device__ __forceinline__ void dtf_gemm_body(const GemmParams& p, const int m0, const int n0, const int z) {
+__device__ __forceinline__ void dtf_gemm_body(const GemmParams& p, const int m0, const int n0, const int z,
+                                              uint16_t* __restrict__ As, uint16_t* __restrict__ Bs) {
+  // As: BM * DTF_LDS_STRIDE halves, Bs: BN * DTF_LDS_STRIDE halves of LDS, 16-byte aligned (the kernel owns the
+  // allocation so horizontally fused kernels can share one buffer between different instantiations)
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static_assert(TM >= 1 && TN >= 1 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0 && BK % 16 == 0, "tile");
-  __shared__ __attribute__((aligned(16))) uint16_t As[BM * DTF_LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[BN * DTF_LDS_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int kbeg = z * p.kchunk;
@@ -601,7 +602,9 @@ __device__ __forceinline__ void dtf_gemm_body(const GemmParams& p, const int m0,
 
 template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP>
 __global__ __launch_bounds__(64 * WM * WN) void dtf_gemm_kernel(const GemmParams p) {
-  dtf_gemm_body<BM, BN, BK, WM, WN, AL, BL, EP>(p, blockIdx.x * BM, blockIdx.y * BN, blockIdx.z);
+  __shared__ __attribute__((aligned(16))) uint16_t smem[(BM + BN) * DTF_LDS_STRIDE];
+  dtf_gemm_body<BM, BN, BK, WM, WN, AL, BL, EP>(p, blockIdx.x * BM, blockIdx.y * BN, blockIdx.z, smem,
+                                                smem + BM * DTF_LDS_STRIDE);
 }
 
 // Two independent problems of the same instantiation in ONE launch (horizontal fusion of small GEMMs:
@@ -615,7 +618,9 @@ __global__ __launch_bounds__(64 * WM * WN) void dtf_gemm_pair_kernel(const GemmP
   const int which = (int)blockIdx.x >= g.nblk0;
   const int id = which ? blockIdx.x - g.nblk0 : blockIdx.x;
   const int mt = which ? g.mt1 : g.mt0;
-  dtf_gemm_body<BM, BN, BK, WM, WN, AL, BL, EP>(g.p[which], (id % mt) * BM, (id / mt) * BN, 0);
+  __shared__ __attribute__((aligned(16))) uint16_t smem[(BM + BN) * DTF_LDS_STRIDE];
+  dtf_gemm_body<BM, BN, BK, WM, WN, AL, BL, EP>(g.p[which], (id % mt) * BM, (id / mt) * BN, 0, smem,
+                                                smem + BM * DTF_LDS_STRIDE);
 }
 
 template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP>

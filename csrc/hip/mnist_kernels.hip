@@ -8,6 +8,7 @@
 //                    softmax cross-entropy + accuracy + dlogits + fc2/fc1 bias grads + fc1 pre-act grad
 // Reference semantics: demo1/train.py:57-141.
 #include "common.h"
+#include "conv1_dw_body.h"
 #include "dtf_structs.h"
 
 namespace {
@@ -15,13 +16,6 @@ constexpr int ERR_SHAPE = -22;
 constexpr int HID = 1024;
 constexpr int NC = 10;
 }  // namespace
-
-// index of the sample feeding batch row b of the current step
-__device__ __forceinline__ int sample_index(const int* perm, const int* step_ptr, int spe, int B, int b) {
-  if (perm == nullptr) return b;
-  const int step = step_ptr ? *step_ptr : 0;
-  return perm[(long)(step % spe) * B + b];
-}
 
 // ------------------------------------------------------------------ conv1 forward
 // grid (B, 4): blockIdx.y = group of 8 output channels (wave-uniform -> weights come through scalar loads).
@@ -117,77 +111,8 @@ __global__ __launch_bounds__(256) void conv1_dw_kernel(const float* __restrict__
                                                        const int* __restrict__ step_ptr, int spe, int B,
                                                        const float* __restrict__ dpool1, const uint8_t* __restrict__ amax,
                                                        float* __restrict__ dW, float* __restrict__ db) {
-  // per image: x halo plane (4 KB) + gradient plane 196x32 fp32 (24.5 KB) + argmax plane (6 KB) are pulled into LDS
-  // with one burst of independent loads; the 196 x 25-tap accumulation then never touches global memory.
-  __shared__ __attribute__((aligned(16))) float img[32 * 32];
-  __shared__ __attribute__((aligned(16))) float gl[7 * 256 * 4];   // 196*32 used; padded so staging needs no predicates
-  __shared__ __attribute__((aligned(16))) uint8_t al[4 * 256 * 8];  // 196*32 used
-  const int tid = threadIdx.x, c = tid & 31, pg = tid >> 5;
-  float acc[26];
-#pragma unroll
-  for (int t = 0; t < 26; ++t) acc[t] = 0.f;
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    const long n = sample_index(perm, step_ptr, spe, B, b);
-    const float* src = images + n * 784;
-    const f32x4* g4 = reinterpret_cast<const f32x4*>(dpool1 + (long)b * 6272);  // ext-vector type: stays in VGPRs
-    const uint2* a8 = reinterpret_cast<const uint2*>(amax + (long)b * 6272);
-    float v[4];
-    f32x4 ga[4], gb[3];  // (HIP's float4 struct copies lower to memcpy and land in scratch/LDS here)
-    uint2 avv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = tid + 256 * i, r = e >> 5, cc = e & 31;
-      const int y = r - 2, x = cc - 2;
-      const bool ok = (unsigned)y < 28u && (unsigned)x < 28u;
-      v[i] = src[ok ? y * 28 + x : 0];
-      v[i] = ok ? v[i] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ga[i] = g4[tid + 256 * i];  // 1568 float4 in total
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int e = tid + 256 * (4 + i);
-      gb[i] = g4[e < 1568 ? e : 0];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {  // 784 uint2
-      const int e = tid + 256 * i;
-      avv[i] = a8[e < 784 ? e : 0];
-    }
-    __syncthreads();  // previous image fully consumed
-#pragma unroll
-    for (int i = 0; i < 4; ++i) img[tid + 256 * i] = v[i];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) reinterpret_cast<f32x4*>(gl)[tid + 256 * i] = ga[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) reinterpret_cast<f32x4*>(gl)[tid + 256 * (4 + i)] = gb[i];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      reinterpret_cast<uint2*>(al)[tid + 256 * i] = avv[i];
-    }
-    __syncthreads();
-    for (int p = pg; p < 196; p += 8) {
-      const float g = gl[p * 32 + c];
-      const int a = al[p * 32 + c];
-      const int py = p / 14, px = p - py * 14;
-      const int r0 = 2 * py + (a >> 1), c0 = 2 * px + (a & 1);
-#pragma unroll
-      for (int dy = 0; dy < 5; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 5; ++dx) acc[dy * 5 + dx] = fmaf(img[(r0 + dy) * 32 + c0 + dx], g, acc[dy * 5 + dx]);
-      acc[25] += g;
-    }
-  }
-  __shared__ float red[8 * 26 * 32];
-#pragma unroll
-  for (int t = 0; t < 26; ++t) red[(pg * 26 + t) * 32 + c] = acc[t];
-  __syncthreads();
-  for (int e = tid; e < 26 * 32; e += 256) {
-    float sum = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) sum += red[q * 26 * 32 + e];
-    if (e < 25 * 32) atomicAdd(&dW[e], sum); else atomicAdd(&db[e - 25 * 32], sum);
-  }
+  __shared__ __attribute__((aligned(16))) float smem[CONV1_DW_LDS_FLOATS];
+  conv1_dw_body(smem, blockIdx.x, gridDim.x, images, perm, step_ptr, spe, B, dpool1, amax, dW, db);
 }
 
 DTF_API int dtf_conv1_dw(const float* images, const int* perm, const int* step_ptr, int spe, int B, const float* dpool1,

@@ -70,10 +70,6 @@ class NativeMnistEngine(_EngineBase):
         native.check(self.lib.dtf_conv2_lds_init() or self.lib.dtf_conv2_bwd_lds_init(),
                      "LDS kernel attribute setup")  # before any stream capture
         self.device = torch.device(device)
-        # independent backward branches run as parallel graph branches (csrc/hip/engine.hip); DTF_MNIST_FORK=0
-        # restores the single chain (bit 0: conv2 filter gradient, bit 1: fc filter gradients)
-        with torch.cuda.device(self.device):
-            native.check(self.lib.dtf_mnist_streams_init(int(os.environ.get("DTF_MNIST_FORK", "3"))), "side streams")
         self.dataset = dataset
         self.batch_size = batch_size
         self.double_softmax = double_softmax
@@ -226,6 +222,12 @@ class NativeMnistEngine(_EngineBase):
                 if rc == 0:
                     hook.after_part2(self.stream)
             return rc or self.lib.dtf_mnist_apply(C.byref(self.cfg), st)
+        if key.startswith("full*"):  # several consecutive steps in one graph (see train_steps)
+            for _ in range(int(key[5:])):
+                rc = self._enqueue("full", st)
+                if rc:
+                    return rc
+            return 0
         if key == "part1":
             return self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 1, st)
         if key == "part2":
@@ -256,6 +258,34 @@ class NativeMnistEngine(_EngineBase):
     def train_step(self) -> None:
         """One full step (single-GPU: fwd+bwd+Adam as one hipGraph replay)."""
         self.launch("full")
+
+    def train_steps(self, n: int, chunk: int = 8) -> None:
+        """``n`` full steps.  Everything a step needs (batch offset, dropout counter, Adam step, metric slot) lives in
+        device memory, so ``chunk`` consecutive steps replay as ONE hipGraph launch: the ~6 us the command processor
+        needs between two graph launches is paid once per chunk (measured on the 0.13 ms step).  A chunk never spans an
+        epoch boundary, where the permutation is regenerated between steps."""
+        chunk = int(os.environ.get("DTF_STEPS_PER_GRAPH", chunk))
+        key = "full*%d" % chunk
+        while n > 0:
+            room = self.spe - (self._steps_done % self.spe) if self.dataset is not None else n
+            if self.use_graph and chunk > 1 and n >= chunk and room >= chunk:
+                self._maybe_reshuffle()
+                if key not in self._graphs:
+                    self._capture(key)
+                native.check(self.lib.dtf_graph_launch(self._graphs[key], self.stream.cuda_stream), "graph launch")
+                self._steps_done += chunk
+                n -= chunk
+            else:
+                self.train_step()
+                n -= 1
+
+    def prepare(self, chunk: int = 8) -> None:
+        """Capture the step graphs now (capturing records, it does not execute) so that no later step pays for it."""
+        if self.use_graph:
+            chunk = int(os.environ.get("DTF_STEPS_PER_GRAPH", chunk))
+            for key in ("full",) + (("full*%d" % chunk,) if chunk > 1 else ()):
+                if key not in self._graphs:
+                    self._capture(key)
 
     def graph_nodes(self) -> int:
         return sum(self.lib.dtf_graph_num_nodes(h) for h in self._graphs.values()) if self._graphs else -1

@@ -278,6 +278,21 @@ class DataParallelTrainer:
                 dist.barrier(group=self.group)
 
     # ------------------------------------------------------------------ stepping
+    def prepare(self) -> None:
+        """Capture the step graphs ahead of the first step (collective-free; every rank may call it)."""
+        if self._native and (not self._multi or (self.sync and self.comm == "ipc")):
+            self.engine.prepare()
+
+    def train_steps(self, n: int) -> None:
+        """``n`` synchronous steps; several per graph launch where the whole step (incl. the gradient all-reduce) is
+        plain kernels on the engine's stream (single replica, or the IPC transport)."""
+        e = self.engine
+        if self._native and (not self._multi or (self.sync and self.comm == "ipc")):
+            e.train_steps(n)
+            return
+        for _ in range(n):
+            self.train_step()
+
     def train_step(self) -> None:
         e = self.engine
         if not self._multi:
