@@ -102,8 +102,8 @@ def run(FLAGS, distributed: bool) -> int:
     writer = None
     if rank == 0:
         graph = {"model": "mnist_cnn", "engine": kind, "world": world,
-                 "step_kernels": ["conv1_fwd", "conv2_fwd_pool", "fc1_fwd_splitk", "head", "fc_dw_pair", "fc1_bwd_data",
-                                  "unpool2", "conv2_bwd_data", "conv2_dw", "conv1_dw", "adam_tf"]}
+                 "step_kernels": ["conv1_fwd", "conv2_fwd_pool", "fc1_fwd_splitk", "head",
+                                  "fc_dw_pair|fc1_bwd_data", "unpool2+conv2_bwd_data", "conv2_dw|conv1_dw", "adam_tf"]}
         writer = FileWriter(FLAGS.log_dir, graph)
 
     sv: Optional[Supervisor] = None
@@ -125,7 +125,15 @@ def run(FLAGS, distributed: bool) -> int:
         while step < FLAGS.training_steps and not (sv is not None and sv.should_stop()):
             if FLAGS.fault_inject_step >= 0 and step == FLAGS.fault_inject_step and rank == world - 1:
                 raise RuntimeError("injected fault at step %d" % step)
-            trainer.train_step()
+            # run up to the next point where the host has something to do (evaluation, summary flush, fault
+            # injection, end of training; the stop flag is polled at least every 64 steps): the engine replays
+            # several steps per graph launch in between
+            interval = max(1, FLAGS.eval_step_interval)
+            burst = min(FLAGS.training_steps - step, interval * -(-step // interval) + 1 - step,
+                        512 - (step - flushed), 64)
+            if FLAGS.fault_inject_step > step:
+                burst = min(burst, FLAGS.fault_inject_step - step)
+            trainer.train_steps(max(1, burst))
             step = engine.global_step
             last = step - 1
             if step - flushed >= 512:
