@@ -53,12 +53,28 @@ __device__ __forceinline__ bool wait_flag(const unsigned* flag, unsigned want, u
   return true;
 }
 
+// Grid-strided copy with COPY_U independent 16-byte loads in flight per lane: at <= 128 workgroups a one-load-per-
+// iteration loop keeps only ~0.5 MB in flight, a fraction of what HBM latency x bandwidth needs.
+constexpr int COPY_U = 8;
+__device__ __forceinline__ void copy_f4(f32x4* __restrict__ dst, const f32x4* __restrict__ src, const long n4) {
+  for (long base = (long)blockIdx.x * 256 * COPY_U + threadIdx.x; base < n4; base += (long)gridDim.x * 256 * COPY_U) {
+    f32x4 v[COPY_U];
+#pragma unroll
+    for (int u = 0; u < COPY_U; ++u) {
+      const long i = base + u * 256;
+      v[u] = src[i < n4 ? i : base];
+    }
+#pragma unroll
+    for (int u = 0; u < COPY_U; ++u) {
+      const long i = base + u * 256;
+      if (i < n4) dst[i] = v[u];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void ipc_publish_kernel(const IpcComm c, const float* __restrict__ src, long n) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *c.epoch += 1u;  // read by K2/K3, which are stream-ordered after this kernel
-  f32x4* dst = reinterpret_cast<f32x4*>(stage_of(c.base[c.rank]));
-  const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
-  const long n4 = n >> 2;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) dst[i] = s4[i];
+  copy_f4(reinterpret_cast<f32x4*>(stage_of(c.base[c.rank])), reinterpret_cast<const f32x4*>(src), n >> 2);
 }
 
 __global__ __launch_bounds__(256) void ipc_reduce_kernel(const IpcComm c, long n) {
@@ -79,18 +95,29 @@ __global__ __launch_bounds__(256) void ipc_reduce_kernel(const IpcComm c, long n
   const long n4 = n >> 2;
   const long chunk = (n4 + c.world - 1) / c.world;
   const long lo = (long)c.rank * chunk, hi = lo + chunk < n4 ? lo + chunk : n4;
-  for (long i = lo + (long)blockIdx.x * 256 + threadIdx.x; i < hi; i += (long)gridDim.x * 256) {
-    f32x4 v[MAX_RANKS];
+  // two elements per lane and iteration, all peer loads of both in flight together (2 x world 16-byte requests per lane)
+  for (long i0 = lo + (long)blockIdx.x * 512 + threadIdx.x; i0 < hi; i0 += (long)gridDim.x * 512) {
+    const long i1 = i0 + 256;
+    const bool two = i1 < hi;
+    f32x4 v[2][MAX_RANKS];
 #pragma unroll
     for (int p = 0; p < MAX_RANKS; ++p)
-      if (p < c.world) v[p] = reinterpret_cast<const f32x4*>(stage_of(c.base[p]))[i];  // all peer loads in flight together
-    f32x4 s = v[0];
+      if (p < c.world) {
+        const f32x4* sp = reinterpret_cast<const f32x4*>(stage_of(c.base[p]));
+        v[0][p] = sp[i0];
+        v[1][p] = sp[two ? i1 : i0];
+      }
+    f32x4 s0 = v[0][0], s1 = v[1][0];
 #pragma unroll
     for (int p = 1; p < MAX_RANKS; ++p)
-      if (p < c.world) s += v[p];
+      if (p < c.world) { s0 += v[0][p]; s1 += v[1][p]; }
 #pragma unroll
     for (int p = 0; p < MAX_RANKS; ++p)
-      if (p < c.world) reinterpret_cast<f32x4*>(result_of(c.base[p], c.n_max))[i] = s;
+      if (p < c.world) {
+        f32x4* rp = reinterpret_cast<f32x4*>(result_of(c.base[p], c.n_max));
+        rp[i0] = s0;
+        if (two) rp[i1] = s1;
+      }
   }
 }
 
@@ -103,10 +130,7 @@ __global__ __launch_bounds__(256) void ipc_collect_kernel(const IpcComm c, float
     if (!wait_flag(&done_flags(c.base[c.rank])[p], e, c.timeout_ticks)) atomicAdd(c.error, 1u);
   }
   __syncthreads();
-  const f32x4* r4 = reinterpret_cast<const f32x4*>(result_of(c.base[c.rank], c.n_max));
-  f32x4* d4 = reinterpret_cast<f32x4*>(dst);
-  const long n4 = n >> 2;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) d4[i] = r4[i];
+  copy_f4(reinterpret_cast<f32x4*>(dst), reinterpret_cast<const f32x4*>(result_of(c.base[c.rank], c.n_max)), n >> 2);
 }
 }  // namespace
 

@@ -124,13 +124,16 @@ class DataParallelTrainer:
         if self._multi and self._native and sync and comm in ("auto", "ipc"):
             self._try_ipc(required=(comm == "ipc"))
 
-    def _time_transports(self, iters: int = 8):
-        """(ipc, process-group) microseconds per all-reduce of the gradient arena, max over ranks."""
+    def _time_transports(self, iters: int = 8, grids=(32, 64, 128)):
+        """(ipc, process-group) microseconds per all-reduce of the gradient arena, max over ranks.  The IPC kernels'
+        grid is tuned on the way (measure, don't guess: how many workgroups saturate seven xGMI links is not something
+        a one-GPU build box can tell); every rank sees the same max-over-ranks timings, so all pick the same grid."""
         import time
         e = self.engine
         buf = torch.zeros_like(e.G)
+        fns = [(lambda g=g: self.ipc.all_reduce(buf, blocks=g)) for g in grids] + [lambda: self._reduce(buf)]
         out = []
-        for fn in (lambda: self.ipc.all_reduce(buf), lambda: self._reduce(buf)):
+        for fn in fns:
             with self._ctx():
                 fn()
                 e.stream.synchronize()
@@ -142,7 +145,10 @@ class DataParallelTrainer:
             out.append((time.perf_counter() - t0) / iters * 1e6)
         t = torch.tensor(out, dtype=torch.float64, device="cpu" if self._stage_host else e.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        return float(t[0]), float(t[1])
+        t = t.cpu().tolist()
+        best = min(range(len(grids)), key=lambda i: t[i])
+        self.ipc.blocks = grids[best]
+        return float(t[best]), float(t[-1])
 
     def _try_ipc(self, required: bool) -> None:
         import socket
@@ -162,11 +168,13 @@ class DataParallelTrainer:
             self.ipc = IpcAllReduce(self.engine.G.numel(), self.engine.device, group=self.group)
             ok = self.ipc.self_test()
             err = self.ipc.failure or "self-test against the process group's all-reduce failed on some rank"
-            if ok and not required:
-                # measure, don't guess: keep the process group's collectives if they reduce the arena clearly faster
+            if ok:
+                # measure, don't guess: tune the IPC grid, and keep the process group's collectives if they reduce the
+                # arena clearly faster (unless the caller insisted on IPC)
                 t_ipc, t_pg = self._time_transports()
-                self.transport_us = {"ipc": round(t_ipc, 1), "process_group": round(t_pg, 1)}
-                if t_ipc > 1.5 * t_pg:
+                self.transport_us = {"ipc": round(t_ipc, 1), "ipc_workgroups": self.ipc.blocks,
+                                     "process_group": round(t_pg, 1)}
+                if not required and t_ipc > 1.5 * t_pg:
                     ok, err = False, "IPC all-reduce slower than the process group's (%.0f vs %.0f us)" % (t_ipc, t_pg)
         if ok:
             self.ipc.set_timeout(float(os.environ.get("DTF_IPC_TIMEOUT_S", "30")))

@@ -92,7 +92,8 @@ class IpcAllReduce:
                 self.failure = repr(e)
         dist.barrier(group=group)  # every rank has mapped every peer before the first flag is written
 
-    def all_reduce(self, src: torch.Tensor, dst: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> None:
+    def all_reduce(self, src: torch.Tensor, dst: Optional[torch.Tensor] = None, stream: Optional[int] = None,
+                   blocks: Optional[int] = None) -> None:
         """dst <- sum over ranks of src (fp32, numel % 4 == 0, <= n_max); in place when ``dst`` is None."""
         dst = src if dst is None else dst
         if self.comm is None:
@@ -100,7 +101,8 @@ class IpcAllReduce:
         assert src.is_cuda and src.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous()
         assert src.numel() == dst.numel() and src.numel() % 4 == 0 and src.numel() <= self.n_max
         st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
-        native.check(self.lib.dtf_ipc_allreduce(C.byref(self.comm), src.data_ptr(), dst.data_ptr(), src.numel(), self.blocks, st),
+        native.check(self.lib.dtf_ipc_allreduce(C.byref(self.comm), src.data_ptr(), dst.data_ptr(), src.numel(),
+                                                self.blocks if blocks is None else blocks, st),
                      "ipc_allreduce")
 
     def set_timeout(self, timeout_s: float) -> None:
