@@ -44,9 +44,12 @@ __device__ __forceinline__ float* stage_of(unsigned char* b) { return reinterpre
 __device__ __forceinline__ float* result_of(unsigned char* b, long n_max) { return reinterpret_cast<float*>(b + HDR_BYTES) + n_max; }
 
 // spin until *flag >= want (system-scope acquire) or the timeout expires; returns false on expiry
+// (relaxed polling; the caller issues ONE system-scope acquire fence after all its flags have arrived — an acquire
+// per poll, or a release per workgroup, costs a cache invalidate / write-back each: measured ~0.09 us per workgroup
+// and kernel, which made larger grids slower instead of faster)
 __device__ __forceinline__ bool wait_flag(const unsigned* flag, unsigned want, unsigned long long timeout) {
   const unsigned long long t0 = wall_clock64();
-  while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
     if (wall_clock64() - t0 > timeout) return false;
     __builtin_amdgcn_s_sleep(8);
   }
@@ -84,12 +87,15 @@ __global__ __launch_bounds__(256) void ipc_reduce_kernel(const IpcComm c, long n
   __syncthreads();
   if (threadIdx.x < c.world) {
     const int p = threadIdx.x;
-    // (every block signals: idempotent, and no block depends on another block of this grid)
-    __hip_atomic_store(&ready_flags(c.base[p])[c.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // workgroup 0 signals (the publish kernel has completed: stream order); no workgroup depends on another one of
+    // this grid, so the grid needs no co-residency
+    if (blockIdx.x == 0)
+      __hip_atomic_store(&ready_flags(c.base[p])[c.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (!wait_flag(&ready_flags(c.base[c.rank])[p], e, c.timeout_ticks)) {
       ok_all = 0;
-      atomicAdd(c.error, 1u);
+      if (blockIdx.x == 0) atomicAdd(c.error, 1u);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: the peers' stage buffers are read below
   }
   __syncthreads();
   const long n4 = n >> 2;
@@ -126,8 +132,10 @@ __global__ __launch_bounds__(256) void ipc_collect_kernel(const IpcComm c, float
   if (threadIdx.x < c.world) {
     const int p = threadIdx.x;
     // K2 has completed (stream order), so this rank's slice is written everywhere: publish that, then wait for all
-    __hip_atomic_store(&done_flags(c.base[p])[c.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (!wait_flag(&done_flags(c.base[c.rank])[p], e, c.timeout_ticks)) atomicAdd(c.error, 1u);
+    if (blockIdx.x == 0)
+      __hip_atomic_store(&done_flags(c.base[p])[c.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!wait_flag(&done_flags(c.base[c.rank])[p], e, c.timeout_ticks) && blockIdx.x == 0) atomicAdd(c.error, 1u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   }
   __syncthreads();
   copy_f4(reinterpret_cast<f32x4*>(dst), reinterpret_cast<const f32x4*>(result_of(c.base[c.rank], c.n_max)), n >> 2);
@@ -164,7 +172,9 @@ DTF_API int dtf_ipc_allreduce(const void* comm, const float* src, float* dst, lo
   const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
   if (n <= 0 || n % 4 || n > c.n_max || c.world < 1 || c.world > MAX_RANKS || c.rank < 0 || c.rank >= c.world) return -22;
   if (blocks < 1) blocks = 64;
-  if (blocks > 128) blocks = 128;  // <= half the CUs: two ranks' grids stay co-resident when ranks share a GPU
+  // (ranks that share one GPU must keep blocks <= 128, half the CUs, so that both ranks' spinning grids stay co-resident;
+  //  the caller knows the placement, see DataParallelTrainer._try_ipc)
+  if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(ipc_publish_kernel, dim3(blocks), dim3(256), 0, st, c, src, n);
   hipLaunchKernelGGL(ipc_reduce_kernel, dim3(blocks), dim3(256), 0, st, c, n);
   hipLaunchKernelGGL(ipc_collect_kernel, dim3(blocks), dim3(256), 0, st, c, dst, n);

@@ -171,7 +171,8 @@ class DataParallelTrainer:
             if ok:
                 # measure, don't guess: tune the IPC grid, and keep the process group's collectives if they reduce the
                 # arena clearly faster (unless the caller insisted on IPC)
-                t_ipc, t_pg = self._time_transports()
+                t_ipc, t_pg = self._time_transports(grids=(32, 64, 128) if len(set(where)) < self.world
+                                                    else (64, 128, 256, 512))
                 self.transport_us = {"ipc": round(t_ipc, 1), "ipc_workgroups": self.ipc.blocks,
                                      "process_group": round(t_pg, 1)}
                 if not required and t_ipc > 1.5 * t_pg:
