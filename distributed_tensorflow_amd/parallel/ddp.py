@@ -70,6 +70,13 @@ class _IpcGradHook:
             self.ev_fork = torch.cuda.Event()
             self.ev_join = torch.cuda.Event()
 
+    def set_overlap(self, overlap: bool) -> None:
+        self.overlap = overlap
+        if overlap and not hasattr(self, "side"):
+            self.side = torch.cuda.Stream(device=self.whole.device)
+            self.ev_fork = torch.cuda.Event()
+            self.ev_join = torch.cuda.Event()
+
     def after_part1(self, stream) -> None:
         if not self.overlap:
             return
@@ -121,8 +128,13 @@ class DataParallelTrainer:
         self.transport_us = None
         if comm not in ("auto", "ipc", "rccl"):
             raise ValueError("comm must be auto, ipc or rccl")
+        self.schedule_us = None
+        self.schedule = None
+        self._shared_gpu = False
         if self._multi and self._native and sync and comm in ("auto", "ipc"):
             self._try_ipc(required=(comm == "ipc"))
+            if self.comm == "ipc" and (not self._shared_gpu or os.environ.get("DTF_IPC_FORCE_OVERLAP")):
+                self._tune_schedule(allow_rccl=(comm == "auto"))
 
     def _time_transports(self, iters: int = 8, grids=(32, 64, 128)):
         """(ipc, process-group) microseconds per all-reduce of the gradient arena, max over ranks.  The IPC kernels'
@@ -159,7 +171,8 @@ class DataParallelTrainer:
         ok = len(set(h for h, _d in where)) == 1 and self.world <= 8
         # ranks sharing one GPU (functional tests): a forked stream whose kernels spin on a peer that needs the same
         # CUs only slows both down (measured 0.51 vs 0.27 ms/step for 2 ranks on one GPU), so no overlap there
-        shared_gpu = len(set(where)) < self.world and not os.environ.get("DTF_IPC_FORCE_OVERLAP")
+        self._shared_gpu = len(set(where)) < self.world
+        shared_gpu = self._shared_gpu and not os.environ.get("DTF_IPC_FORCE_OVERLAP")
         err = "ranks span several hosts or more than 8 ranks"
         if ok:
             # (IpcAllReduce and self_test keep every rank on the same sequence of collectives even when a local HIP
@@ -190,6 +203,65 @@ class DataParallelTrainer:
                 raise RuntimeError("IPC all-reduce unavailable: " + err)
             if self.rank == 0:
                 print("IPC all-reduce not used (%s); gradients go through %s" % (err, dist.get_backend(self.group)), flush=True)
+
+    def _tune_schedule(self, allow_rccl: bool, steps: int = 160) -> None:
+        """Pick the step schedule by running it.  Whether forking the fc-bucket all-reduce onto a second queue beats
+        reducing the whole arena in-stream depends on what a cross-queue dependency costs against what the xGMI
+        transfer takes at this world size (5-10 us per edge was measured on one GPU; the transfer time cannot be
+        measured on a one-GPU build box), and RCCL's own overlapped path is a third candidate.  Each candidate runs
+        ``steps`` real training steps from the same snapshot of (P, M, V, step), which is restored afterwards, so
+        training starts from exactly the state it would have had without tuning.  All ranks see the same
+        max-over-ranks timings and therefore make the same choice."""
+        import time
+        e = self.engine
+        forced = os.environ.get("DTF_DP_SCHEDULE", "auto")
+        room = e.spe - (e.global_step % e.spe) - 1 if getattr(e, "dataset", None) is not None else steps + 8
+        steps = min(steps, room - 8)
+        cands = ["ipc-overlap", "ipc-inline"] + (["rccl"] if allow_rccl and not self._stage_host else [])
+        if forced != "auto":
+            if forced not in cands:
+                raise ValueError("DTF_DP_SCHEDULE=%s is not available here (%s)" % (forced, cands))
+            cands = [forced]
+        hook = e.grad_hook
+
+        def use(c: str) -> None:
+            if c == "rccl":
+                e.set_grad_hook(None)
+                self.comm = "rccl"
+            else:
+                hook.set_overlap(c == "ipc-overlap")
+                e.set_grad_hook(hook)  # (drops the captured graphs)
+                self.comm = "ipc"
+
+        if len(cands) > 1 and steps >= 8:
+            with self._ctx():
+                snap = [t.clone() for t in (e.P, e.M, e.V, e.step_t)]
+            done0, times = e._steps_done, []
+            for c in cands:
+                use(c)
+                self.prepare()
+                self.train_steps(8)
+                e.stream.synchronize()
+                dist.barrier(group=self.group)
+                t0 = time.perf_counter()
+                self.train_steps(steps)
+                e.stream.synchronize()
+                times.append((time.perf_counter() - t0) / steps * 1e6)
+                with self._ctx():
+                    for t, s0 in zip((e.P, e.M, e.V, e.step_t), snap):
+                        t.copy_(s0)
+                    e.metrics_ring.zero_()  # (the per-step loss/accuracy slots the trial steps accumulated into)
+                e.stream.synchronize()
+                e._steps_done = done0
+            t = torch.tensor(times, dtype=torch.float64, device="cpu" if self._stage_host else e.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            times = t.cpu().tolist()
+            self.schedule_us = {c: round(v, 1) for c, v in zip(cands, times)}
+            cands = [cands[min(range(len(cands)), key=lambda i: times[i])]]
+        use(cands[0])
+        self.schedule = cands[0]
+        if self.rank == 0:
+            print("data-parallel step schedule: %s %s" % (self.schedule, self.schedule_us or ""), flush=True)
 
     # ------------------------------------------------------------------ collectives
     def _ctx(self):
