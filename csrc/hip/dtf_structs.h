@@ -45,4 +45,6 @@ struct OptimParams {
   unsigned int* ticket;  // device: arrival counter (0 between launches)
   float* metrics_ring;   // optional: slot (t % ring) zeroed for the next step's head kernel
   int ring;
+  const float* Gsrc;     // optional: read the gradients from here instead of G (an all-reduce result buffer);
+                         // the re-zeroing of [zero_from, n) still applies to G
 };

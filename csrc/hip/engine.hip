@@ -31,6 +31,10 @@ struct MnistEngine {
   float* dpool2;
   void* dy2;
   float* dpool1;
+  // data-parallel zero-copy exchange (both null otherwise): where the fc1 filter gradient (98 % of the arena, offset 0)
+  // is stored instead of G, and where the optimizer reads the reduced gradients of the whole arena from
+  float* G_fc1_dst;
+  const float* G_src;
 };
 
 #define DTF_TRY(x)            \
@@ -65,6 +69,8 @@ static bool trio_ok(const MnistEngine* e) { return e->B <= 128 && effective_spli
 DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e, int parts, hipStream_t st) {
   const int B = e->B;
   if (B <= 0 || B > e->maxB) return -22;
+  if (e->G_fc1_dst && e->off_Wfc1 != 0) return -22;
+  float* const dW_fc1 = e->G_fc1_dst ? e->G_fc1_dst : e->G + e->off_Wfc1;
   if (parts & 1) {
     DTF_TRY(forward_to_slabs(e, e->images, e->perm, e->step, B, e->fc1_splits, true, st));
     HeadParams hp{};
@@ -99,14 +105,14 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e, int parts, hipStream_t st) {
     if (trio_ok(e)) {
       // fc1 dW[3136][1024] = pool2^T * dh (stored: 12.8 MB, the one gradient that is never re-zeroed), fc2 dW[1024][10] =
       // h_drop^T * dz and the split-K fc1 data gradient dpool2 += dh * W_fc1^T as one launch
-      DTF_TRY(dtf_fc_bwd_trio(e->pool2, e->dh, e->G + e->off_Wfc1, 3136, 1024, e->h_drop, e->dz, e->G + e->off_Wfc2, 1024, 10,
+      DTF_TRY(dtf_fc_bwd_trio(e->pool2, e->dh, dW_fc1, 3136, 1024, e->h_drop, e->dz, e->G + e->off_Wfc2, 1024, 10,
                               B, e->dh, e->P + e->off_Wfc1, e->dpool2, B, 3136, 1024, e->bwd_splits, st));
     } else if (B <= 128) {
-      DTF_TRY(dtf_fc_dw_pair(e->pool2, e->dh, e->G + e->off_Wfc1, 3136, 1024, e->h_drop, e->dz, e->G + e->off_Wfc2,
+      DTF_TRY(dtf_fc_dw_pair(e->pool2, e->dh, dW_fc1, 3136, 1024, e->h_drop, e->dz, e->G + e->off_Wfc2,
                              1024, 10, B, st));
     } else {
       DTF_TRY(dtf_fc_dw(e->h_drop, 0, e->dz, e->G + e->off_Wfc2, 1024, 10, B, 1, st));
-      DTF_TRY(dtf_fc_dw(e->pool2, 0, e->dh, e->G + e->off_Wfc1, 3136, 1024, B, 1, st));
+      DTF_TRY(dtf_fc_dw(e->pool2, 0, e->dh, dW_fc1, 3136, 1024, B, 1, st));
     }
   }
   if (parts & 2) {
@@ -133,6 +139,7 @@ DTF_API int dtf_mnist_apply(const MnistEngine* e, hipStream_t st) {
   op.ticket = e->ticket;
   op.metrics_ring = e->metrics_ring;
   op.ring = e->ring;
+  op.Gsrc = e->G_src;
   return dtf_adam_tf(&op, st);
 }
 

@@ -140,6 +140,27 @@ __global__ __launch_bounds__(256) void ipc_collect_kernel(const IpcComm c, float
   __syncthreads();
   copy_f4(reinterpret_cast<f32x4*>(dst), reinterpret_cast<const f32x4*>(result_of(c.base[c.rank], c.n_max)), n >> 2);
 }
+
+// ---- zero-copy variant: the producers wrote stage[0, rest_off) themselves (the step executor points the big fc1
+// filter-gradient GEMM straight at the stage buffer) and the consumer reads result[] in place (the optimizer takes it as
+// its gradient source), so both 13 MB local copies disappear; only the small tail [rest_off, rest_off + rest_n) is copied.
+__global__ __launch_bounds__(256) void ipc_publish_rest_kernel(const IpcComm c, const float* __restrict__ src_rest,
+                                                               long rest_off, long rest_n) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *c.epoch += 1u;
+  copy_f4(reinterpret_cast<f32x4*>(stage_of(c.base[c.rank]) + rest_off), reinterpret_cast<const f32x4*>(src_rest), rest_n >> 2);
+}
+
+// one wave: "my slice is written everywhere" (the reduce kernel has completed: stream order), then wait until every
+// peer says the same; the kernels that follow on the stream may read result[] and overwrite stage[]
+__global__ __launch_bounds__(64) void ipc_done_kernel(const IpcComm c) {
+  const unsigned e = *c.epoch;
+  if (threadIdx.x < c.world) {
+    const int p = threadIdx.x;
+    __hip_atomic_store(&done_flags(c.base[p])[c.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!wait_flag(&done_flags(c.base[c.rank])[p], e, c.timeout_ticks)) atomicAdd(c.error, 1u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  }
+}
 }  // namespace
 
 // ---- allocation / handle exchange (host)
@@ -166,6 +187,29 @@ DTF_API int dtf_ipc_open_handle(const void* handle64, void** out) {
   return hipIpcOpenMemHandle(out, h, hipIpcMemLazyEnablePeerAccess) == hipSuccess ? 0 : -1;
 }
 DTF_API int dtf_ipc_close_handle(void* p) { return hipIpcCloseMemHandle(p) == hipSuccess ? 0 : -1; }
+
+DTF_API void* dtf_ipc_stage_ptr(void* base) { return reinterpret_cast<unsigned char*>(base) + HDR_BYTES; }
+DTF_API void* dtf_ipc_result_ptr(void* base, long n_max) {
+  return reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(base) + HDR_BYTES) + n_max;
+}
+
+// Zero-copy all-reduce of n floats: stage[0, rest_off) of this rank already holds its data, src_rest[0, rest_n) is
+// copied to stage[rest_off, ...) (rest_off + rest_n == n); afterwards result[0, n) of this rank holds the sum.
+DTF_API int dtf_ipc_allreduce_zc(const void* comm, const float* src_rest, long rest_off, long rest_n, long n, int blocks,
+                                 hipStream_t st) {
+  const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
+  if (n <= 0 || n % 4 || n > c.n_max || c.world < 1 || c.world > MAX_RANKS || c.rank < 0 || c.rank >= c.world) return -22;
+  if (rest_off < 0 || rest_n < 0 || rest_off % 4 || rest_n % 4 || rest_off + rest_n != n) return -22;
+  if (blocks < 1) blocks = 64;
+  if (blocks > 1024) blocks = 1024;
+  const long rest_blocks = (rest_n / 4 + 256 * COPY_U - 1) / (256 * COPY_U);
+  hipLaunchKernelGGL(ipc_publish_rest_kernel, dim3(rest_blocks < 1 ? 1 : (rest_blocks > blocks ? blocks : (int)rest_blocks)),
+                     dim3(256), 0, st, c, src_rest, rest_off, rest_n);
+  hipLaunchKernelGGL(ipc_reduce_kernel, dim3(blocks), dim3(256), 0, st, c, n);
+  hipLaunchKernelGGL(ipc_done_kernel, dim3(1), dim3(64), 0, st, c);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
 
 // comm: struct IpcComm by pointer (host memory).  src/dst may alias (in-place all-reduce of a gradient arena).
 DTF_API int dtf_ipc_allreduce(const void* comm, const float* src, float* dst, long n, int blocks, hipStream_t st) {

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(const OptimParams p) {
   const float lr_t = (float)((double)p.lr * sqrt(1.0 - b2p) / (1.0 - b1p));
   const float b1 = p.beta1, b2 = p.beta2, ob1 = 1.f - p.beta1, ob2 = 1.f - p.beta2;
   const long n4 = p.n >> 2;
+  const float* __restrict__ gsrc = p.Gsrc ? p.Gsrc : p.G;
   constexpr int U = 4;  // 16 independent 16-B loads in flight per lane before the first use
   for (long base = (long)blockIdx.x * 256 * U + threadIdx.x; base < n4; base += (long)gridDim.x * 256 * U) {
     float4 g[U], m[U], v[U], w[U];
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(const OptimParams p) {
     for (int u = 0; u < U; ++u) {
       const long i = base + u * 256;
       const long j = i < n4 ? i : base;  // clamped address, result discarded below
-      g[u] = reinterpret_cast<const float4*>(p.G)[j];
+      g[u] = reinterpret_cast<const float4*>(gsrc)[j];
       m[u] = reinterpret_cast<const float4*>(p.M)[j];
       v[u] = reinterpret_cast<const float4*>(p.V)[j];
       w[u] = reinterpret_cast<const float4*>(p.P)[j];
@@ -70,8 +71,9 @@ __global__ __launch_bounds__(256) void sgd_kernel(const OptimParams p) {
   const int t = *p.step + 1;
   const float a = p.lr * p.grad_scale;
   const long n4 = p.n >> 2;
+  const float* __restrict__ gsrc = p.Gsrc ? p.Gsrc : p.G;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    const float4 g = reinterpret_cast<const float4*>(p.G)[i];
+    const float4 g = reinterpret_cast<const float4*>(gsrc)[i];
     float4 w = reinterpret_cast<const float4*>(p.P)[i];
     w.x -= a * g.x; w.y -= a * g.y; w.z -= a * g.z; w.w -= a * g.w;
     reinterpret_cast<float4*>(p.P)[i] = w;

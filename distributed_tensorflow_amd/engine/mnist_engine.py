@@ -146,6 +146,12 @@ class NativeMnistEngine(_EngineBase):
         split = self.layout["W_conv2"][0]
         return (0, split), (split, self.n_arena)
 
+    def fc1_grad_numel(self) -> int:
+        """Size of the fc1 filter gradient, the stored (never atomically accumulated) segment at the arena's head."""
+        off, n, _shape = self.layout["W_fc1"]
+        assert off == 0
+        return int(n)
+
     def state_dict(self) -> Dict[str, torch.Tensor]:
         # snapshot in stream order (between two steps) so a saver thread never sees a half-applied update
         with torch.cuda.stream(self.stream):
@@ -235,6 +241,14 @@ class NativeMnistEngine(_EngineBase):
         if key == "apply":
             return self.lib.dtf_mnist_apply(C.byref(self.cfg), st)
         return -22
+
+    def set_grad_redirect(self, fc1_dst: int = 0, apply_src: int = 0) -> None:
+        """Zero-copy gradient exchange: store the fc1 filter gradient (arena offset 0, 98 % of the bytes) at device
+        address ``fc1_dst`` instead of into ``G``, and let the optimizer read the whole arena's gradients from
+        ``apply_src`` (0 = back to ``G`` for both).  Drops the captured graphs."""
+        self.cfg.G_fc1_dst = fc1_dst or None
+        self.cfg.G_src = apply_src or None
+        self._drop_graph()
 
     def set_grad_hook(self, hook) -> None:
         """``hook.after_part1(stream)`` / ``hook.after_part2(stream)`` run inside the ``full`` segment after the fc

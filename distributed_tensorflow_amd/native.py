@@ -47,6 +47,7 @@ class OptimParams(C.Structure):
         ("n", c_long), ("zero_from", c_long),
         ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("grad_scale", c_float),
         ("step", c_void_p), ("ticket", c_void_p), ("metrics_ring", c_void_p), ("ring", c_int),
+        ("Gsrc", c_void_p),
     ]
 
 
@@ -65,6 +66,7 @@ class MnistEngineStruct(C.Structure):  # csrc/hip/engine.hip: struct MnistEngine
         ("pool1", c_void_p), ("amax1", c_void_p), ("pool2", c_void_p), ("amax2", c_void_p),
         ("slabs", c_void_p), ("h_drop", c_void_p), ("dh", c_void_p), ("dz", c_void_p),
         ("dpool2", c_void_p), ("dy2", c_void_p), ("dpool1", c_void_p),
+        ("G_fc1_dst", c_void_p), ("G_src", c_void_p),
     ]
 
 

@@ -65,6 +65,9 @@ class _IpcGradHook:
 
     def __init__(self, ipc, bucket_a: torch.Tensor, bucket_b: torch.Tensor, whole: torch.Tensor, overlap: bool):
         self.ipc, self.a, self.b, self.whole, self.overlap = ipc, bucket_a, bucket_b, whole, overlap
+        # zero-copy mode (set_zero_copy): the fc1 filter gradient, arena [0, zc_off), is produced straight into the
+        # exchange buffer and the optimizer reads the reduced arena from the result buffer; see ipc_allreduce.hip
+        self.zc_off = 0
         if overlap:
             self.side = torch.cuda.Stream(device=whole.device)
             self.ev_fork = torch.cuda.Event()
@@ -77,6 +80,11 @@ class _IpcGradHook:
             self.ev_fork = torch.cuda.Event()
             self.ev_join = torch.cuda.Event()
 
+    def set_zero_copy(self, rest_off: int) -> None:
+        self.zc_off = rest_off
+        if rest_off:
+            self.overlap = False
+
     def after_part1(self, stream) -> None:
         if not self.overlap:
             return
@@ -86,6 +94,10 @@ class _IpcGradHook:
         self.ev_join.record(self.side)
 
     def after_part2(self, stream) -> None:
+        if self.zc_off:
+            self.ipc.all_reduce_zero_copy(self.whole[self.zc_off:], self.zc_off, self.whole.numel(),
+                                          stream=stream.cuda_stream)
+            return
         if not self.overlap:
             self.ipc.all_reduce(self.whole, stream=stream.cuda_stream)
             return
@@ -133,7 +145,7 @@ class DataParallelTrainer:
         self._shared_gpu = False
         if self._multi and self._native and sync and comm in ("auto", "ipc"):
             self._try_ipc(required=(comm == "ipc"))
-            if self.comm == "ipc" and (not self._shared_gpu or os.environ.get("DTF_IPC_FORCE_OVERLAP")):
+            if self.comm == "ipc":
                 self._tune_schedule(allow_rccl=(comm == "auto"))
 
     def _time_transports(self, iters: int = 8, grids=(32, 64, 128)):
@@ -188,7 +200,7 @@ class DataParallelTrainer:
                                                     else (64, 128, 256, 512))
                 self.transport_us = {"ipc": round(t_ipc, 1), "ipc_workgroups": self.ipc.blocks,
                                      "process_group": round(t_pg, 1)}
-                if not required and t_ipc > 1.5 * t_pg:
+                if not required and t_ipc > 1.5 * t_pg and not os.environ.get("DTF_IPC_KEEP"):  # (env: diagnostics)
                     ok, err = False, "IPC all-reduce slower than the process group's (%.0f vs %.0f us)" % (t_ipc, t_pg)
         if ok:
             self.ipc.set_timeout(float(os.environ.get("DTF_IPC_TIMEOUT_S", "30")))
@@ -217,7 +229,11 @@ class DataParallelTrainer:
         forced = os.environ.get("DTF_DP_SCHEDULE", "auto")
         room = e.spe - (e.global_step % e.spe) - 1 if getattr(e, "dataset", None) is not None else steps + 8
         steps = min(steps, room - 8)
-        cands = ["ipc-overlap", "ipc-inline"] + (["rccl"] if allow_rccl and not self._stage_host else [])
+        fc1_end = e.bucket_bounds()[0][0] + e.fc1_grad_numel()  # the fc1 filter gradient leads the arena
+        zc_ok = e.bucket_bounds()[0][0] == 0 and fc1_end % 4 == 0 and (e.G.numel() - fc1_end) % 4 == 0
+        shared = self._shared_gpu and not os.environ.get("DTF_IPC_FORCE_OVERLAP")
+        cands = (["ipc-zerocopy"] if zc_ok else []) + ([] if shared else ["ipc-overlap"]) + ["ipc-inline"] + \
+                (["rccl"] if allow_rccl and not self._stage_host and not shared else [])
         if forced != "auto":
             if forced not in cands:
                 raise ValueError("DTF_DP_SCHEDULE=%s is not available here (%s)" % (forced, cands))
@@ -225,11 +241,14 @@ class DataParallelTrainer:
         hook = e.grad_hook
 
         def use(c: str) -> None:
+            zc = c == "ipc-zerocopy"
+            e.set_grad_redirect(self.ipc.stage_ptr if zc else 0, self.ipc.result_ptr if zc else 0)
             if c == "rccl":
                 e.set_grad_hook(None)
                 self.comm = "rccl"
             else:
                 hook.set_overlap(c == "ipc-overlap")
+                hook.set_zero_copy(fc1_end if zc else 0)
                 e.set_grad_hook(hook)  # (drops the captured graphs)
                 self.comm = "ipc"
 
@@ -305,6 +324,7 @@ class DataParallelTrainer:
     def close(self) -> None:
         """Release the IPC exchange buffers (collective: every rank calls it, before the process group is destroyed)."""
         if self.ipc is not None:
+            self.engine.set_grad_redirect(0, 0)
             self.engine.set_grad_hook(None)
             self.ipc.close()
             self.ipc = None

@@ -35,6 +35,9 @@ def _signatures(lib) -> None:
     lib.dtf_ipc_open_handle.argtypes, lib.dtf_ipc_open_handle.restype = [P, C.POINTER(P)], I
     lib.dtf_ipc_close_handle.argtypes, lib.dtf_ipc_close_handle.restype = [P], I
     lib.dtf_ipc_allreduce.argtypes, lib.dtf_ipc_allreduce.restype = [P, P, P, L, I, P], I
+    lib.dtf_ipc_allreduce_zc.argtypes, lib.dtf_ipc_allreduce_zc.restype = [P, P, L, L, L, I, P], I
+    lib.dtf_ipc_stage_ptr.argtypes, lib.dtf_ipc_stage_ptr.restype = [P], P
+    lib.dtf_ipc_result_ptr.argtypes, lib.dtf_ipc_result_ptr.restype = [P, L], P
     lib._dtf_ipc_sigs = True
 
 
@@ -104,6 +107,30 @@ class IpcAllReduce:
         native.check(self.lib.dtf_ipc_allreduce(C.byref(self.comm), src.data_ptr(), dst.data_ptr(), src.numel(),
                                                 self.blocks if blocks is None else blocks, st),
                      "ipc_allreduce")
+
+    @property
+    def stage_ptr(self) -> int:
+        """Device address of this rank's stage buffer (n_max floats): peers read it during the reduction."""
+        return int(self.lib.dtf_ipc_stage_ptr(self._own))
+
+    @property
+    def result_ptr(self) -> int:
+        """Device address of this rank's result buffer (n_max floats): peers write their reduced slices into it."""
+        return int(self.lib.dtf_ipc_result_ptr(self._own, self.n_max))
+
+    def all_reduce_zero_copy(self, src_rest: torch.Tensor, rest_off: int, n: int, stream: Optional[int] = None,
+                             blocks: Optional[int] = None) -> None:
+        """Sum over ranks of the ``n`` floats whose first ``rest_off`` already sit in this rank's stage buffer (written
+        there by their producer) and whose tail is ``src_rest``; the sum is left in the result buffer (``result_ptr``)
+        for the consumer to read in place.  Between this call and the next one nothing may write the stage buffer
+        except that producer."""
+        if self.comm is None:
+            raise RuntimeError("IPC all-reduce is not usable on this rank: %s" % self.failure)
+        assert src_rest.is_cuda and src_rest.dtype == torch.float32 and src_rest.is_contiguous()
+        assert rest_off % 4 == 0 and src_rest.numel() % 4 == 0 and rest_off + src_rest.numel() == n <= self.n_max
+        st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        native.check(self.lib.dtf_ipc_allreduce_zc(C.byref(self.comm), src_rest.data_ptr(), rest_off, src_rest.numel(), n,
+                                                   self.blocks if blocks is None else blocks, st), "ipc_allreduce_zc")
 
     def set_timeout(self, timeout_s: float) -> None:
         """Bound of every in-kernel wait.  The struct is a by-value kernel argument: call this BEFORE the all-reduce is

@@ -131,20 +131,27 @@ def test_training_reaches_high_accuracy_on_synthetic():
     assert acc2 > 0.8, (loss2, acc2)
 
 
-@pytest.mark.parametrize("comm", ["ipc", "ipc-overlap", "rccl"])
+@pytest.mark.parametrize("comm", ["ipc-zerocopy", "ipc-inline", "ipc-overlap", "ipc-auto", "rccl"])
 def test_native_data_parallel_path_two_ranks_one_gpu(tmp_path, comm):
     """The multi-GPU step with 2 ranks sharing the single test GPU (RCCL refuses duplicate devices, so the process
-    group is gloo): ``ipc`` = fwd+bwd | direct IPC all-reduce | Adam as one hipGraph; ``rccl`` = the collective path
+    group is gloo).  ``ipc-*`` = fwd+bwd | direct IPC all-reduce | Adam as one hipGraph, in each of its schedules
+    (zero-copy: fc1 dW produced into the exchange buffer, Adam reads the result buffer; inline: staged copies;
+    overlap: fc bucket reduced on a forked stream; auto: picked by the start-up trial); ``rccl`` = the collective path
     (part1 graph -> bucket-A all-reduce || part2 graph -> bucket-B all-reduce -> Adam graph), host-staged for gloo."""
     import json
     import os
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = {"ipc": "29577", "ipc-overlap": "29579", "rccl": "29578"}[comm]
+    port = {"ipc-zerocopy": "29577", "ipc-inline": "29576", "ipc-overlap": "29579", "ipc-auto": "29575",
+            "rccl": "29578"}[comm]
     env = dict(os.environ, MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if comm == "ipc-overlap":  # the forked-stream graph variant used when every rank owns a GPU
-        env["DTF_IPC_FORCE_OVERLAP"] = "1"
+    schedule = None
+    if comm.startswith("ipc-"):
+        if comm == "ipc-overlap":  # a candidate only where every rank owns a GPU, unless forced
+            env["DTF_IPC_FORCE_OVERLAP"] = "1"
+        if comm != "ipc-auto":
+            schedule = env["DTF_DP_SCHEDULE"] = comm
         comm = "ipc"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", port, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5",
@@ -155,6 +162,11 @@ def test_native_data_parallel_path_two_ranks_one_gpu(tmp_path, comm):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 200 and out["replicas_in_sync"] is True
     assert out["config"]["gradient_transport"] == comm
+    if schedule is not None:
+        assert out["config"]["dp_schedule"] == schedule
+    elif comm == "ipc":
+        assert out["config"]["dp_schedule"] in out["dp_schedule_us_at_startup"]
+    assert out["ipc_wait_timeouts"] in (0, None)
     assert out["final_train_loss"] < 2.35 and out["value"] > 0
 
 
