@@ -35,6 +35,12 @@ struct MnistEngine {
   // is stored instead of G, and where the optimizer reads the reduced gradients of the whole arena from
   float* G_fc1_dst;
   const float* G_src;
+  // data-parallel "gather" schedule (gather_n = world size, 0 = off): every rank's pool2 / dh as mapped into this
+  // process (exchange buffers of the IpcComm at gather_comm); the fc1 filter gradient is then computed globally
+  const void* gather_A[8];
+  const void* gather_B[8];
+  const void* gather_comm;
+  int gather_n;
 };
 
 #define DTF_TRY(x)            \
@@ -102,11 +108,16 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e, int parts, hipStream_t st) {
     DTF_TRY(dtf_head(&hp, e->head_blocks, st));
     // fc1 dW[3136][1024] = pool2^T * dh  (stored: 12.8 MB, the one gradient that is never re-zeroed) and
     // fc2 dW[1024][10] = h_drop^T * dz, as one grouped launch when the batch fits a single K slab
+    const bool gather = e->gather_n > 0 && trio_ok(e);
+    if (e->gather_n > 0 && !gather) return -22;
+    if (gather)  // publish this rank's fc1 operands (bf16 pool2 [B,3136], dh [B,1024]) and wait for every peer's
+      DTF_TRY(dtf_ipc_publish_sync(e->gather_comm, e->pool2, (long)B * 3136 * 2, e->dh, (long)B * 1024 * 2, 64, st));
     if (trio_ok(e)) {
       // fc1 dW[3136][1024] = pool2^T * dh (stored: 12.8 MB, the one gradient that is never re-zeroed), fc2 dW[1024][10] =
       // h_drop^T * dz and the split-K fc1 data gradient dpool2 += dh * W_fc1^T as one launch
       DTF_TRY(dtf_fc_bwd_trio(e->pool2, e->dh, dW_fc1, 3136, 1024, e->h_drop, e->dz, e->G + e->off_Wfc2, 1024, 10,
-                              B, e->dh, e->P + e->off_Wfc1, e->dpool2, B, 3136, 1024, e->bwd_splits, st));
+                              B, e->dh, e->P + e->off_Wfc1, e->dpool2, B, 3136, 1024, e->bwd_splits, e->gather_A, e->gather_B,
+                              gather ? e->gather_n : 0, st));
     } else if (B <= 128) {
       DTF_TRY(dtf_fc_dw_pair(e->pool2, e->dh, dW_fc1, 3136, 1024, e->h_drop, e->dz, e->G + e->off_Wfc2,
                              1024, 10, B, st));

@@ -81,6 +81,11 @@ struct GemmTrio {
   GemmPair pair;
   GemmParams q;             // data gradient: dX[M][N] += dY[M][K] * W[N][K]^T, split over K
   int nblk_q, q_mt, q_nt;   // its blocks come first: m-tile fastest, then n-tile, then K split
+  // "gather" data parallelism (ipc_allreduce.hip): problem 0 of the pair sums over the operand pairs of all ranks,
+  // read in place from the peers' exchange buffers, instead of being all-reduced afterwards
+  const void* gA[8];
+  const void* gB[8];
+  int granks;  // 0 = off
 };
 using TrioDwA = LoadColK<uint16_t, 128, 256, 128, true>;
 using TrioDwB = LoadColK<uint16_t, 64, 256, 128, false>;
@@ -99,20 +104,32 @@ __global__ __launch_bounds__(256) void fc_bwd_trio_kernel(const GemmTrio g) {
     const int which = j >= g.pair.nblk0;
     const int k = which ? j - g.pair.nblk0 : j;
     const int mt = which ? g.pair.mt1 : g.pair.mt0;
-    dtf_gemm_body<128, 64, 128, 4, 1, TrioDwA, TrioDwB, EpStoreF32>(g.pair.p[which], (k % mt) * 128, (k / mt) * 64, 0, smem,
-                                                                    smem + 128 * (128 + 8));
+    if (which == 0 && g.granks > 0)
+      dtf_gemm_body_ranks<128, 64, 128, 4, 1, TrioDwA, TrioDwB, EpStoreF32>(g.pair.p[0], g.gA, g.gB, g.granks, (k % mt) * 128,
+                                                                            (k / mt) * 64, smem, smem + 128 * (128 + 8));
+    else
+      dtf_gemm_body<128, 64, 128, 4, 1, TrioDwA, TrioDwB, EpStoreF32>(g.pair.p[which], (k % mt) * 128, (k / mt) * 64, 0, smem,
+                                                                      smem + 128 * (128 + 8));
   }
 }
 }  // namespace
 
 // dW0 = X0^T dY0, dW1 = X1^T dY1 (as dtf_fc_dw_pair) and dX[Mq][Nq] += dYq[Mq][Kq] * Wq[Nq][Kq]^T (as dtf_fc_bwd_data with
-// splits > 1: dX pre-zeroed) in one launch.
+// splits > 1: dX pre-zeroed) in one launch.  With granks > 0, dW0 = sum over r < granks of gA[r]^T gB[r] instead (operand
+// pairs of the same shapes as X0 / dY0, e.g. in peer GPUs' exchange buffers; X0 / dY0 themselves are then unused).
 DTF_API int dtf_fc_bwd_trio(const void* X0, const void* dY0, float* dW0, int M0, int N0, const void* X1, const void* dY1,
                             float* dW1, int M1, int N1, int K, const void* dYq, const float* Wq, float* dXq, int Mq, int Nq,
-                            int Kq, int splits, hipStream_t st) {
+                            int Kq, int splits, const void* const* gA, const void* const* gB, int granks, hipStream_t st) {
   if (M0 <= 0 || N0 <= 0 || M1 <= 0 || N1 <= 0 || K <= 0 || K > 128 || M0 % 2 || N0 % 2 || M1 % 2 || N1 % 2) return ERR_SHAPE;
   if (Mq <= 0 || Nq <= 0 || Kq <= 0 || Kq % 8 || splits < 2) return ERR_SHAPE;
+  if (granks < 0 || granks > 8 || (granks > 0 && (!gA || !gB))) return ERR_SHAPE;
   GemmTrio g;
+  g.granks = granks;
+  for (int r = 0; r < 8; ++r) {
+    g.gA[r] = r < granks ? gA[r] : nullptr;
+    g.gB[r] = r < granks ? gB[r] : nullptr;
+    if (r < granks && (!g.gA[r] || !g.gB[r])) return ERR_SHAPE;
+  }
   g.pair.p[0] = base_params(X0, dY0, dW0, M0, N0, K, M0, N0, N0, 1, 128);
   g.pair.p[1] = base_params(X1, dY1, dW1, M1, N1, K, M1, N1, N1, 1, 128);
   g.pair.mt0 = dtf_cdiv(M0, 128);

@@ -600,6 +600,61 @@ __device__ __forceinline__ void dtf_gemm_body(const GemmParams& p, const int m0,
 }
 
 
+// C = sum over `nranks` operand pairs (A_r, B_r) of A_r * B_r, each pair with the same shapes / strides as p (K <= BK: one
+// k-step per pair).  The pairs may live in peer GPUs' memory; pair r+1 is in flight while pair r is multiplied.
+template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP>
+__device__ __forceinline__ void dtf_gemm_body_ranks(const GemmParams& p, const void* const* __restrict__ Ar,
+                                                    const void* const* __restrict__ Br, const int nranks, const int m0,
+                                                    const int n0, uint16_t* __restrict__ As, uint16_t* __restrict__ Bs) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  AL al;
+  BL bl;
+  al.init(p, m0, tid);
+  bl.init(p, n0, tid);
+  al.src = reinterpret_cast<decltype(al.src)>(Ar[0]);
+  bl.src = reinterpret_cast<decltype(bl.src)>(Br[0]);
+  al.load(0, p.K, tid);
+  bl.load(0, p.K, tid);
+  const int r = lane & 31, h = lane >> 5;
+  for (int rk = 0; rk < nranks; ++rk) {
+    __syncthreads();
+    al.store(As, tid);
+    bl.store(Bs, tid);
+    __syncthreads();
+    if (rk + 1 < nranks) {
+      al.src = reinterpret_cast<decltype(al.src)>(Ar[rk + 1]);
+      bl.src = reinterpret_cast<decltype(bl.src)>(Br[rk + 1]);
+      al.load(0, p.K, tid);
+      bl.load(0, p.K, tid);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 16) {
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+        af[a] = *reinterpret_cast<const bf16x8*>(&As[(wm * (BM / WM) + a * 32 + r) * DTF_LDS_STRIDE + kk + 8 * h]);
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+        bfr[b] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * (BN / WN) + b * 32 + r) * DTF_LDS_STRIDE + kk + 8 * h]);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+  }
+  EP::template run<TM, TN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, 0);
+}
+
 template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP>
 __global__ __launch_bounds__(64 * WM * WN) void dtf_gemm_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) uint16_t smem[(BM + BN) * DTF_LDS_STRIDE];

@@ -161,6 +161,33 @@ __global__ __launch_bounds__(64) void ipc_done_kernel(const IpcComm c) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   }
 }
+
+// ---- activation exchange ("gather" schedule).  For a wide dense layer at small batch the operands of the filter-
+// gradient GEMM (x^T [K x batch] and dy [batch x N], bf16) are far smaller than the gradient itself (0.8 MB against
+// 12.8 MB for the MNIST fc1), and xGMI all-reduce time is per-link bound: so every rank publishes its two operand
+// tensors, and every rank computes the GLOBAL gradient  sum_r x_r^T dy_r  itself, reading the peers' operands in
+// place over all links at once (gemm_api.hip: fc_bwd_trio_kernel).  Same rank order everywhere -> bit-identical
+// replicas.  K1 copies the operands into stage[] and bumps the epoch; K2 (one wave) tells every peer "stage holds
+// epoch e" and waits for all of them.  There is no "done" handshake here: the caller runs an all-reduce of the
+// remaining gradients on another IpcComm later in the same step, and no rank enters that before it has finished
+// reading — which is what makes overwriting stage[] in the next step safe.
+__global__ __launch_bounds__(256) void ipc_publish2_kernel(const IpcComm c, const f32x4* __restrict__ s0, long n0,
+                                                           const f32x4* __restrict__ s1, long n1) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *c.epoch += 1u;
+  f32x4* st = reinterpret_cast<f32x4*>(stage_of(c.base[c.rank]));
+  copy_f4(st, s0, n0);
+  copy_f4(st + n0, s1, n1);
+}
+
+__global__ __launch_bounds__(64) void ipc_sync_kernel(const IpcComm c) {
+  const unsigned e = *c.epoch;
+  if (threadIdx.x < c.world) {
+    const int p = threadIdx.x;
+    __hip_atomic_store(&ready_flags(c.base[p])[c.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!wait_flag(&ready_flags(c.base[c.rank])[p], e, c.timeout_ticks)) atomicAdd(c.error, 1u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  }
+}
 }  // namespace
 
 // ---- allocation / handle exchange (host)
@@ -191,6 +218,22 @@ DTF_API int dtf_ipc_close_handle(void* p) { return hipIpcCloseMemHandle(p) == hi
 DTF_API void* dtf_ipc_stage_ptr(void* base) { return reinterpret_cast<unsigned char*>(base) + HDR_BYTES; }
 DTF_API void* dtf_ipc_result_ptr(void* base, long n_max) {
   return reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(base) + HDR_BYTES) + n_max;
+}
+
+// stage[0, bytes0) <- src0, stage[bytes0, bytes0 + bytes1) <- src1 on this rank, then wait until every rank has done the
+// same for this epoch (sizes in bytes, multiples of 16).
+DTF_API int dtf_ipc_publish_sync(const void* comm, const void* src0, long bytes0, const void* src1, long bytes1, int blocks,
+                                 hipStream_t st) {
+  const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
+  if (bytes0 <= 0 || bytes1 < 0 || bytes0 % 16 || bytes1 % 16 || (bytes0 + bytes1) / 4 > c.n_max) return -22;
+  if (c.world < 1 || c.world > MAX_RANKS || c.rank < 0 || c.rank >= c.world) return -22;
+  if (blocks < 1) blocks = 32;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(ipc_publish2_kernel, dim3(blocks), dim3(256), 0, st, c, reinterpret_cast<const f32x4*>(src0), bytes0 / 16,
+                     reinterpret_cast<const f32x4*>(src1), bytes1 / 16);
+  hipLaunchKernelGGL(ipc_sync_kernel, dim3(1), dim3(64), 0, st, c);
+  DTF_CHECK_LAUNCH();
+  return 0;
 }
 
 // Zero-copy all-reduce of n floats: stage[0, rest_off) of this rank already holds its data, src_rest[0, rest_n) is

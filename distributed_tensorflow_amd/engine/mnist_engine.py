@@ -250,6 +250,31 @@ class NativeMnistEngine(_EngineBase):
         self.cfg.G_src = apply_src or None
         self._drop_graph()
 
+    def gather_supported(self) -> bool:
+        """The activation-gather schedule rides on the fused fc backward launch (batch <= 128, split-K data gradient)."""
+        return self.batch_size <= 128 and self.cfg.bwd_splits > 1
+
+    def gather_bytes(self) -> Tuple[int, int]:
+        """Bytes of the two fc1 filter-gradient operands a rank publishes: bf16 pool2 [B,3136] and dh [B,1024]."""
+        return self.batch_size * 3136 * 2, self.batch_size * 1024 * 2
+
+    def set_gather(self, ipc=None) -> None:
+        """Data-parallel "gather" schedule: publish pool2 / dh through ``ipc`` (an IpcAllReduce whose stage buffers are
+        at least gather_bytes() large) after the loss head and compute the fc1 filter gradient over ALL ranks'
+        operands, read in place from the peers' buffers; ``None`` switches it off.  Drops the captured graphs."""
+        if ipc is None:
+            self.cfg.gather_n = 0
+            self.cfg.gather_comm = None
+        else:
+            b0, b1 = self.gather_bytes()
+            assert (b0 + b1) // 4 <= ipc.n_max and self.gather_supported()
+            for p in range(ipc.world):
+                self.cfg.gather_A[p] = ipc.peer_stage_ptr(p)
+                self.cfg.gather_B[p] = ipc.peer_stage_ptr(p) + b0
+            self.cfg.gather_comm = ipc.comm_addr
+            self.cfg.gather_n = ipc.world
+        self._drop_graph()
+
     def set_grad_hook(self, hook) -> None:
         """``hook.after_part1(stream)`` / ``hook.after_part2(stream)`` run inside the ``full`` segment after the fc
         gradients resp. all gradients have been enqueued (``stream`` is the engine's torch stream)."""

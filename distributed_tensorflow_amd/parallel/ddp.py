@@ -68,6 +68,9 @@ class _IpcGradHook:
         # zero-copy mode (set_zero_copy): the fc1 filter gradient, arena [0, zc_off), is produced straight into the
         # exchange buffer and the optimizer reads the reduced arena from the result buffer; see ipc_allreduce.hip
         self.zc_off = 0
+        # gather mode (set_gather): the fc1 filter gradient, arena [0, rest_off), is computed globally from gathered
+        # operands inside the step; only the rest of the arena is all-reduced
+        self.rest_off = 0
         if overlap:
             self.side = torch.cuda.Stream(device=whole.device)
             self.ev_fork = torch.cuda.Event()
@@ -85,6 +88,11 @@ class _IpcGradHook:
         if rest_off:
             self.overlap = False
 
+    def set_gather(self, rest_off: int) -> None:
+        self.rest_off = rest_off
+        if rest_off:
+            self.overlap = False
+
     def after_part1(self, stream) -> None:
         if not self.overlap:
             return
@@ -94,6 +102,9 @@ class _IpcGradHook:
         self.ev_join.record(self.side)
 
     def after_part2(self, stream) -> None:
+        if self.rest_off:
+            self.ipc.all_reduce(self.whole[self.rest_off:], stream=stream.cuda_stream)
+            return
         if self.zc_off:
             self.ipc.all_reduce_zero_copy(self.whole[self.zc_off:], self.zc_off, self.whole.numel(),
                                           stream=stream.cuda_stream)
@@ -142,6 +153,7 @@ class DataParallelTrainer:
             raise ValueError("comm must be auto, ipc or rccl")
         self.schedule_us = None
         self.schedule = None
+        self.ipc_act = None
         self._shared_gpu = False
         if self._multi and self._native and sync and comm in ("auto", "ipc"):
             self._try_ipc(required=(comm == "ipc"))
@@ -232,7 +244,20 @@ class DataParallelTrainer:
         fc1_end = e.bucket_bounds()[0][0] + e.fc1_grad_numel()  # the fc1 filter gradient leads the arena
         zc_ok = e.bucket_bounds()[0][0] == 0 and fc1_end % 4 == 0 and (e.G.numel() - fc1_end) % 4 == 0
         shared = self._shared_gpu and not os.environ.get("DTF_IPC_FORCE_OVERLAP")
-        cands = (["ipc-zerocopy"] if zc_ok else []) + ([] if shared else ["ipc-overlap"]) + ["ipc-inline"] + \
+        # "gather": exchange the fc1 filter gradient's OPERANDS (0.8 MB/rank) instead of the gradient (12.8 MB) through a
+        # second, small exchange buffer; collective set-up, so every rank decides it from the same facts
+        gather_ok = zc_ok and hasattr(e, "gather_supported") and e.gather_supported() and forced in ("auto", "ipc-gather")
+        if gather_ok and self.ipc_act is None:
+            from .ipc_comm import IpcAllReduce
+            self.ipc_act = IpcAllReduce(sum(e.gather_bytes()) // 4, e.device, group=self.group)
+            gather_ok = self.ipc_act.self_test()
+            if gather_ok:
+                self.ipc_act.set_timeout(float(os.environ.get("DTF_IPC_TIMEOUT_S", "30")))
+            else:
+                self.ipc_act.close()
+                self.ipc_act = None
+        cands = (["ipc-gather"] if gather_ok else []) + (["ipc-zerocopy"] if zc_ok else []) + \
+                ([] if shared else ["ipc-overlap"]) + ["ipc-inline"] + \
                 (["rccl"] if allow_rccl and not self._stage_host and not shared else [])
         if forced != "auto":
             if forced not in cands:
@@ -241,46 +266,70 @@ class DataParallelTrainer:
         hook = e.grad_hook
 
         def use(c: str) -> None:
-            zc = c == "ipc-zerocopy"
+            zc, ga = c == "ipc-zerocopy", c == "ipc-gather"
             e.set_grad_redirect(self.ipc.stage_ptr if zc else 0, self.ipc.result_ptr if zc else 0)
+            if hasattr(e, "set_gather"):
+                e.set_gather(self.ipc_act if ga else None)
             if c == "rccl":
                 e.set_grad_hook(None)
                 self.comm = "rccl"
             else:
                 hook.set_overlap(c == "ipc-overlap")
                 hook.set_zero_copy(fc1_end if zc else 0)
+                hook.set_gather(fc1_end if ga else 0)
                 e.set_grad_hook(hook)  # (drops the captured graphs)
                 self.comm = "ipc"
 
         if len(cands) > 1 and steps >= 8:
             with self._ctx():
                 snap = [t.clone() for t in (e.P, e.M, e.V, e.step_t)]
-            done0, times = e._steps_done, []
-            for c in cands:
-                use(c)
-                self.prepare()
-                self.train_steps(8)
-                e.stream.synchronize()
-                dist.barrier(group=self.group)
-                t0 = time.perf_counter()
-                self.train_steps(steps)
-                e.stream.synchronize()
-                times.append((time.perf_counter() - t0) / steps * 1e6)
+            done0, times, grads = e._steps_done, [], []
+            b1 = float(e.cfg.beta1) if hasattr(e, "cfg") else float(getattr(e, "b1", 0.9))
+
+            def restore() -> None:
                 with self._ctx():
                     for t, s0 in zip((e.P, e.M, e.V, e.step_t), snap):
                         t.copy_(s0)
                     e.metrics_ring.zero_()  # (the per-step loss/accuracy slots the trial steps accumulated into)
                 e.stream.synchronize()
                 e._steps_done = done0
-            t = torch.tensor(times, dtype=torch.float64, device="cpu" if self._stage_host else e.device)
+
+            for c in cands:
+                use(c)
+                self.prepare()
+                # one step from the snapshot: Adam's first moment is linear in the gradient, m' = b1*m + (1-b1)*g, which
+                # gives the reduced gradient this schedule produced, wherever it keeps it
+                self.train_steps(1)
+                with self._ctx():
+                    grads.append((e.M - b1 * snap[1]) / (1.0 - b1))
+                self.train_steps(7)
+                e.stream.synchronize()
+                dist.barrier(group=self.group)
+                t0 = time.perf_counter()
+                self.train_steps(steps)
+                e.stream.synchronize()
+                times.append((time.perf_counter() - t0) / steps * 1e6)
+                restore()
+            # every schedule computes the same gradient up to summation order (same batch, same dropout mask: both are
+            # keyed by the step): a candidate that is far from the staged in-stream all-reduce — the path the start-up
+            # self-test validated against the process group — is broken on this machine and is not eligible
+            ref = grads[cands.index("ipc-inline")]
+            with self._ctx():
+                off = [float((g - ref).norm() / (ref.norm() + 1e-30)) for g in grads]
+            del grads
+            t = torch.tensor(times + off, dtype=torch.float64, device="cpu" if self._stage_host else e.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            times = t.cpu().tolist()
+            t = t.cpu().tolist()
+            times, off = t[:len(cands)], t[len(cands):]
             self.schedule_us = {c: round(v, 1) for c, v in zip(cands, times)}
-            cands = [cands[min(range(len(cands)), key=lambda i: times[i])]]
+            self.schedule_deviation = {c: float("%.3g" % v) for c, v in zip(cands, off)}
+            good = [i for i in range(len(cands)) if off[i] < 0.02]
+            cands = [cands[min(good, key=lambda i: times[i])]]
         use(cands[0])
         self.schedule = cands[0]
         if self.rank == 0:
-            print("data-parallel step schedule: %s %s" % (self.schedule, self.schedule_us or ""), flush=True)
+            print("data-parallel step schedule: %s %s gradient deviation from the staged all-reduce %s" % (
+                self.schedule, self.schedule_us or "", getattr(self, "schedule_deviation", "")), flush=True)
 
     # ------------------------------------------------------------------ collectives
     def _ctx(self):
@@ -325,7 +374,12 @@ class DataParallelTrainer:
         """Release the IPC exchange buffers (collective: every rank calls it, before the process group is destroyed)."""
         if self.ipc is not None:
             self.engine.set_grad_redirect(0, 0)
+            if hasattr(self.engine, "set_gather"):
+                self.engine.set_gather(None)
             self.engine.set_grad_hook(None)
+            if self.ipc_act is not None:
+                self.ipc_act.close()
+                self.ipc_act = None
             self.ipc.close()
             self.ipc = None
             self.comm = "rccl"

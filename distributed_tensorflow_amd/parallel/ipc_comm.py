@@ -36,6 +36,7 @@ def _signatures(lib) -> None:
     lib.dtf_ipc_close_handle.argtypes, lib.dtf_ipc_close_handle.restype = [P], I
     lib.dtf_ipc_allreduce.argtypes, lib.dtf_ipc_allreduce.restype = [P, P, P, L, I, P], I
     lib.dtf_ipc_allreduce_zc.argtypes, lib.dtf_ipc_allreduce_zc.restype = [P, P, L, L, L, I, P], I
+    lib.dtf_ipc_publish_sync.argtypes, lib.dtf_ipc_publish_sync.restype = [P, P, L, P, L, I, P], I
     lib.dtf_ipc_stage_ptr.argtypes, lib.dtf_ipc_stage_ptr.restype = [P], P
     lib.dtf_ipc_result_ptr.argtypes, lib.dtf_ipc_result_ptr.restype = [P, L], P
     lib._dtf_ipc_sigs = True
@@ -87,6 +88,7 @@ class IpcAllReduce:
                                  "hipIpcOpenMemHandle (rank %d -> %d)" % (self.rank, p))
                     bases[p] = ptr.value
                     self._mapped.append(ptr.value)
+                self._bases = [int(bases[p]) for p in range(self.world)]
                 self._words = torch.zeros(2, dtype=torch.int32, device=self.device)  # epoch, error
                 self.comm = _IpcCommStruct(self.rank, self.world, self.n_max, bases, self._words.data_ptr(),
                                            self._words.data_ptr() + 4, int(timeout_s * 100e6))
@@ -117,6 +119,15 @@ class IpcAllReduce:
     def result_ptr(self) -> int:
         """Device address of this rank's result buffer (n_max floats): peers write their reduced slices into it."""
         return int(self.lib.dtf_ipc_result_ptr(self._own, self.n_max))
+
+    @property
+    def comm_addr(self) -> int:
+        """Host address of the communicator struct (kept alive by this object), for native callers."""
+        return C.addressof(self.comm)
+
+    def peer_stage_ptr(self, p: int) -> int:
+        """Device address, in THIS process, of rank ``p``'s stage buffer."""
+        return int(self.lib.dtf_ipc_stage_ptr(self._bases[p]))
 
     def all_reduce_zero_copy(self, src_rest: torch.Tensor, rest_off: int, n: int, stream: Optional[int] = None,
                              blocks: Optional[int] = None) -> None:

@@ -131,11 +131,11 @@ def test_training_reaches_high_accuracy_on_synthetic():
     assert acc2 > 0.8, (loss2, acc2)
 
 
-@pytest.mark.parametrize("comm", ["ipc-zerocopy", "ipc-inline", "ipc-overlap", "ipc-auto", "rccl"])
+@pytest.mark.parametrize("comm", ["ipc-gather", "ipc-zerocopy", "ipc-inline", "ipc-overlap", "ipc-auto", "rccl"])
 def test_native_data_parallel_path_two_ranks_one_gpu(tmp_path, comm):
     """The multi-GPU step with 2 ranks sharing the single test GPU (RCCL refuses duplicate devices, so the process
     group is gloo).  ``ipc-*`` = fwd+bwd | direct IPC all-reduce | Adam as one hipGraph, in each of its schedules
-    (zero-copy: fc1 dW produced into the exchange buffer, Adam reads the result buffer; inline: staged copies;
+    (gather: fc1 dW computed over all ranks' published operands; zero-copy: fc1 dW produced into the exchange buffer, Adam reads the result buffer; inline: staged copies;
     overlap: fc bucket reduced on a forked stream; auto: picked by the start-up trial); ``rccl`` = the collective path
     (part1 graph -> bucket-A all-reduce || part2 graph -> bucket-B all-reduce -> Adam graph), host-staged for gloo."""
     import json
@@ -143,7 +143,7 @@ def test_native_data_parallel_path_two_ranks_one_gpu(tmp_path, comm):
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = {"ipc-zerocopy": "29577", "ipc-inline": "29576", "ipc-overlap": "29579", "ipc-auto": "29575",
+    port = {"ipc-gather": "29574", "ipc-zerocopy": "29577", "ipc-inline": "29576", "ipc-overlap": "29579", "ipc-auto": "29575",
             "rccl": "29578"}[comm]
     env = dict(os.environ, MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
     schedule = None
