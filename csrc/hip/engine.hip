@@ -40,7 +40,7 @@ struct MnistEngine {
   const void* gather_A[8];
   const void* gather_B[8];
   const void* gather_comm;
-  int gather_n;
+  int gather_n, gather_rank;
 };
 
 #define DTF_TRY(x)            \
@@ -72,9 +72,18 @@ static int effective_splits(int K, int splits, int BK = 64) {  // mirrors base_p
 //   head -> [fc1 dW | fc2 dW | fc1 bwd-data] -> conv2 bwd-data -> [conv2 dW | conv1 dW] -> Adam
 static bool trio_ok(const MnistEngine* e) { return e->B <= 128 && effective_splits(1024, e->bwd_splits) > 1; }
 
-DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e, int parts, hipStream_t st) {
-  const int B = e->B;
-  if (B <= 0 || B > e->maxB) return -22;
+DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st) {
+  const int B = e_in->B;
+  if (B <= 0 || B > e_in->maxB) return -22;
+  // gather schedule: this step's pool2 / dh live in this rank's exchange buffer, where the peers read them in place
+  // (evaluation keeps the engine's own, larger buffers)
+  MnistEngine loc = *e_in;
+  const MnistEngine* e = &loc;
+  if (loc.gather_n > 0) {
+    if (!trio_ok(e_in) || loc.gather_rank < 0 || loc.gather_rank >= loc.gather_n || loc.gather_n > 8) return -22;
+    loc.pool2 = const_cast<void*>(loc.gather_A[loc.gather_rank]);
+    loc.dh = const_cast<void*>(loc.gather_B[loc.gather_rank]);
+  }
   if (e->G_fc1_dst && e->off_Wfc1 != 0) return -22;
   float* const dW_fc1 = e->G_fc1_dst ? e->G_fc1_dst : e->G + e->off_Wfc1;
   if (parts & 1) {
@@ -108,10 +117,9 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e, int parts, hipStream_t st) {
     DTF_TRY(dtf_head(&hp, e->head_blocks, st));
     // fc1 dW[3136][1024] = pool2^T * dh  (stored: 12.8 MB, the one gradient that is never re-zeroed) and
     // fc2 dW[1024][10] = h_drop^T * dz, as one grouped launch when the batch fits a single K slab
-    const bool gather = e->gather_n > 0 && trio_ok(e);
-    if (e->gather_n > 0 && !gather) return -22;
-    if (gather)  // publish this rank's fc1 operands (bf16 pool2 [B,3136], dh [B,1024]) and wait for every peer's
-      DTF_TRY(dtf_ipc_publish_sync(e->gather_comm, e->pool2, (long)B * 3136 * 2, e->dh, (long)B * 1024 * 2, 64, st));
+    const bool gather = e->gather_n > 0;
+    if (gather)  // this rank's fc1 operands (bf16 pool2 [B,3136], dh [B,1024]) are complete: tell the peers, wait for theirs
+      DTF_TRY(dtf_ipc_sync(e->gather_comm, st));
     if (trio_ok(e)) {
       // fc1 dW[3136][1024] = pool2^T * dh (stored: 12.8 MB, the one gradient that is never re-zeroed), fc2 dW[1024][10] =
       // h_drop^T * dz and the split-K fc1 data gradient dpool2 += dh * W_fc1^T as one launch

@@ -167,25 +167,47 @@ __global__ __launch_bounds__(64) void ipc_done_kernel(const IpcComm c) {
 // 12.8 MB for the MNIST fc1), and xGMI all-reduce time is per-link bound: so every rank publishes its two operand
 // tensors, and every rank computes the GLOBAL gradient  sum_r x_r^T dy_r  itself, reading the peers' operands in
 // place over all links at once (gemm_api.hip: fc_bwd_trio_kernel).  Same rank order everywhere -> bit-identical
-// replicas.  K1 copies the operands into stage[] and bumps the epoch; K2 (one wave) tells every peer "stage holds
-// epoch e" and waits for all of them.  There is no "done" handshake here: the caller runs an all-reduce of the
-// remaining gradients on another IpcComm later in the same step, and no rank enters that before it has finished
-// reading — which is what makes overwriting stage[] in the next step safe.
-__global__ __launch_bounds__(256) void ipc_publish2_kernel(const IpcComm c, const f32x4* __restrict__ s0, long n0,
-                                                           const f32x4* __restrict__ s1, long n1) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *c.epoch += 1u;
-  f32x4* st = reinterpret_cast<f32x4*>(stage_of(c.base[c.rank]));
-  copy_f4(st, s0, n0);
-  copy_f4(st + n0, s1, n1);
-}
-
+// replicas.  The operands are produced straight into stage[] (the step executor points its pool2 / dh buffers there); a
+// one-wave kernel then bumps the epoch, tells every peer "stage holds epoch e" and waits for all of them.  There is no
+// "done" handshake here: the caller runs an all-reduce of the remaining gradients on another IpcComm later in the same
+// step, and no rank enters that before it has finished reading — which is what makes overwriting stage[] in the next
+// step safe.
 __global__ __launch_bounds__(64) void ipc_sync_kernel(const IpcComm c) {
-  const unsigned e = *c.epoch;
+  const unsigned e = *c.epoch + 1u;  // (one wave: every lane reads before lane 0 writes)
+  if (threadIdx.x == 0) *c.epoch = e;
   if (threadIdx.x < c.world) {
     const int p = threadIdx.x;
     __hip_atomic_store(&ready_flags(c.base[p])[c.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (!wait_flag(&ready_flags(c.base[c.rank])[p], e, c.timeout_ticks)) atomicAdd(c.error, 1u);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  }
+}
+
+// One-shot all-reduce for small buffers: after the publish kernel every rank sums ALL ranks' stage buffers itself (rank
+// order: bit-identical everywhere) straight into dst — one exchange phase and one kernel less than the two-shot form,
+// at N x the read volume.  No "done" handshake: see dtf_ipc_allreduce_oneshot for the contract.
+__global__ __launch_bounds__(256) void ipc_reduce_all_kernel(const IpcComm c, float* __restrict__ dst, long n) {
+  const unsigned e = *c.epoch;
+  if (threadIdx.x < c.world) {
+    const int p = threadIdx.x;
+    if (blockIdx.x == 0)
+      __hip_atomic_store(&ready_flags(c.base[p])[c.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!wait_flag(&ready_flags(c.base[c.rank])[p], e, c.timeout_ticks) && blockIdx.x == 0) atomicAdd(c.error, 1u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  }
+  __syncthreads();
+  const long n4 = n >> 2;
+  f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 v[MAX_RANKS];
+#pragma unroll
+    for (int p = 0; p < MAX_RANKS; ++p)
+      if (p < c.world) v[p] = reinterpret_cast<const f32x4*>(stage_of(c.base[p]))[i];
+    f32x4 s0 = v[0];
+#pragma unroll
+    for (int p = 1; p < MAX_RANKS; ++p)
+      if (p < c.world) s0 += v[p];
+    d4[i] = s0;
   }
 }
 }  // namespace
@@ -220,18 +242,30 @@ DTF_API void* dtf_ipc_result_ptr(void* base, long n_max) {
   return reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(base) + HDR_BYTES) + n_max;
 }
 
-// stage[0, bytes0) <- src0, stage[bytes0, bytes0 + bytes1) <- src1 on this rank, then wait until every rank has done the
-// same for this epoch (sizes in bytes, multiples of 16).
-DTF_API int dtf_ipc_publish_sync(const void* comm, const void* src0, long bytes0, const void* src1, long bytes1, int blocks,
-                                 hipStream_t st) {
+// Barrier over the ranks of `comm` on the stream (one wave): bumps the epoch, tells every peer, waits for every peer.
+// What it orders is up to the caller: here, "my fc1 operands for this step are in my stage buffer" (their producers
+// write them there directly, stream-ordered before this kernel).
+DTF_API int dtf_ipc_sync(const void* comm, hipStream_t st) {
   const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
-  if (bytes0 <= 0 || bytes1 < 0 || bytes0 % 16 || bytes1 % 16 || (bytes0 + bytes1) / 4 > c.n_max) return -22;
   if (c.world < 1 || c.world > MAX_RANKS || c.rank < 0 || c.rank >= c.world) return -22;
-  if (blocks < 1) blocks = 32;
-  if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL(ipc_publish2_kernel, dim3(blocks), dim3(256), 0, st, c, reinterpret_cast<const f32x4*>(src0), bytes0 / 16,
-                     reinterpret_cast<const f32x4*>(src1), bytes1 / 16);
   hipLaunchKernelGGL(ipc_sync_kernel, dim3(1), dim3(64), 0, st, c);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// dst <- sum over ranks of src (n floats, n % 4 == 0), two kernels.  CONTRACT: a rank overwrites its stage buffer at its
+// next call, so between two calls every rank must pass some other barrier over the same ranks (in the gather schedule:
+// the operand exchange's dtf_ipc_sync at the start of the next step, which no rank reaches before this reduction of
+// the previous step has finished on it).
+DTF_API int dtf_ipc_allreduce_oneshot(const void* comm, const float* src, float* dst, long n, int blocks, hipStream_t st) {
+  const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
+  if (n <= 0 || n % 4 || n > c.n_max || c.world < 1 || c.world > MAX_RANKS || c.rank < 0 || c.rank >= c.world) return -22;
+  if (blocks < 1) blocks = 32;
+  const long want = (n / 4 + 255) / 256;
+  if (blocks > want) blocks = (int)want;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(ipc_publish_kernel, dim3(blocks), dim3(256), 0, st, c, src, n);
+  hipLaunchKernelGGL(ipc_reduce_all_kernel, dim3(blocks), dim3(256), 0, st, c, dst, n);
   DTF_CHECK_LAUNCH();
   return 0;
 }

@@ -259,9 +259,10 @@ class NativeMnistEngine(_EngineBase):
         return self.batch_size * 3136 * 2, self.batch_size * 1024 * 2
 
     def set_gather(self, ipc=None) -> None:
-        """Data-parallel "gather" schedule: publish pool2 / dh through ``ipc`` (an IpcAllReduce whose stage buffers are
-        at least gather_bytes() large) after the loss head and compute the fc1 filter gradient over ALL ranks'
-        operands, read in place from the peers' buffers; ``None`` switches it off.  Drops the captured graphs."""
+        """Data-parallel "gather" schedule: a training step keeps its pool2 / dh in this rank's stage buffer of ``ipc``
+        (an IpcAllReduce whose stage buffers are at least gather_bytes() large), ranks meet after the loss head, and the
+        fc1 filter gradient is computed over ALL ranks' operands, read in place from the peers' buffers; ``None``
+        switches it off.  Drops the captured graphs."""
         if ipc is None:
             self.cfg.gather_n = 0
             self.cfg.gather_comm = None
@@ -273,6 +274,7 @@ class NativeMnistEngine(_EngineBase):
                 self.cfg.gather_B[p] = ipc.peer_stage_ptr(p) + b0
             self.cfg.gather_comm = ipc.comm_addr
             self.cfg.gather_n = ipc.world
+            self.cfg.gather_rank = ipc.rank
         self._drop_graph()
 
     def set_grad_hook(self, hook) -> None:

@@ -103,7 +103,9 @@ class _IpcGradHook:
 
     def after_part2(self, stream) -> None:
         if self.rest_off:
-            self.ipc.all_reduce(self.whole[self.rest_off:], stream=stream.cuda_stream)
+            # (one-shot form: its "next call only after another barrier" contract is met by the operand exchange's
+            # barrier after the next step's loss head)
+            self.ipc.all_reduce_oneshot(self.whole[self.rest_off:], stream=stream.cuda_stream)
             return
         if self.zc_off:
             self.ipc.all_reduce_zero_copy(self.whole[self.zc_off:], self.zc_off, self.whole.numel(),

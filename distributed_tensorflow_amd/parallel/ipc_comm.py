@@ -36,7 +36,7 @@ def _signatures(lib) -> None:
     lib.dtf_ipc_close_handle.argtypes, lib.dtf_ipc_close_handle.restype = [P], I
     lib.dtf_ipc_allreduce.argtypes, lib.dtf_ipc_allreduce.restype = [P, P, P, L, I, P], I
     lib.dtf_ipc_allreduce_zc.argtypes, lib.dtf_ipc_allreduce_zc.restype = [P, P, L, L, L, I, P], I
-    lib.dtf_ipc_publish_sync.argtypes, lib.dtf_ipc_publish_sync.restype = [P, P, L, P, L, I, P], I
+    lib.dtf_ipc_allreduce_oneshot.argtypes, lib.dtf_ipc_allreduce_oneshot.restype = [P, P, P, L, I, P], I
     lib.dtf_ipc_stage_ptr.argtypes, lib.dtf_ipc_stage_ptr.restype = [P], P
     lib.dtf_ipc_result_ptr.argtypes, lib.dtf_ipc_result_ptr.restype = [P, L], P
     lib._dtf_ipc_sigs = True
@@ -119,6 +119,19 @@ class IpcAllReduce:
     def result_ptr(self) -> int:
         """Device address of this rank's result buffer (n_max floats): peers write their reduced slices into it."""
         return int(self.lib.dtf_ipc_result_ptr(self._own, self.n_max))
+
+    def all_reduce_oneshot(self, src: torch.Tensor, dst: Optional[torch.Tensor] = None, stream: Optional[int] = None,
+                           blocks: int = 64) -> None:
+        """Small-buffer all-reduce in two kernels (every rank sums all ranks' buffers itself).  Contract: between two
+        calls every rank passes another barrier over the same ranks (see ``dtf_ipc_allreduce_oneshot``)."""
+        dst = src if dst is None else dst
+        if self.comm is None:
+            raise RuntimeError("IPC all-reduce is not usable on this rank: %s" % self.failure)
+        assert src.is_cuda and src.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous()
+        assert src.numel() == dst.numel() and src.numel() % 4 == 0 and src.numel() <= self.n_max
+        st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        native.check(self.lib.dtf_ipc_allreduce_oneshot(C.byref(self.comm), src.data_ptr(), dst.data_ptr(), src.numel(),
+                                                        blocks, st), "ipc_allreduce_oneshot")
 
     @property
     def comm_addr(self) -> int:
