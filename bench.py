@@ -147,7 +147,7 @@ def main():
             "final_train_loss": last_loss,
             "replicas_in_sync": in_sync,
             "dp_schedule_us_at_startup": getattr(trainer, "schedule_us", None),
-            "ipc_wait_timeouts": trainer.ipc.errors() if trainer.ipc is not None else None,
+            "ipc_wait_timeouts": trainer.transport_errors() if trainer.ipc is not None else None,
             "allreduce_us_at_startup": trainer.transport_us,
         }
         print(json.dumps(out), flush=True)

@@ -386,11 +386,15 @@ class DataParallelTrainer:
             self.ipc = None
             self.comm = "rccl"
 
+    def transport_errors(self) -> int:
+        """Expired in-kernel waits of the IPC exchanges so far (synchronises); 0 when IPC is not in use."""
+        return sum(c.errors() for c in (self.ipc, self.ipc_act) if c is not None)
+
     def check_transport(self) -> None:
         """Raise if an in-kernel wait of the IPC all-reduce ever expired (a peer stalled for longer than the bound, so
         some step used an incomplete gradient sum).  Called at logging points; synchronises."""
         if self.ipc is not None:
-            n = self.ipc.errors()
+            n = self.transport_errors()
             if n:
                 raise RuntimeError("IPC gradient all-reduce: %d wait(s) timed out on rank %d; a peer stalled or died" %
                                    (n, self.rank))
