@@ -92,7 +92,10 @@ using TrioDwB = LoadColK<uint16_t, 64, 256, 128, false>;
 using TrioBdA = LoadRowK<uint16_t, 128, 256, 64, true>;
 using TrioBdB = LoadRowK<float, 64, 256, 64, false>;
 
-__global__ __launch_bounds__(256) void fc_bwd_trio_kernel(const GemmTrio g) {
+// (GATHER is a template parameter, not a run-time branch: with both bodies in one kernel the register allocation of
+// the plain path grew enough to lose a resident workgroup per CU, +9 us on the step)
+template <bool GATHER>
+__global__ __launch_bounds__(256, 2) void fc_bwd_trio_kernel(const GemmTrio g) {
   __shared__ __attribute__((aligned(16))) uint16_t smem[(128 + 64) * (128 + 8)];  // the larger instantiation (BK = 128)
   const int id = blockIdx.x;
   if (id < g.nblk_q) {
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256) void fc_bwd_trio_kernel(const GemmTrio g) {
     const int which = j >= g.pair.nblk0;
     const int k = which ? j - g.pair.nblk0 : j;
     const int mt = which ? g.pair.mt1 : g.pair.mt0;
-    if (which == 0 && g.granks > 0)
+    if (GATHER && which == 0)
       dtf_gemm_body_ranks<128, 64, 128, 4, 1, TrioDwA, TrioDwB, EpStoreF32>(g.pair.p[0], g.gA, g.gB, g.granks, (k % mt) * 128,
                                                                             (k / mt) * 64, smem, smem + 128 * (128 + 8));
     else
@@ -142,7 +145,10 @@ DTF_API int dtf_fc_bwd_trio(const void* X0, const void* dY0, float* dW0, int M0,
   g.q_mt = dtf_cdiv(Mq, 128);
   g.q_nt = dtf_cdiv(Nq, 64);
   g.nblk_q = g.q_mt * g.q_nt * s;
-  hipLaunchKernelGGL(fc_bwd_trio_kernel, dim3(g.nblk_q + npair), dim3(256), 0, st, g);
+  if (granks > 0)
+    hipLaunchKernelGGL(fc_bwd_trio_kernel<true>, dim3(g.nblk_q + npair), dim3(256), 0, st, g);
+  else
+    hipLaunchKernelGGL(fc_bwd_trio_kernel<false>, dim3(g.nblk_q + npair), dim3(256), 0, st, g);
   DTF_CHECK_LAUNCH();
   return 0;
 }
