@@ -41,6 +41,8 @@ struct MnistEngine {
   const void* gather_B[8];
   const void* gather_comm;
   int gather_n, gather_rank;
+  void* gather_local;  // [gather_n][gather_bytes]: local copies of the peers' operands (what gather_A/B point at for peers)
+  long gather_bytes;   // bytes of (pool2, dh) per rank
 };
 
 #define DTF_TRY(x)            \
@@ -118,8 +120,13 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
     // fc1 dW[3136][1024] = pool2^T * dh  (stored: 12.8 MB, the one gradient that is never re-zeroed) and
     // fc2 dW[1024][10] = h_drop^T * dz, as one grouped launch when the batch fits a single K slab
     const bool gather = e->gather_n > 0;
-    if (gather)  // this rank's fc1 operands (bf16 pool2 [B,3136], dh [B,1024]) are complete: tell the peers, wait for theirs
+    if (gather) {
+      // this rank's fc1 operands (bf16 pool2 [B,3136], dh [B,1024]) are complete: tell the peers, wait for theirs, and
+      // pull theirs into local memory (one pass over each xGMI link)
+      if (e->gather_bytes != (long)B * (3136 + 1024) * 2 || !e->gather_local) return -22;
       DTF_TRY(dtf_ipc_sync(e->gather_comm, st));
+      DTF_TRY(dtf_ipc_gather_copy(e->gather_comm, e->gather_local, e->gather_bytes, 16, st));
+    }
     if (trio_ok(e)) {
       // fc1 dW[3136][1024] = pool2^T * dh (stored: 12.8 MB, the one gradient that is never re-zeroed), fc2 dW[1024][10] =
       // h_drop^T * dz and the split-K fc1 data gradient dpool2 += dh * W_fc1^T as one launch

@@ -183,6 +183,31 @@ __global__ __launch_bounds__(64) void ipc_sync_kernel(const IpcComm c) {
   }
 }
 
+// After the barrier: pull every peer's operands (stage[0, n4) in 16-byte units) into local memory, dst[p][n4], once.  The
+// GEMM that consumes them re-reads every operand tile from 16-25 workgroups; peer memory is not cached in the reader's
+// L2, so reading it in place would put that factor on the xGMI links (15 MB instead of 0.8 MB per peer and step).
+__global__ __launch_bounds__(256) void ipc_gather_copy_kernel(const IpcComm c, f32x4* __restrict__ dst, long n4,
+                                                             int blocks_per_peer) {
+  const int slot = blockIdx.x / blocks_per_peer, sub = blockIdx.x % blocks_per_peer;
+  const int p = slot + (slot >= c.rank ? 1 : 0);  // peers only: this rank's own operands are read from its stage buffer
+  if (p >= c.world) return;
+  const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(stage_of(c.base[p]));
+  f32x4* __restrict__ d = dst + (long)p * n4;
+  for (long base = (long)sub * 256 * COPY_U + threadIdx.x; base < n4; base += (long)blocks_per_peer * 256 * COPY_U) {
+    f32x4 v[COPY_U];
+#pragma unroll
+    for (int u = 0; u < COPY_U; ++u) {
+      const long i = base + u * 256;
+      v[u] = src[i < n4 ? i : base];
+    }
+#pragma unroll
+    for (int u = 0; u < COPY_U; ++u) {
+      const long i = base + u * 256;
+      if (i < n4) d[i] = v[u];
+    }
+  }
+}
+
 // One-shot all-reduce for small buffers: after the publish kernel every rank sums ALL ranks' stage buffers itself (rank
 // order: bit-identical everywhere) straight into dst — one exchange phase and one kernel less than the two-shot form,
 // at N x the read volume.  No "done" handshake: see dtf_ipc_allreduce_oneshot for the contract.
@@ -249,6 +274,19 @@ DTF_API int dtf_ipc_sync(const void* comm, hipStream_t st) {
   const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
   if (c.world < 1 || c.world > MAX_RANKS || c.rank < 0 || c.rank >= c.world) return -22;
   hipLaunchKernelGGL(ipc_sync_kernel, dim3(1), dim3(64), 0, st, c);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// dst[p][bytes] <- rank p's stage[0, bytes) for every peer p != rank (dst row `rank` is left alone); call after dtf_ipc_sync.
+DTF_API int dtf_ipc_gather_copy(const void* comm, void* dst, long bytes, int blocks_per_peer, hipStream_t st) {
+  const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
+  if (!dst || bytes <= 0 || bytes % 16 || bytes / 4 > c.n_max || c.world < 1 || c.world > MAX_RANKS) return -22;
+  if (c.world == 1) return 0;
+  if (blocks_per_peer < 1) blocks_per_peer = 16;
+  if (blocks_per_peer > 64) blocks_per_peer = 64;
+  hipLaunchKernelGGL(ipc_gather_copy_kernel, dim3((c.world - 1) * blocks_per_peer), dim3(256), 0, st, c,
+                     reinterpret_cast<f32x4*>(dst), bytes / 16, blocks_per_peer);
   DTF_CHECK_LAUNCH();
   return 0;
 }

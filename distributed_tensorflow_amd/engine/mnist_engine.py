@@ -267,12 +267,20 @@ class NativeMnistEngine(_EngineBase):
         if ipc is None:
             self.cfg.gather_n = 0
             self.cfg.gather_comm = None
+            self.cfg.gather_local = None
+            self._gather_buf = None
         else:
             b0, b1 = self.gather_bytes()
             assert (b0 + b1) // 4 <= ipc.n_max and self.gather_supported()
+            # the peers' operands are pulled into this buffer once per step (peer memory is not cached by the reader's L2,
+            # and the GEMM re-reads every tile from many workgroups); this rank's own are read from its stage buffer
+            self._gather_buf = torch.empty(ipc.world * (b0 + b1), dtype=torch.uint8, device=self.device)
+            self.cfg.gather_local = self._gather_buf.data_ptr()
+            self.cfg.gather_bytes = b0 + b1
             for p in range(ipc.world):
-                self.cfg.gather_A[p] = ipc.peer_stage_ptr(p)
-                self.cfg.gather_B[p] = ipc.peer_stage_ptr(p) + b0
+                base = ipc.peer_stage_ptr(p) if p == ipc.rank else self._gather_buf.data_ptr() + p * (b0 + b1)
+                self.cfg.gather_A[p] = base
+                self.cfg.gather_B[p] = base + b0
             self.cfg.gather_comm = ipc.comm_addr
             self.cfg.gather_n = ipc.world
             self.cfg.gather_rank = ipc.rank
