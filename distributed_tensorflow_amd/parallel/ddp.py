@@ -282,7 +282,11 @@ class DataParallelTrainer:
                 e.set_grad_hook(hook)  # (drops the captured graphs)
                 self.comm = "ipc"
 
-        if len(cands) > 1 and steps >= 8:
+        # (a forced schedule other than the reference is still checked against it)
+        trial = cands if len(cands) > 1 or cands == ["ipc-inline"] else cands + ["ipc-inline"]
+        timed = steps >= 8 and len(cands) > 1
+        if len(trial) > 1 and room >= 2:
+            cands = trial
             with self._ctx():
                 snap = [t.clone() for t in (e.P, e.M, e.V, e.step_t)]
             done0, times, grads = e._steps_done, [], []
@@ -304,13 +308,16 @@ class DataParallelTrainer:
                 self.train_steps(1)
                 with self._ctx():
                     grads.append((e.M - b1 * snap[1]) / (1.0 - b1))
-                self.train_steps(7)
-                e.stream.synchronize()
-                dist.barrier(group=self.group)
-                t0 = time.perf_counter()
-                self.train_steps(steps)
-                e.stream.synchronize()
-                times.append((time.perf_counter() - t0) / steps * 1e6)
+                if timed:
+                    self.train_steps(7)
+                    e.stream.synchronize()
+                    dist.barrier(group=self.group)
+                    t0 = time.perf_counter()
+                    self.train_steps(steps)
+                    e.stream.synchronize()
+                    times.append((time.perf_counter() - t0) / steps * 1e6)
+                else:
+                    times.append(float(len(times)))  # untimed: keep the order of preference
                 restore()
             # every schedule computes the same gradient up to summation order (same batch, same dropout mask: both are
             # keyed by the step): a candidate that is far from the staged in-stream all-reduce — the path the start-up
@@ -323,9 +330,11 @@ class DataParallelTrainer:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
             t = t.cpu().tolist()
             times, off = t[:len(cands)], t[len(cands):]
-            self.schedule_us = {c: round(v, 1) for c, v in zip(cands, times)}
+            self.schedule_us = {c: round(v, 1) for c, v in zip(cands, times)} if timed else None
             self.schedule_deviation = {c: float("%.3g" % v) for c, v in zip(cands, off)}
-            good = [i for i in range(len(cands)) if off[i] < 0.02]
+            good = [i for i in range(len(cands)) if off[i] < 0.02 and (forced == "auto" or cands[i] == forced)]
+            if not good:
+                raise RuntimeError("schedule %s disagrees with the staged all-reduce: %s" % (forced, self.schedule_deviation))
             cands = [cands[min(good, key=lambda i: times[i])]]
         use(cands[0])
         self.schedule = cands[0]
