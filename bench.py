@@ -101,6 +101,8 @@ def main():
     trainer.prepare()  # graph capture only: nothing executes
     trainer.train_steps(args.warmup)
     sync()
+    if world > 1:
+        trainer.ensure_healthy()  # (IPC waits timed out during warm-up -> every rank switches to RCCL before the clock starts)
     t0 = time.perf_counter()
     trainer.train_steps(args.steps)
     sync()

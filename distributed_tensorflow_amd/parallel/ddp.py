@@ -265,22 +265,23 @@ class DataParallelTrainer:
             if forced not in cands:
                 raise ValueError("DTF_DP_SCHEDULE=%s is not available here (%s)" % (forced, cands))
             cands = [forced]
-        hook = e.grad_hook
+        self._ipc_hook, self._fc1_end = e.grad_hook, fc1_end
+        use = self._use_schedule
+        op_timeout = float(os.environ.get("DTF_IPC_TIMEOUT_S", "30"))
 
-        def use(c: str) -> None:
-            zc, ga = c == "ipc-zerocopy", c == "ipc-gather"
-            e.set_grad_redirect(self.ipc.stage_ptr if zc else 0, self.ipc.result_ptr if zc else 0)
-            if hasattr(e, "set_gather"):
-                e.set_gather(self.ipc_act if ga else None)
-            if c == "rccl":
-                e.set_grad_hook(None)
-                self.comm = "rccl"
-            else:
-                hook.set_overlap(c == "ipc-overlap")
-                hook.set_zero_copy(fc1_end if zc else 0)
-                hook.set_gather(fc1_end if ga else 0)
-                e.set_grad_hook(hook)  # (drops the captured graphs)
-                self.comm = "ipc"
+        def set_timeouts(sec: float) -> None:  # (by-value kernel argument: takes effect at the next graph capture)
+            for c in (self.ipc, self.ipc_act):
+                if c is not None:
+                    c.set_timeout(sec)
+
+        def new_timeouts(seen: list) -> bool:
+            """Did any rank's in-kernel wait expire since the last call (agreed across ranks)?"""
+            t = torch.tensor([float(self.transport_errors())], dtype=torch.float64,
+                             device="cpu" if self._stage_host else e.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            bad = float(t.item()) > seen[0]
+            seen[0] = max(seen[0], float(t.item()))
+            return bad
 
         # (a forced schedule other than the reference is still checked against it)
         trial = cands if len(cands) > 1 or cands == ["ipc-inline"] else cands + ["ipc-inline"]
@@ -300,6 +301,8 @@ class DataParallelTrainer:
                 e.stream.synchronize()
                 e._steps_done = done0
 
+            set_timeouts(2.0)  # a schedule that cannot make progress on this machine must cost seconds, not minutes
+            errs_seen, broken = [0.0], set()
             for c in cands:
                 use(c)
                 self.prepare()
@@ -308,6 +311,11 @@ class DataParallelTrainer:
                 self.train_steps(1)
                 with self._ctx():
                     grads.append((e.M - b1 * snap[1]) / (1.0 - b1))
+                if c != "rccl" and new_timeouts(errs_seen):
+                    broken.add(c)
+                    times.append(float("inf"))
+                    restore()
+                    continue
                 if timed:
                     self.train_steps(7)
                     e.stream.synchronize()
@@ -332,15 +340,54 @@ class DataParallelTrainer:
             times, off = t[:len(cands)], t[len(cands):]
             self.schedule_us = {c: round(v, 1) for c, v in zip(cands, times)} if timed else None
             self.schedule_deviation = {c: float("%.3g" % v) for c, v in zip(cands, off)}
-            good = [i for i in range(len(cands)) if off[i] < 0.02 and (forced == "auto" or cands[i] == forced)]
+            set_timeouts(op_timeout)
+            good = [i for i in range(len(cands)) if off[i] < 0.02 and cands[i] not in broken
+                    and (forced == "auto" or cands[i] == forced)]
+            if not good and forced == "auto" and "rccl" in cands:
+                good = [cands.index("rccl")]
             if not good:
-                raise RuntimeError("schedule %s disagrees with the staged all-reduce: %s" % (forced, self.schedule_deviation))
+                raise RuntimeError("no usable data-parallel schedule (%s): deviations %s, timed out %s" % (
+                    forced, self.schedule_deviation, sorted(broken)))
             cands = [cands[min(good, key=lambda i: times[i])]]
         use(cands[0])
-        self.schedule = cands[0]
         if self.rank == 0:
             print("data-parallel step schedule: %s %s gradient deviation from the staged all-reduce %s" % (
                 self.schedule, self.schedule_us or "", getattr(self, "schedule_deviation", "")), flush=True)
+
+    def _use_schedule(self, c: str) -> None:
+        e, hook, fc1_end = self.engine, self._ipc_hook, self._fc1_end
+        zc, ga = c == "ipc-zerocopy", c == "ipc-gather"
+        e.set_grad_redirect(self.ipc.stage_ptr if zc else 0, self.ipc.result_ptr if zc else 0)
+        if hasattr(e, "set_gather"):
+            e.set_gather(self.ipc_act if ga else None)
+        if c == "rccl":
+            e.set_grad_hook(None)
+            self.comm = "rccl"
+        else:
+            hook.set_overlap(c == "ipc-overlap")
+            hook.set_zero_copy(fc1_end if zc else 0)
+            hook.set_gather(fc1_end if ga else 0)
+            e.set_grad_hook(hook)  # (drops the captured graphs)
+            self.comm = "ipc"
+        self.schedule = c
+
+    def ensure_healthy(self) -> bool:
+        """Call between steps (synchronises).  If an in-kernel wait of the IPC exchange has expired on any rank since
+        the start, the ranks agree on it, fall back to the RCCL schedule and re-broadcast rank 0's state (some step
+        used an incomplete gradient sum on some rank).  Returns False if it had to do that."""
+        if self.ipc is None or self.comm != "ipc":
+            return True
+        e = self.engine
+        t = torch.tensor([float(self.transport_errors())], dtype=torch.float64, device="cpu" if self._stage_host else e.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        if float(t.item()) == 0:
+            return True
+        if self.rank == 0:
+            print("IPC exchange: %d wait(s) timed out; falling back to the process group's all-reduce" % int(t.item()),
+                  flush=True)
+        self._use_schedule("rccl")
+        self.broadcast_state()
+        return False
 
     # ------------------------------------------------------------------ collectives
     def _ctx(self):

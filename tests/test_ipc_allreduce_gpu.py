@@ -62,3 +62,50 @@ def test_ipc_allreduce_ranks_sharing_one_gpu(tmp_path, world):
     print(out)
     assert out["self_test"] is True and out["errors"] == 0 and out["small"] is True
     assert all(out["it%d" % i] for i in range(5))
+
+
+_STALL_WORKER = r"""
+import os, sys, json, time
+sys.path.insert(0, sys.argv[1])
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch, torch.distributed as dist
+from distributed_tensorflow_amd.parallel.ipc_comm import IpcAllReduce
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+comm = IpcAllReduce(4096, "cuda:0", timeout_s=5.0)
+ok = comm.self_test(rounds=1)
+comm.set_timeout(0.3)
+x = torch.ones(4096, device="cuda")
+t0 = time.perf_counter()
+if rank == 0:            # rank 1 never joins this all-reduce: rank 0's kernels must give up, not hang
+    comm.all_reduce(x)
+    torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+res = {"self_test": ok, "errors": comm.errors(), "seconds": dt}
+print(json.dumps({"rank": rank, **res}), flush=True)
+dist.barrier()
+comm.close()
+dist.destroy_process_group()
+"""
+
+
+def test_ipc_wait_is_bounded_when_a_peer_stalls(tmp_path):
+    """Failure detection: every in-kernel wait has a wall-clock bound, so a rank whose peer never shows up
+    records the expiry and its grid drains (a kernel that spins forever would take the GPU with it)."""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "ipc_stall.py"
+    script.write_text(_STALL_WORKER)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", str(script), repo]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-3000:]
+    outs = {}
+    for l in r.stdout.splitlines():
+        if l.startswith("{"):
+            d = json.loads(l)
+            outs[d["rank"]] = d
+    assert outs[0]["self_test"] is True
+    assert outs[0]["errors"] >= 1 and 0.25 < outs[0]["seconds"] < 10.0, outs
+    assert outs[1]["errors"] == 0
