@@ -15,6 +15,7 @@
 //    A 32-lane half reads 4 rows x 64 B = one full 256-B bank row: conflict-free without padding.
 #include "common.h"
 #include "conv1_dw_body.h"
+#include "conv2_pack.h"
 
 namespace {
 constexpr int ERR_SHAPE = -22;
@@ -35,8 +36,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* lds_row0) {
 }
 }  // namespace
 
-// grid (B, 2); 256 threads.  x bf16 [B,14,14,32]; W fp32 [800][64]; out bf16 [B,49,64]; amax uint8 [B,49,64]
-__global__ __launch_bounds__(256) void conv2_fwd_lds_kernel(const uint16_t* __restrict__ x, const float* __restrict__ W,
+// grid (B, 2); 256 threads.  x bf16 [B,14,14,32]; Wf packed bf16 [2][800][32] (conv2_pack.h); out bf16 [B,49,64];
+// amax uint8 [B,49,64]
+__global__ __launch_bounds__(256) void conv2_fwd_lds_kernel(const uint16_t* __restrict__ x, const char* __restrict__ Wf,
                                                             const float* __restrict__ bias, uint16_t* __restrict__ out,
                                                             uint8_t* __restrict__ amax) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -57,11 +59,12 @@ __global__ __launch_bounds__(256) void conv2_fwd_lds_kernel(const uint16_t* __re
     iv[i] = *reinterpret_cast<const uint4*>(x + (ok ? (((long)b * 14 + y) * 14 + xx) * 32 + q * 8 : 0L));
     if (!ok) iv[i] = make_uint4(0, 0, 0, 0);
   }
-  f32x4 wv[25];
+  u32x4 wv[13];  // this half's packed slice: 51 200 B = 3200 chunks of 16 B, already in LDS order
+  const u32x4* wsrc = reinterpret_cast<const u32x4*>(Wf + blockIdx.y * W_BYTES);
 #pragma unroll
-  for (int j = 0; j < 25; ++j) {
-    const int idx = tid + 256 * j;  // 6400 float4 = 800 rows x 8
-    wv[j] = *reinterpret_cast<const f32x4*>(W + (long)(idx >> 3) * 64 + n0 + (idx & 7) * 4);
+  for (int j = 0; j < 13; ++j) {
+    const int c = tid + 256 * j;
+    wv[j] = wsrc[c < 3200 ? c : 0];
   }
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
@@ -69,10 +72,9 @@ __global__ __launch_bounds__(256) void conv2_fwd_lds_kernel(const uint16_t* __re
     if (c < 1296) *reinterpret_cast<uint4*>(img + (c >> 2) * PIX + (c & 3) * 16) = iv[i];
   }
 #pragma unroll
-  for (int j = 0; j < 25; ++j) {
-    const int idx = tid + 256 * j;
-    *reinterpret_cast<uint2*>(wl + (idx >> 3) * WROW + (idx & 7) * 8) =
-        make_uint2(pack_bf2(wv[j][0], wv[j][1]), pack_bf2(wv[j][2], wv[j][3]));
+  for (int j = 0; j < 13; ++j) {
+    const int c = tid + 256 * j;
+    if (c < 3200) *reinterpret_cast<u32x4*>(wl + c * 16) = wv[j];
   }
   __syncthreads();
 
@@ -140,6 +142,11 @@ __global__ __launch_bounds__(256) void conv2_fwd_lds_kernel(const uint16_t* __re
 }
 
 static bool g_attr_set = false;
+static char* g_pack = nullptr;  // packed filter copies for callers that pass fp32 weights (the step executor keeps its own)
+
+__global__ __launch_bounds__(256) void conv2_pack_kernel(const float* __restrict__ W, char* __restrict__ Wf, char* __restrict__ Wb) {
+  conv2_pack_body(W, Wf, Wb, blockIdx.x, gridDim.x);
+}
 
 // Raises the dynamic-LDS limit of the kernels in this file (> 64 KB).  Called once per process before the
 // first launch and never from inside a stream capture.
@@ -148,22 +155,37 @@ DTF_API int dtf_conv2_lds_init() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_fwd_lds_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, IMG_BYTES + W_BYTES);
   if (e != hipSuccess) return (int)e;
+  if (!g_pack && hipMalloc(reinterpret_cast<void**>(&g_pack), CONV2_WF_BYTES + CONV2_WB_BYTES) != hipSuccess) return -12;
   g_attr_set = true;
   return 0;
 }
 
-DTF_API int dtf_conv2_fwd_lds(const void* x, const float* W, const float* bias, void* out, void* amax, int B,
-                              hipStream_t st) {
-  if (B <= 0) return ERR_SHAPE;
+// Wf: packed bf16 filter [2][800][32] (conv2_pack.h)
+DTF_API int dtf_conv2_fwd_lds_packed(const void* x, const void* Wf, const float* bias, void* out, void* amax, int B,
+                                     hipStream_t st) {
+  if (B <= 0 || !Wf) return ERR_SHAPE;
   const int lds = IMG_BYTES + W_BYTES;
   if (!g_attr_set) {
     const int rc = dtf_conv2_lds_init();
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(conv2_fwd_lds_kernel, dim3(B, 2), dim3(256), lds, st, (const uint16_t*)x, W, bias, (uint16_t*)out,
-                     (uint8_t*)amax);
+  hipLaunchKernelGGL(conv2_fwd_lds_kernel, dim3(B, 2), dim3(256), lds, st, (const uint16_t*)x, (const char*)Wf, bias,
+                     (uint16_t*)out, (uint8_t*)amax);
   DTF_CHECK_LAUNCH();
   return 0;
+}
+
+// fp32 HWIO filter [800][64]: packed into a library-owned scratch first (one extra small launch)
+DTF_API int dtf_conv2_fwd_lds(const void* x, const float* W, const float* bias, void* out, void* amax, int B,
+                              hipStream_t st) {
+  if (B <= 0) return ERR_SHAPE;
+  if (!g_attr_set) {
+    const int rc = dtf_conv2_lds_init();
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(conv2_pack_kernel, dim3(25), dim3(256), 0, st, W, g_pack, g_pack + CONV2_WF_BYTES);
+  DTF_CHECK_LAUNCH();
+  return dtf_conv2_fwd_lds_packed(x, g_pack, bias, out, amax, B, st);
 }
 
 // =====================================================================================================
@@ -220,7 +242,7 @@ __device__ __forceinline__ void unpool_task_store(char* dimg, int task, const f3
 __global__ __launch_bounds__(256) void conv2_bwd_data_lds_kernel(const float* __restrict__ dpool2,
                                                                  const uint16_t* __restrict__ pool2,
                                                                  const uint8_t* __restrict__ amax2,
-                                                                 const float* __restrict__ W,
+                                                                 const char* __restrict__ Wb,
                                                                  const uint16_t* __restrict__ pool1,
                                                                  float* __restrict__ dpool1, float* __restrict__ db2) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -230,7 +252,7 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_lds_kernel(const float* __
   const int b = blockIdx.x, half = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-  // burst 1: un-pool inputs (2 tasks / thread) + first half of the filter (25 float4 / thread)
+  // one burst: un-pool inputs (2 tasks / thread) + the filter image
   f32x4 ug0[2], ug1[2];
   uint4 upv[2];
   uint2 uav[2];
@@ -239,9 +261,10 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_lds_kernel(const float* __
     const int task = tid + 256 * i;
     unpool_task_load(dpool2, pool2, amax2, (long)b * 3136, task, task < 392, ug0[i], ug1[i], upv[i], uav[i]);
   }
-  f32x4 wv[25];
+  // the packed, pre-swizzled filter image (conv2_pack.h): 102 400 B = 25 chunks of 16 B per thread, copied as is
+  u32x4 wv[25];
 #pragma unroll
-  for (int j = 0; j < 25; ++j) wv[j] = reinterpret_cast<const f32x4*>(W)[tid + 256 * j];
+  for (int j = 0; j < 25; ++j) wv[j] = reinterpret_cast<const u32x4*>(Wb)[tid + 256 * j];
   // zero the halo image while the loads fly (2916 x 16 B)
   if (tid < 64) dbs[tid] = 0.f;
 #pragma unroll
@@ -262,22 +285,8 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_lds_kernel(const float* __
       }
     }
   }
-  // filter rows: float4 index f -> row = f >> 4 (= tap*32 + cin), 4 cout at (f & 15) * 4; 16-B chunk = (f & 15) >> 1
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass == 1) {
-#pragma unroll
-      for (int j = 0; j < 25; ++j) wv[j] = reinterpret_cast<const f32x4*>(W)[6400 + tid + 256 * j];
-    }
-#pragma unroll
-    for (int j = 0; j < 25; ++j) {
-      const int f = pass * 6400 + tid + 256 * j;
-      const int row = f >> 4, q = f & 15;
-      const int chunk = (q >> 1) ^ (row & 7);
-      *reinterpret_cast<uint2*>(wl + row * WB_ROW + chunk * 16 + (q & 1) * 8) =
-          make_uint2(pack_bf2(wv[j][0], wv[j][1]), pack_bf2(wv[j][2], wv[j][3]));
-    }
-  }
+  for (int j = 0; j < 25; ++j) *reinterpret_cast<u32x4*>(wl + (tid + 256 * j) * 16) = wv[j];
   __syncthreads();
   if (half == 0 && db2 && tid < 64) atomicAdd(&db2[tid], dbs[tid]);
 
@@ -453,17 +462,30 @@ DTF_API int dtf_conv2_bwd_lds_init() {
 // Fused conv2 backward for the MNIST geometry (14x14, 32 -> 64 channels, 5x5 SAME, 2x2 pool behind it).
 // The two kernels are independent of each other (each rebuilds dY from the pooled gradient), so the step
 // executor may issue them on different streams.
-DTF_API int dtf_conv2_bwd_data_lds(const float* dpool2, const void* pool2, const void* amax2, const float* W,
-                                   const void* pool1, float* dpool1, float* db2, int B, hipStream_t st) {
-  if (B <= 0) return ERR_SHAPE;
+// Wb: packed, swizzled bf16 filter image [800][64] (conv2_pack.h)
+DTF_API int dtf_conv2_bwd_data_lds_packed(const float* dpool2, const void* pool2, const void* amax2, const void* Wb,
+                                          const void* pool1, float* dpool1, float* db2, int B, hipStream_t st) {
+  if (B <= 0 || !Wb) return ERR_SHAPE;
   if (!g_bwd_attr_set) {
     const int rc = dtf_conv2_bwd_lds_init();
     if (rc) return rc;
   }
   hipLaunchKernelGGL(conv2_bwd_data_lds_kernel, dim3(B, 2), dim3(256), DIMG_BYTES + WB_BYTES, st, dpool2,
-                     (const uint16_t*)pool2, (const uint8_t*)amax2, W, (const uint16_t*)pool1, dpool1, db2);
+                     (const uint16_t*)pool2, (const uint8_t*)amax2, (const char*)Wb, (const uint16_t*)pool1, dpool1, db2);
   DTF_CHECK_LAUNCH();
   return 0;
+}
+
+DTF_API int dtf_conv2_bwd_data_lds(const float* dpool2, const void* pool2, const void* amax2, const float* W,
+                                   const void* pool1, float* dpool1, float* db2, int B, hipStream_t st) {
+  if (B <= 0) return ERR_SHAPE;
+  if (!g_bwd_attr_set || !g_attr_set) {
+    const int rc = dtf_conv2_bwd_lds_init() || dtf_conv2_lds_init();
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(conv2_pack_kernel, dim3(25), dim3(256), 0, st, W, g_pack, g_pack + CONV2_WF_BYTES);
+  DTF_CHECK_LAUNCH();
+  return dtf_conv2_bwd_data_lds_packed(dpool2, pool2, amax2, g_pack + CONV2_WF_BYTES, pool1, dpool1, db2, B, st);
 }
 
 DTF_API int dtf_conv2_dw_lds(const float* dpool2, const void* pool2, const void* amax2, const void* pool1, float* dW,

@@ -36,6 +36,13 @@ DTF_API int dtf_adam_tf(const OptimParams* p, hipStream_t st);
 DTF_API int dtf_sgd(const OptimParams* p, hipStream_t st);
 DTF_API int dtf_conv2_lds_init();
 DTF_API int dtf_conv2_bwd_lds_init();
+DTF_API int dtf_conv1_fwd_pack(const float* images, const int* perm, const int* step_ptr, int spe, int B, const float* Wt,
+                               const float* bias, void* out, void* amax, const float* Wc2, void* Wc2f, void* Wc2b,
+                               hipStream_t st);
+DTF_API int dtf_conv2_fwd_lds_packed(const void* x, const void* Wf, const float* bias, void* out, void* amax, int B,
+                                     hipStream_t st);
+DTF_API int dtf_conv2_bwd_data_lds_packed(const float* dpool2, const void* pool2, const void* amax2, const void* Wb,
+                                          const void* pool1, float* dpool1, float* db2, int B, hipStream_t st);
 DTF_API int dtf_conv2_bwd_data_lds(const float* dpool2, const void* pool2, const void* amax2, const float* W,
                                    const void* pool1, float* dpool1, float* db2, int B, hipStream_t st);
 DTF_API int dtf_conv_dw_duo(const float* dpool2, const void* pool2, const void* amax2, const void* pool1, float* dW2, int B,

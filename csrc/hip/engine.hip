@@ -41,6 +41,7 @@ struct MnistEngine {
   const void* gather_B[8];
   const void* gather_comm;
   int gather_n, gather_rank;
+  void *wc2f, *wc2b;   // packed bf16 copies of conv2's filter (conv2_pack.h), rewritten by the first kernel of every forward
   void* gather_local;  // [gather_n][gather_bytes]: local copies of the peers' operands (what gather_A/B point at for peers)
   long gather_bytes;   // bytes of (pool2, dh) per rank
 };
@@ -53,10 +54,10 @@ struct MnistEngine {
 
 static int forward_to_slabs(const MnistEngine* e, const float* images, const int* perm, const int* step, int n,
                             int splits, bool need_argmax, hipStream_t st) {
-  DTF_TRY(dtf_conv1_fwd(images, perm, step, e->spe, n, e->P + e->off_Wc1, e->P + e->off_bc1, e->pool1,
-                        need_argmax ? e->amax1 : nullptr, st));
-  DTF_TRY(dtf_conv_bias_relu_pool(e->pool1, e->P + e->off_Wc2, e->P + e->off_bc2, e->pool2,
-                                  need_argmax ? e->amax2 : nullptr, n, 14, 14, 32, 64, 5, 5, st));
+  if (!e->wc2f || !e->wc2b) return -22;
+  DTF_TRY(dtf_conv1_fwd_pack(images, perm, step, e->spe, n, e->P + e->off_Wc1, e->P + e->off_bc1, e->pool1,
+                             need_argmax ? e->amax1 : nullptr, e->P + e->off_Wc2, e->wc2f, e->wc2b, st));
+  DTF_TRY(dtf_conv2_fwd_lds_packed(e->pool1, e->wc2f, e->P + e->off_bc2, e->pool2, need_argmax ? e->amax2 : nullptr, n, st));
   DTF_TRY(dtf_fc_fwd(e->pool2, 0, e->P + e->off_Wfc1, e->slabs, n, 1024, 3136, splits, nullptr, 0, st));
   return 0;
 }
@@ -146,8 +147,8 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
       DTF_TRY(dtf_fc_bwd_data(e->dh, e->P + e->off_Wfc1, e->dpool2, B, 3136, 1024, e->bwd_splits, st));
     // un-pool + conv2 bwd-data (+db2) as one LDS-resident kernel, then both conv filter gradients as one launch
     const int ipw = e->dw2_splits > 0 && e->dw2_splits <= 16 ? e->dw2_splits : 4;
-    DTF_TRY(dtf_conv2_bwd_data_lds(e->dpool2, e->pool2, e->amax2, e->P + e->off_Wc2, e->pool1, e->dpool1,
-                                   e->G + e->off_bc2, B, st));
+    DTF_TRY(dtf_conv2_bwd_data_lds_packed(e->dpool2, e->pool2, e->amax2, e->wc2b, e->pool1, e->dpool1, e->G + e->off_bc2, B,
+                                          st));
     DTF_TRY(dtf_conv_dw_duo(e->dpool2, e->pool2, e->amax2, e->pool1, e->G + e->off_Wc2, B, ipw, e->images, e->perm, e->step,
                             e->spe, e->dpool1, e->amax1, e->G + e->off_Wc1, e->G + e->off_bc1, st));
   }

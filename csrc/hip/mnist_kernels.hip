@@ -9,6 +9,7 @@
 // Reference semantics: demo1/train.py:57-141.
 #include "common.h"
 #include "conv1_dw_body.h"
+#include "conv2_pack.h"
 #include "dtf_structs.h"
 
 namespace {
@@ -18,15 +19,24 @@ constexpr int NC = 10;
 }  // namespace
 
 // ------------------------------------------------------------------ conv1 forward
-// grid (B, 4): blockIdx.y = group of 8 output channels (wave-uniform -> weights come through scalar loads).
+// one workgroup per (image, group of 8 output channels) (wave-uniform -> weights come through scalar loads).
 // x: fp32 [N,784]; Wt: fp32 [25][32] (HWIO, I=1); out: bf16 [B,14,14,32]; amax: uint8 [B,14,14,32].
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ images, const int* __restrict__ perm,
                                                         const int* __restrict__ step_ptr, int spe, int B,
                                                         const float* __restrict__ Wt, const float* __restrict__ bias,
-                                                        uint16_t* __restrict__ out, uint8_t* __restrict__ amax) {
+                                                        uint16_t* __restrict__ out, uint8_t* __restrict__ amax,
+                                                        const float* __restrict__ Wc2, char* __restrict__ Wc2f,
+                                                        char* __restrict__ Wc2b) {
   __shared__ __attribute__((aligned(16))) float img[32 * 32];  // rows/cols -2..29 (SAME padding halo)
   __shared__ __attribute__((aligned(16))) float wl[26 * 8];    // this block's 8 filters (25 taps) + bias
-  const int b = blockIdx.x, cg = blockIdx.y, tid = threadIdx.x;
+  // 1-D grid of npack + 4*B workgroups.  The leading npack ones (dispatched first, so they are no tail) pack conv2's
+  // weights for the kernels that follow; the rest are (image, channel group) pairs, channel group fastest.
+  const int npack = (int)gridDim.x - 4 * B;
+  if ((int)blockIdx.x < npack) {
+    conv2_pack_body(Wc2, Wc2f, Wc2b, blockIdx.x, npack);
+    return;
+  }
+  const int b = ((int)blockIdx.x - npack) >> 2, cg = ((int)blockIdx.x - npack) & 3, tid = threadIdx.x;
   const long n = sample_index(perm, step_ptr, spe, B, b);
   const float* src = images + n * 784;
   // every global load of the block is issued before the first wait: one memory round trip
@@ -95,13 +105,21 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
   if (amax) *reinterpret_cast<uint2*>(amax + o) = make_uint2(av[0], av[1]);
 }
 
-DTF_API int dtf_conv1_fwd(const float* images, const int* perm, const int* step_ptr, int spe, int B, const float* Wt,
-                          const float* bias, void* out, void* amax, hipStream_t st) {
-  if (B <= 0 || (perm && spe <= 0)) return ERR_SHAPE;
-  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(B, 4), dim3(256), 0, st, images, perm, step_ptr, spe, B, Wt, bias,
-                     (uint16_t*)out, (uint8_t*)amax);
+// Wc2 != null: also writes the packed bf16 copies of the conv2 filter (conv2_pack.h) into Wc2f / Wc2b.
+DTF_API int dtf_conv1_fwd_pack(const float* images, const int* perm, const int* step_ptr, int spe, int B, const float* Wt,
+                               const float* bias, void* out, void* amax, const float* Wc2, void* Wc2f, void* Wc2b,
+                               hipStream_t st) {
+  if (B <= 0 || (perm && spe <= 0) || (Wc2 && (!Wc2f || !Wc2b))) return ERR_SHAPE;
+  const int npack = Wc2 ? 25 : 0;  // one 16-byte chunk of each packed copy per thread
+  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(4 * B + npack), dim3(256), 0, st, images, perm, step_ptr, spe, B, Wt, bias,
+                     (uint16_t*)out, (uint8_t*)amax, Wc2, (char*)Wc2f, (char*)Wc2b);
   DTF_CHECK_LAUNCH();
   return 0;
+}
+
+DTF_API int dtf_conv1_fwd(const float* images, const int* perm, const int* step_ptr, int spe, int B, const float* Wt,
+                          const float* bias, void* out, void* amax, hipStream_t st) {
+  return dtf_conv1_fwd_pack(images, perm, step_ptr, spe, B, Wt, bias, out, amax, nullptr, nullptr, nullptr, st);
 }
 
 // ------------------------------------------------------------------ conv1 backward (filter + bias grads)

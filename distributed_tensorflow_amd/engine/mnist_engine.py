@@ -99,6 +99,8 @@ class NativeMnistEngine(_EngineBase):
             "dz": torch.zeros(batch_size * 16, **bf),
             "dpool2": torch.zeros(batch_size * 3136, **f32), "dy2": torch.zeros(batch_size * 196 * 64, **bf),
             "dpool1": torch.zeros(batch_size * 196 * 32, **f32),
+            # packed bf16 copies of the conv2 filter in the two LDS layouts (csrc/hip/conv2_pack.h)
+            "wc2f": torch.zeros(2 * 800 * 32, **bf), "wc2b": torch.zeros(800 * 64, **bf),
         }
         self.seed = int(seed if seed is not None else np.random.SeedSequence().entropy % (2 ** 62))
         self.spe = dataset.steps_per_epoch(batch_size) if dataset is not None else 1
@@ -120,7 +122,7 @@ class NativeMnistEngine(_EngineBase):
                             ("off_Wc2", "W_conv2"), ("off_bc2", "b_conv2"), ("off_Wc1", "W_conv1"), ("off_bc1", "b_conv1")):
             setattr(s, field, self.layout[name][0])
         s.step, s.ticket, s.metrics_ring = self.step_t.data_ptr(), self.ticket.data_ptr(), self.metrics_ring.data_ptr()
-        for k in ("pool1", "amax1", "pool2", "amax2", "slabs", "h_drop", "dh", "dz", "dpool2", "dy2", "dpool1"):
+        for k in ("pool1", "amax1", "pool2", "amax2", "slabs", "h_drop", "dh", "dz", "dpool2", "dy2", "dpool1", "wc2f", "wc2b"):
             setattr(s, k, self.ws[k].data_ptr())
         self.cfg = s
         self._graphs = {}

@@ -68,6 +68,7 @@ class MnistEngineStruct(C.Structure):  # csrc/hip/engine.hip: struct MnistEngine
         ("dpool2", c_void_p), ("dy2", c_void_p), ("dpool1", c_void_p),
         ("G_fc1_dst", c_void_p), ("G_src", c_void_p),
         ("gather_A", c_void_p * 8), ("gather_B", c_void_p * 8), ("gather_comm", c_void_p), ("gather_n", c_int), ("gather_rank", c_int),
+        ("wc2f", c_void_p), ("wc2b", c_void_p),
         ("gather_local", c_void_p), ("gather_bytes", c_long),
     ]
 
