@@ -95,7 +95,8 @@ def run(FLAGS, distributed: bool) -> int:
         kind = "native" if device.type == "cuda" else "eager"
     engine = make_engine(kind, train_dd, batch_size=FLAGS.batch_size, lr=FLAGS.learning_rate, keep_prob=FLAGS.keep_prob,
                          double_softmax=FLAGS.double_softmax, seed=FLAGS.seed, device=device, use_graph=FLAGS.use_graph)
-    trainer = DataParallelTrainer(engine, sync=FLAGS.sync, async_period=FLAGS.async_period)
+    trainer = DataParallelTrainer(engine, sync=FLAGS.sync, async_period=FLAGS.async_period,
+                                  comm=getattr(FLAGS, "comm", "auto"))
     _log(rank, "engine=%s device=%s world=%d global_batch=%d sync=%s" % (
         kind, device, world, FLAGS.batch_size * world, FLAGS.sync))
 

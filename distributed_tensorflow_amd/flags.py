@@ -59,6 +59,10 @@ def add_framework_flags(p: argparse.ArgumentParser) -> None:
                    help="emulate the reference's asynchronous updates: local steps, parameter "
                         "averaging every --async_period steps")
     p.add_argument("--async_period", type=int, default=8)
+    p.add_argument("--comm", type=str, default="auto", choices=["auto", "ipc", "rccl"],
+                   help="gradient exchange between GPUs of one node: direct IPC/xGMI exchange (its step schedule is "
+                        "picked by a start-up trial; DTF_DP_SCHEDULE pins one), the process group's all-reduce, or "
+                        "auto = whichever a start-up trial measures as fastest")
     p.add_argument("--engine", type=str, default="auto",
                    help="auto | native (HIP fused step executor) | eager (PyTorch oracle)")
     p.add_argument("--use_graph", type="bool", nargs="?", const=True, default=True,

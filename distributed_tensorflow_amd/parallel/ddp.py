@@ -208,14 +208,13 @@ class DataParallelTrainer:
             ok = self.ipc.self_test()
             err = self.ipc.failure or "self-test against the process group's all-reduce failed on some rank"
             if ok:
-                # measure, don't guess: tune the IPC grid, and keep the process group's collectives if they reduce the
-                # arena clearly faster (unless the caller insisted on IPC)
+                # measure, don't guess: tune the IPC grid on the arena-sized all-reduce.  Whether gradients then travel
+                # by IPC or by the process group is decided by _tune_schedule on whole steps (the gather schedule does
+                # not all-reduce the arena at all, so a slower IPC all-reduce says nothing about it).
                 t_ipc, t_pg = self._time_transports(grids=(32, 64, 128) if len(set(where)) < self.world
                                                     else (64, 128, 256, 512))
                 self.transport_us = {"ipc": round(t_ipc, 1), "ipc_workgroups": self.ipc.blocks,
                                      "process_group": round(t_pg, 1)}
-                if not required and t_ipc > 1.5 * t_pg and not os.environ.get("DTF_IPC_KEEP"):  # (env: diagnostics)
-                    ok, err = False, "IPC all-reduce slower than the process group's (%.0f vs %.0f us)" % (t_ipc, t_pg)
         if ok:
             self.ipc.set_timeout(float(os.environ.get("DTF_IPC_TIMEOUT_S", "30")))
             self.engine.set_grad_hook(_IpcGradHook(self.ipc, self._bucket_a, self._bucket_b, self.engine.G,
