@@ -185,8 +185,8 @@ def run(FLAGS, distributed: bool) -> int:
                        seed=seed, final_tensor_name=FLAGS.final_tensor_name)
     head.world = world
     if world > 1:
-        import torch.distributed as dist
-        dist.broadcast(head.P, src=0)
+        from ..parallel.ddp import broadcast_
+        broadcast_(head.P, src=0)
 
     distortion = Distortion(FLAGS.flip_left_right, FLAGS.random_crop, FLAGS.random_scale, FLAGS.random_brightness)
     cache = BottleneckCache(index, device)
@@ -228,7 +228,8 @@ def run(FLAGS, distributed: bool) -> int:
             vce, val_acc = head.evaluate(cache.values, cache.labels, vrows)
             if world > 1:
                 import torch.distributed as dist
-                t = torch.tensor([ce, train_acc, vce, val_acc], dtype=torch.float64, device=device)
+                t = torch.tensor([ce, train_acc, vce, val_acc], dtype=torch.float64,
+                                 device="cpu" if dist.get_backend() == "gloo" else device)
                 dist.all_reduce(t)
                 ce, train_acc, vce, val_acc = (t / world).tolist()
             if train_writer is not None:

@@ -187,9 +187,11 @@ class BottleneckCache:
         self.filled[lo:hi] = True
         if world > 1:
             import torch.distributed as dist
-            padded = torch.zeros(per * world, BOTTLENECK_SIZE, dtype=torch.float32, device=self.device)
-            local = torch.zeros(per, BOTTLENECK_SIZE, dtype=torch.float32, device=self.device)
-            local[:hi - lo] = self.values[lo:hi]
+            # (device tensors on a gloo group — several ranks on one GPU — are staged through the host, see ddp.all_reduce_)
+            xdev = "cpu" if dist.get_backend() == "gloo" else self.device
+            padded = torch.zeros(per * world, BOTTLENECK_SIZE, dtype=torch.float32, device=xdev)
+            local = torch.zeros(per, BOTTLENECK_SIZE, dtype=torch.float32, device=xdev)
+            local[:hi - lo] = self.values[lo:hi].to(xdev)
             dist.all_gather_into_tensor(padded, local)
             self.values.copy_(padded[:n])
             self.filled[:] = True

@@ -135,13 +135,13 @@ class RetrainHead:
                 native.check(lib.dtf_retrain_head_bwd(cache.data_ptr(), native.ptr(rows), self._dz.data_ptr(), B, self.C,
                                                       self.weights.data_ptr(), self.biases.data_ptr(), 0, 0, self.lr, st), "head bwd")
             else:
-                import torch.distributed as dist
                 from ..ops import hip_ops
+                from ..parallel.ddp import all_reduce_
                 gW = self.G[:BOTTLENECK * self.C]
                 gb = self.G[BOTTLENECK * self.C:]
                 native.check(lib.dtf_retrain_head_bwd(cache.data_ptr(), native.ptr(rows), self._dz.data_ptr(), B, self.C,
                                                       0, 0, gW.data_ptr(), gb.data_ptr(), 0.0, st), "head bwd")
-                dist.all_reduce(self.G, group=group)
+                all_reduce_(self.G, group=group)
                 hip_ops.sgd_(self.P, self.G, self._step_t, self._ticket, lr=self.lr, grad_scale=1.0 / self.world)
         else:
             x = cache if rows is None else cache.index_select(0, rows.long())
@@ -155,8 +155,8 @@ class RetrainHead:
             loss = torch.nn.functional.nll_loss(torch.log_softmax(z, 1), y.long())
             (g,) = torch.autograd.grad(loss, leaf)
             if self.world > 1:
-                import torch.distributed as dist
-                dist.all_reduce(g, group=group)
+                from ..parallel.ddp import all_reduce_
+                all_reduce_(g, group=group)
                 g = g / self.world
             self.P.sub_(g, alpha=self.lr)
             self._metrics[0] = loss.detach() * x.shape[0]

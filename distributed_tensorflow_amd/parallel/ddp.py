@@ -57,6 +57,33 @@ def init_process_group(backend: str = "auto", rank: Optional[int] = None, world:
     return rank, world
 
 
+def _needs_host_staging(t: torch.Tensor, group=None) -> bool:
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_(t: torch.Tensor, group=None, op=None) -> None:
+    """In-place all-reduce that also works for device tensors on a gloo group (functional runs with several ranks on
+    one GPU, where RCCL refuses duplicate devices): those are staged through host memory explicitly — gloo's own CUDA
+    path was seen to stall after a few dozen calls with two ranks on one device."""
+    op = dist.ReduceOp.SUM if op is None else op
+    if _needs_host_staging(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
+def broadcast_(t: torch.Tensor, src: int = 0, group=None) -> None:
+    """In-place broadcast with the same host staging rule as :func:`all_reduce_`."""
+    if _needs_host_staging(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+
+
 class _IpcGradHook:
     """Gradient all-reduce of the native MNIST step over the IPC transport.  With ``overlap`` the fc bucket (12.9 MB,
     final after step part 1) is reduced on a forked stream while the conv backward (part 2) runs on the main one —

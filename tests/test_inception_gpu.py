@@ -178,3 +178,24 @@ def test_retrain_end_to_end_inception_small(tmp_path):
         assert os.path.isdir("retrain_logs/train") and os.path.isdir("retrain_logs/validation")
     finally:
         os.chdir(cwd)
+
+
+def test_retrain2_two_ranks_one_gpu(tmp_path):
+    """retrain2 (the distributed retrain): 2 ranks sharing the test GPU shard the bottleneck extraction, all-gather the
+    cache, all-reduce the head gradients every step (host-staged on the gloo group) and rank 0 exports graph + labels."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    w = str(tmp_path)
+    cmd = [sys.executable, "-u", os.path.join(repo, "retrain2", "retrain2.py"), "--num_gpus", "2", "--backend", "gloo",
+           "--synthetic", "--synthetic_classes", "3", "--synthetic_images_per_class", "40", "--training_steps", "120",
+           "--bottleneck_dir", w + "/bn", "--summaries_dir", w + "/rl", "--output_graph", w + "/rg.pb",
+           "--output_labels", w + "/labels.txt", "--model_dir", w + "/model_dir"]
+    r = subprocess.run(cmd, cwd=w, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=280,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29641"))
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "Step 110:" in r.stdout and "(N=100)" in r.stdout and "Final test accuracy" in r.stdout
+    acc = float(r.stdout.split("Final test accuracy = ")[1].split("%")[0])
+    assert acc >= 80.0, r.stdout[-1500:]
+    assert os.path.exists(w + "/rg.pb") and os.path.exists(w + "/labels.txt")
