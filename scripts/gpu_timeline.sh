@@ -1,3 +1,5 @@
+#!/bin/bash
+# rocprofv3 kernel timeline + per-kernel table of the MNIST step on one GPU (run through gpurun from the repo root).
 set -e
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
