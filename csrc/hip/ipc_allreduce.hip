@@ -20,6 +20,10 @@
 // after my K3(e) copy; I overwrite stage_own for e+1 only after every peer signalled done(e), i.e. finished reading.
 // Every wait is bounded (wall-clock timeout): on expiry the kernel records an error and proceeds, so the grid always
 // drains; the host checks the error word.
+//
+// The same buffers and flags also serve: a zero-copy all-reduce (producer writes stage[], consumer reads result[]), a
+// one-shot all-reduce for small buffers, a one-wave stream-ordered barrier, the operand exchange of the "gather"
+// data-parallel schedule (barrier + pull), and plain all-gather / broadcast — see the sections below.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include "common.h"
@@ -208,6 +212,11 @@ __global__ __launch_bounds__(256) void ipc_gather_copy_kernel(const IpcComm c, f
   }
 }
 
+// dst <- the first n4 16-byte units of rank `peer`'s stage buffer (general-purpose all-gather / broadcast building block)
+__global__ __launch_bounds__(256) void ipc_copy_from_kernel(const IpcComm c, int peer, f32x4* __restrict__ dst, long n4) {
+  copy_f4(dst, reinterpret_cast<const f32x4*>(stage_of(c.base[peer])), n4);
+}
+
 // One-shot all-reduce for small buffers: after the publish kernel every rank sums ALL ranks' stage buffers itself (rank
 // order: bit-identical everywhere) straight into dst — one exchange phase and one kernel less than the two-shot form,
 // at N x the read volume.  No "done" handshake: see dtf_ipc_allreduce_oneshot for the contract.
@@ -287,6 +296,43 @@ DTF_API int dtf_ipc_gather_copy(const void* comm, void* dst, long bytes, int blo
   if (blocks_per_peer > 64) blocks_per_peer = 64;
   hipLaunchKernelGGL(ipc_gather_copy_kernel, dim3((c.world - 1) * blocks_per_peer), dim3(256), 0, st, c,
                      reinterpret_cast<f32x4*>(dst), bytes / 16, blocks_per_peer);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- general-purpose collectives over the same buffers (not on the training hot path: each is bracketed by barriers,
+// so calls need no external ordering).  n counts floats (any 4-byte payload), n % 4 == 0, n <= n_max.
+// dst[world][n] <- every rank's src[n]
+DTF_API int dtf_ipc_all_gather(const void* comm, const float* src, float* dst, long n, int blocks, hipStream_t st) {
+  const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
+  if (!src || !dst || n <= 0 || n % 4 || n > c.n_max || c.world < 1 || c.world > MAX_RANKS || c.rank < 0 || c.rank >= c.world)
+    return -22;
+  if (blocks < 1) blocks = 32;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(ipc_publish_kernel, dim3(blocks), dim3(256), 0, st, c, src, n);
+  hipLaunchKernelGGL(ipc_sync_kernel, dim3(1), dim3(64), 0, st, c);
+  for (int p = 0; p < c.world; ++p)
+    hipLaunchKernelGGL(ipc_copy_from_kernel, dim3(blocks), dim3(256), 0, st, c, p, reinterpret_cast<f32x4*>(dst + (long)p * n),
+                       n / 4);
+  hipLaunchKernelGGL(ipc_sync_kernel, dim3(1), dim3(64), 0, st, c);  // everyone has read: stage buffers may be reused
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// buf[n] on every rank <- rank root's buf[n]
+DTF_API int dtf_ipc_broadcast(const void* comm, float* buf, long n, int root, int blocks, hipStream_t st) {
+  const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
+  if (!buf || n <= 0 || n % 4 || n > c.n_max || c.world < 1 || c.world > MAX_RANKS || c.rank < 0 || c.rank >= c.world ||
+      root < 0 || root >= c.world)
+    return -22;
+  if (blocks < 1) blocks = 32;
+  if (blocks > 256) blocks = 256;
+  // (every rank runs the publish kernel so that the epochs stay in step; only the root has something to copy)
+  hipLaunchKernelGGL(ipc_publish_kernel, dim3(c.rank == root ? blocks : 1), dim3(256), 0, st, c, buf, c.rank == root ? n : 0L);
+  hipLaunchKernelGGL(ipc_sync_kernel, dim3(1), dim3(64), 0, st, c);
+  if (c.rank != root)
+    hipLaunchKernelGGL(ipc_copy_from_kernel, dim3(blocks), dim3(256), 0, st, c, root, reinterpret_cast<f32x4*>(buf), n / 4);
+  hipLaunchKernelGGL(ipc_sync_kernel, dim3(1), dim3(64), 0, st, c);
   DTF_CHECK_LAUNCH();
   return 0;
 }

@@ -36,6 +36,9 @@ def _signatures(lib) -> None:
     lib.dtf_ipc_close_handle.argtypes, lib.dtf_ipc_close_handle.restype = [P], I
     lib.dtf_ipc_allreduce.argtypes, lib.dtf_ipc_allreduce.restype = [P, P, P, L, I, P], I
     lib.dtf_ipc_allreduce_zc.argtypes, lib.dtf_ipc_allreduce_zc.restype = [P, P, L, L, L, I, P], I
+    lib.dtf_ipc_sync.argtypes, lib.dtf_ipc_sync.restype = [P, P], I
+    lib.dtf_ipc_all_gather.argtypes, lib.dtf_ipc_all_gather.restype = [P, P, P, L, I, P], I
+    lib.dtf_ipc_broadcast.argtypes, lib.dtf_ipc_broadcast.restype = [P, P, L, I, I, P], I
     lib.dtf_ipc_allreduce_oneshot.argtypes, lib.dtf_ipc_allreduce_oneshot.restype = [P, P, P, L, I, P], I
     lib.dtf_ipc_stage_ptr.argtypes, lib.dtf_ipc_stage_ptr.restype = [P], P
     lib.dtf_ipc_result_ptr.argtypes, lib.dtf_ipc_result_ptr.restype = [P, L], P
@@ -132,6 +135,31 @@ class IpcAllReduce:
         st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
         native.check(self.lib.dtf_ipc_allreduce_oneshot(C.byref(self.comm), src.data_ptr(), dst.data_ptr(), src.numel(),
                                                         blocks, st), "ipc_allreduce_oneshot")
+
+    # ---- the rest of a small collective backend over the same buffers; not on the training hot path
+    def _stream(self, stream: Optional[int]) -> int:
+        if self.comm is None:
+            raise RuntimeError("IPC exchange is not usable on this rank: %s" % self.failure)
+        return torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+
+    def barrier(self, stream: Optional[int] = None) -> None:
+        """Stream-ordered barrier over the ranks (one one-wave kernel; the host does not wait)."""
+        native.check(self.lib.dtf_ipc_sync(C.byref(self.comm), self._stream(stream)), "ipc_sync")
+
+    def all_gather(self, src: torch.Tensor, stream: Optional[int] = None) -> torch.Tensor:
+        """``[world, n]`` <- every rank's ``src`` (fp32, numel % 4 == 0, <= n_max)."""
+        assert src.is_cuda and src.dtype == torch.float32 and src.is_contiguous() and src.numel() % 4 == 0
+        assert src.numel() <= self.n_max
+        out = torch.empty(self.world, src.numel(), dtype=torch.float32, device=self.device)
+        native.check(self.lib.dtf_ipc_all_gather(C.byref(self.comm), src.data_ptr(), out.data_ptr(), src.numel(), 64,
+                                                 self._stream(stream)), "ipc_all_gather")
+        return out
+
+    def broadcast(self, t: torch.Tensor, src: int = 0, stream: Optional[int] = None) -> None:
+        """``t`` (fp32, numel % 4 == 0, <= n_max) on every rank <- rank ``src``'s ``t``."""
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() % 4 == 0 and t.numel() <= self.n_max
+        native.check(self.lib.dtf_ipc_broadcast(C.byref(self.comm), t.data_ptr(), t.numel(), src, 64, self._stream(stream)),
+                     "ipc_broadcast")
 
     @property
     def comm_addr(self) -> int:

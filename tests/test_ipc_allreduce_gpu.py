@@ -33,6 +33,20 @@ small = torch.arange(1000, dtype=torch.float32, device="cuda") * (rank + 1)
 comm.all_reduce(small)
 torch.cuda.synchronize()
 res["small"] = bool(torch.equal(small, torch.arange(1000, dtype=torch.float32, device="cuda") * (world * (world + 1) / 2)))
+# the other collectives of the backend: all-gather, broadcast, stream-ordered barrier
+mine = torch.full((4096,), float(rank), device="cuda")
+allg = comm.all_gather(mine)
+torch.cuda.synchronize()
+res["all_gather"] = bool(all(bool((allg[r] == r).all()) for r in range(world))) and tuple(allg.shape) == (world, 4096)
+bc = torch.arange(2048, dtype=torch.float32, device="cuda") + 100 * rank
+comm.broadcast(bc, src=world - 1)
+comm.barrier()
+torch.cuda.synchronize()
+res["broadcast"] = bool(torch.equal(bc, torch.arange(2048, dtype=torch.float32, device="cuda") + 100 * (world - 1)))
+y2 = torch.full((n,), float(rank + 1), device="cuda")
+comm.all_reduce(y2)   # the two-shot all-reduce still lines up after the other collectives moved the epoch
+torch.cuda.synchronize()
+res["after"] = bool((y2 == world * (world + 1) / 2).all())
 torch.cuda.synchronize(); dist.barrier()
 t0 = time.perf_counter()
 for _ in range(50):
@@ -62,6 +76,7 @@ def test_ipc_allreduce_ranks_sharing_one_gpu(tmp_path, world):
     print(out)
     assert out["self_test"] is True and out["errors"] == 0 and out["small"] is True
     assert all(out["it%d" % i] for i in range(5))
+    assert out["all_gather"] is True and out["broadcast"] is True and out["after"] is True
 
 
 _STALL_WORKER = r"""
