@@ -1,0 +1,49 @@
+// TF-1.x Adam over a flat fp32 range as a device function: the optimizer kernel (optim.hip) and the launch that fuses
+// the update of the fc1 weights with the conv filter gradients (conv2_lds.hip) share it.
+//   lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  m,v EMA;  p -= lr_t*m/(sqrt(v)+eps)   (eps outside the bias correction)
+// Workgroup `block` of `nblocks`, `nthreads` threads each, grid-strides over p.n/4 float4 with U of them in flight per lane.
+#pragma once
+#include "common.h"
+#include "dtf_structs.h"
+
+__device__ __forceinline__ void adam_tf_body(const OptimParams& p, const int t, const int block, const int nblocks,
+                                             const int nthreads) {
+  const double b1p = pow((double)p.beta1, (double)t), b2p = pow((double)p.beta2, (double)t);
+  const float lr_t = (float)((double)p.lr * sqrt(1.0 - b2p) / (1.0 - b1p));
+  const float b1 = p.beta1, b2 = p.beta2, ob1 = 1.f - p.beta1, ob2 = 1.f - p.beta2;
+  const long n4 = p.n >> 2;
+  const float* __restrict__ gsrc = p.Gsrc ? p.Gsrc : p.G;
+  constexpr int U = 4;  // 16 independent 16-B loads in flight per lane before the first use
+  for (long base = (long)block * nthreads * U + threadIdx.x; base < n4; base += (long)nblocks * nthreads * U) {
+    float4 g[U], m[U], v[U], w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = base + (long)u * nthreads;
+      const long j = i < n4 ? i : base;  // clamped address, result discarded below
+      g[u] = reinterpret_cast<const float4*>(gsrc)[j];
+      m[u] = reinterpret_cast<const float4*>(p.M)[j];
+      v[u] = reinterpret_cast<const float4*>(p.V)[j];
+      w[u] = reinterpret_cast<const float4*>(p.P)[j];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = base + (long)u * nthreads;
+      if (i >= n4) continue;
+      float* gp = &g[u].x;
+      float* mp = &m[u].x;
+      float* vp = &v[u].x;
+      float* wp = &w[u].x;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float gg = gp[c] * p.grad_scale;
+        mp[c] = b1 * mp[c] + ob1 * gg;
+        vp[c] = b2 * vp[c] + ob2 * gg * gg;
+        wp[c] -= lr_t * mp[c] / (sqrtf(vp[c]) + p.eps);
+      }
+      reinterpret_cast<float4*>(p.M)[i] = m[u];
+      reinterpret_cast<float4*>(p.V)[i] = v[u];
+      reinterpret_cast<float4*>(p.P)[i] = w[u];
+      if (i * 4 >= p.zero_from) reinterpret_cast<float4*>(p.G)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}

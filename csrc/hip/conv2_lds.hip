@@ -16,6 +16,7 @@
 #include "common.h"
 #include "conv1_dw_body.h"
 #include "conv2_pack.h"
+#include "adam_body.h"
 
 namespace {
 constexpr int ERR_SHAPE = -22;
@@ -423,12 +424,17 @@ __global__ __launch_bounds__(320) void conv2_dw_lds_kernel(const uint16_t* __res
 }
 
 // conv2 dW (workgroups [0, n2), id -> (image group id % gx, tap row id / gx)) and conv1 dW/db (the rest) in one launch.
+// (+ optionally, trailing workgroups that apply Adam to a parameter range whose gradient is already final — the fc1
+// weights, 98 % of the optimizer's bytes: the bandwidth-bound update then runs next to these latency-bound kernels
+// instead of after them.  Horizontal fusion, because a forked stream costs more than it hides; see engine.hip.)
 struct ConvDwDuo {
   const uint16_t* pool1; const float* dpool2; const uint16_t* pool2; const uint8_t* amax2; float* dW2;
   int B, ipw, gx, n2;
   const float* images; const int* perm; const int* step_ptr; int spe;
   const float* dpool1; const uint8_t* amax1; float* dW1; float* db1;
   int n1;
+  OptimParams adam;  // adam.n == 0: no optimizer workgroups
+  int nadam;
 };
 constexpr int DUO_LDS = (IMG_BYTES + DIMG_BYTES) > CONV1_DW_LDS_FLOATS * 4 ? (IMG_BYTES + DIMG_BYTES) : CONV1_DW_LDS_FLOATS * 4;
 
@@ -437,6 +443,8 @@ __global__ __launch_bounds__(320) void conv_dw_duo_kernel(const ConvDwDuo a) {
   const int id = blockIdx.x;
   if (id < a.n2)
     conv2_dw_body(smem, id % a.gx, id / a.gx, a.pool1, a.dpool2, a.pool2, a.amax2, a.dW2, a.B, a.ipw);
+  else if (id >= a.n2 + a.n1)
+    adam_tf_body(a.adam, *a.adam.step + 1, id - a.n2 - a.n1, a.nadam, 320);
   else
     conv1_dw_body(reinterpret_cast<float*>(smem), id - a.n2, a.n1, a.images, a.perm, a.step_ptr, a.spe, a.B, a.dpool1,
                   a.amax1, a.dW1, a.db1);
@@ -505,8 +513,10 @@ DTF_API int dtf_conv2_dw_lds(const float* dpool2, const void* pool2, const void*
 // conv1's from (images[perm], dpool1, amax1).  dW2 / dW1 / db1 are accumulated with atomics (pre-zeroed).
 DTF_API int dtf_conv_dw_duo(const float* dpool2, const void* pool2, const void* amax2, const void* pool1, float* dW2, int B,
                             int ipw, const float* images, const int* perm, const int* step_ptr, int spe,
-                            const float* dpool1, const void* amax1, float* dW1, float* db1, hipStream_t st) {
+                            const float* dpool1, const void* amax1, float* dW1, float* db1, const OptimParams* adam,
+                            hipStream_t st) {
   if (B <= 0 || ipw <= 0 || (perm && spe <= 0)) return ERR_SHAPE;
+  if (adam && (adam->n <= 0 || adam->n % 4 || adam->zero_from % 4 || !adam->step)) return ERR_SHAPE;
   if (!g_bwd_attr_set) {
     const int rc = dtf_conv2_bwd_lds_init();
     if (rc) return rc;
@@ -517,7 +527,16 @@ DTF_API int dtf_conv_dw_duo(const float* dpool2, const void* pool2, const void* 
   a.images = images; a.perm = perm; a.step_ptr = step_ptr; a.spe = spe;
   a.dpool1 = dpool1; a.amax1 = (const uint8_t*)amax1; a.dW1 = dW1; a.db1 = db1;
   a.n1 = B < 128 ? B : 128;
-  hipLaunchKernelGGL(conv_dw_duo_kernel, dim3(a.n2 + a.n1), dim3(320), DUO_LDS, st, a);
+  a.adam = OptimParams{};
+  a.nadam = 0;
+  if (adam) {
+    a.adam = *adam;
+    a.adam.ticket = nullptr;  // (the step is advanced by the optimizer launch that covers the rest of the arena)
+    // two workgroups of this launch fit on a CU (72 KB of LDS each): fill what the filter-gradient workgroups leave
+    // (measured at batch 100: 150 -> 117.7, 287 = fill -> 114.7, 400 -> 115.4, 800 -> 115.9 us per step)
+    a.nadam = 512 - (a.n2 + a.n1) > 64 ? 512 - (a.n2 + a.n1) : 64;
+  }
+  hipLaunchKernelGGL(conv_dw_duo_kernel, dim3(a.n2 + a.n1 + a.nadam), dim3(320), DUO_LDS, st, a);
   DTF_CHECK_LAUNCH();
   return 0;
 }

@@ -47,7 +47,8 @@ DTF_API int dtf_conv2_bwd_data_lds(const float* dpool2, const void* pool2, const
                                    const void* pool1, float* dpool1, float* db2, int B, hipStream_t st);
 DTF_API int dtf_conv_dw_duo(const float* dpool2, const void* pool2, const void* amax2, const void* pool1, float* dW2, int B,
                             int ipw, const float* images, const int* perm, const int* step_ptr, int spe,
-                            const float* dpool1, const void* amax1, float* dW1, float* db1, hipStream_t st);
+                            const float* dpool1, const void* amax1, float* dW1, float* db1, const struct OptimParams* adam,
+                            hipStream_t st);
 DTF_API int dtf_conv2_dw_lds(const float* dpool2, const void* pool2, const void* amax2, const void* pool1, float* dW,
                              int B, int ipw, hipStream_t st);
 DTF_API int dtf_conv2_bwd_lds(const float* dpool2, const void* pool2, const void* amax2, const float* W, const void* pool1,

@@ -87,6 +87,13 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
     loc.pool2 = const_cast<void*>(loc.gather_A[loc.gather_rank]);
     loc.dh = const_cast<void*>(loc.gather_B[loc.gather_rank]);
   }
+  // parts bit 2 (value 4): W_fc1's Adam update rides along with the conv filter-gradient launch at the end of part 2 (its
+  // gradient is final after part 1 and W_fc1 has been read by then); the caller finishes with dtf_mnist_apply_part(e, 2).
+  // Only where this rank's fc1 gradient is the GLOBAL one: a single replica, or the gather schedule.
+  const bool early_adam = (parts & 4) != 0;
+  parts &= 3;
+  if (early_adam && ((e->world > 1 && e->gather_n == 0) || e->G_fc1_dst || e->G_src || e->off_Wfc1 != 0 || e->off_bfc1 % 4))
+    return -22;
   if (e->G_fc1_dst && e->off_Wfc1 != 0) return -22;
   float* const dW_fc1 = e->G_fc1_dst ? e->G_fc1_dst : e->G + e->off_Wfc1;
   if (parts & 1) {
@@ -149,25 +156,44 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
     const int ipw = e->dw2_splits > 0 && e->dw2_splits <= 16 ? e->dw2_splits : 4;
     DTF_TRY(dtf_conv2_bwd_data_lds_packed(e->dpool2, e->pool2, e->amax2, e->wc2b, e->pool1, e->dpool1, e->G + e->off_bc2, B,
                                           st));
+    OptimParams fc1{};
+    if (early_adam) {
+      fc1.P = e->P; fc1.G = e->G; fc1.M = e->M; fc1.V = e->V;
+      fc1.n = e->off_bfc1;
+      fc1.zero_from = e->off_bfc1;  // (W_fc1's gradient is stored, never accumulated: nothing to re-zero)
+      fc1.lr = e->lr; fc1.beta1 = e->beta1; fc1.beta2 = e->beta2; fc1.eps = e->eps;
+      fc1.grad_scale = 1.0f / (float)(e->world > 0 ? e->world : 1);
+      fc1.step = e->step;
+    }
     DTF_TRY(dtf_conv_dw_duo(e->dpool2, e->pool2, e->amax2, e->pool1, e->G + e->off_Wc2, B, ipw, e->images, e->perm, e->step,
-                            e->spe, e->dpool1, e->amax1, e->G + e->off_Wc1, e->G + e->off_bc1, st));
+                            e->spe, e->dpool1, e->amax1, e->G + e->off_Wc1, e->G + e->off_bc1, early_adam ? &fc1 : nullptr,
+                            st));
   }
   return 0;
 }
 
-DTF_API int dtf_mnist_apply(const MnistEngine* e, hipStream_t st) {
+// which: 0 = whole arena; 2 = everything but W_fc1 (updated by the conv filter-gradient launch, see above) + step counter
+static int apply_range(const MnistEngine* e, int which, hipStream_t st) {
+  const long lo = which == 2 ? e->off_bfc1 : 0;
   OptimParams op{};
-  op.P = e->P; op.G = e->G; op.M = e->M; op.V = e->V;
-  op.n = e->n_arena;
-  op.zero_from = e->off_bfc1;  // everything after W_fc1 is accumulated with atomics
+  op.P = e->P + lo; op.G = e->G + lo; op.M = e->M + lo; op.V = e->V + lo;
+  op.n = e->n_arena - lo;
+  op.zero_from = which == 2 ? 0 : e->off_bfc1;  // everything after W_fc1 is accumulated with atomics
   op.lr = e->lr; op.beta1 = e->beta1; op.beta2 = e->beta2; op.eps = e->eps;
   op.grad_scale = 1.0f / (float)(e->world > 0 ? e->world : 1);
   op.step = e->step;
   op.ticket = e->ticket;
   op.metrics_ring = e->metrics_ring;
   op.ring = e->ring;
-  op.Gsrc = e->G_src;
+  op.Gsrc = e->G_src ? e->G_src + lo : nullptr;
   return dtf_adam_tf(&op, st);
+}
+
+DTF_API int dtf_mnist_apply(const MnistEngine* e, hipStream_t st) { return apply_range(e, 0, st); }
+DTF_API int dtf_mnist_apply_part(const MnistEngine* e, int which, hipStream_t st) {
+  if (which != 0 && which != 2) return -22;
+  if (which == 2 && (e->off_Wfc1 != 0 || e->off_bfc1 % 4 || (e->n_arena - e->off_bfc1) % 4)) return -22;
+  return apply_range(e, which, st);
 }
 
 // Inference / evaluation over n samples (contiguous or via `index`), chunked by the workspace size.

@@ -7,9 +7,11 @@
 // finish (arrival ticket), so a captured hipGraph can be replayed without any host-side argument patch.
 #include "common.h"
 #include "dtf_structs.h"
+#include "adam_body.h"
 
 
 __device__ __forceinline__ void finish_step(const OptimParams& p, int t) {
+  if (!p.ticket) return;  // a partial update of the arena: the launch covering the rest advances the step
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned int prev = atomicAdd(p.ticket, 1u);
@@ -26,44 +28,7 @@ __device__ __forceinline__ void finish_step(const OptimParams& p, int t) {
 
 __global__ __launch_bounds__(256) void adam_tf_kernel(const OptimParams p) {
   const int t = *p.step + 1;
-  const double b1p = pow((double)p.beta1, (double)t), b2p = pow((double)p.beta2, (double)t);
-  const float lr_t = (float)((double)p.lr * sqrt(1.0 - b2p) / (1.0 - b1p));
-  const float b1 = p.beta1, b2 = p.beta2, ob1 = 1.f - p.beta1, ob2 = 1.f - p.beta2;
-  const long n4 = p.n >> 2;
-  const float* __restrict__ gsrc = p.Gsrc ? p.Gsrc : p.G;
-  constexpr int U = 4;  // 16 independent 16-B loads in flight per lane before the first use
-  for (long base = (long)blockIdx.x * 256 * U + threadIdx.x; base < n4; base += (long)gridDim.x * 256 * U) {
-    float4 g[U], m[U], v[U], w[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long i = base + u * 256;
-      const long j = i < n4 ? i : base;  // clamped address, result discarded below
-      g[u] = reinterpret_cast<const float4*>(gsrc)[j];
-      m[u] = reinterpret_cast<const float4*>(p.M)[j];
-      v[u] = reinterpret_cast<const float4*>(p.V)[j];
-      w[u] = reinterpret_cast<const float4*>(p.P)[j];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long i = base + u * 256;
-      if (i >= n4) continue;
-      float* gp = &g[u].x;
-      float* mp = &m[u].x;
-      float* vp = &v[u].x;
-      float* wp = &w[u].x;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float gg = gp[c] * p.grad_scale;
-        mp[c] = b1 * mp[c] + ob1 * gg;
-        vp[c] = b2 * vp[c] + ob2 * gg * gg;
-        wp[c] -= lr_t * mp[c] / (sqrtf(vp[c]) + p.eps);
-      }
-      reinterpret_cast<float4*>(p.M)[i] = m[u];
-      reinterpret_cast<float4*>(p.V)[i] = v[u];
-      reinterpret_cast<float4*>(p.P)[i] = w[u];
-      if (i * 4 >= p.zero_from) reinterpret_cast<float4*>(p.G)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
+  adam_tf_body(p, t, blockIdx.x, gridDim.x, 256);
   finish_step(p, t);
 }
 
@@ -90,7 +55,7 @@ static int optim_grid(long n) {
 }
 
 DTF_API int dtf_adam_tf(const OptimParams* p, hipStream_t st) {
-  if (p->n <= 0 || p->n % 4 || p->zero_from % 4 || !p->step || !p->ticket) return -22;
+  if (p->n <= 0 || p->n % 4 || p->zero_from % 4 || !p->step) return -22;
   hipLaunchKernelGGL(adam_tf_kernel, dim3(optim_grid(p->n)), dim3(256), 0, st, *p);
   DTF_CHECK_LAUNCH();
   return 0;

@@ -218,8 +218,10 @@ class NativeMnistEngine(_EngineBase):
         """Enqueue the kernels of one step segment on stream ``st`` (directly or under capture)."""
         if key == "full":
             hook = self.grad_hook
+            # W_fc1's Adam update inside the conv filter-gradient launch, wherever this rank holds the global fc1 gradient
+            early = 4 if self.early_fc1_adam() else 0
             if hook is None:
-                rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 3, st)
+                rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 3 | early, st)
             else:
                 # in-stream gradient collective (the IPC all-reduce is plain kernels, so it is captured into the same
                 # hipGraph and the whole data-parallel step stays ONE graph launch): the fc gradients are reduced on a
@@ -227,10 +229,10 @@ class NativeMnistEngine(_EngineBase):
                 rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 1, st)
                 if rc == 0:
                     hook.after_part1(self.stream)
-                    rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 2, st)
+                    rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 2 | early, st)
                 if rc == 0:
                     hook.after_part2(self.stream)
-            return rc or self.lib.dtf_mnist_apply(C.byref(self.cfg), st)
+            return rc or self.lib.dtf_mnist_apply_part(C.byref(self.cfg), 2 if early else 0, st)
         if key.startswith("full*"):  # several consecutive steps in one graph (see train_steps)
             for _ in range(int(key[5:])):
                 rc = self._enqueue("full", st)
@@ -252,6 +254,17 @@ class NativeMnistEngine(_EngineBase):
         self.cfg.G_fc1_dst = fc1_dst or None
         self.cfg.G_src = apply_src or None
         self._drop_graph()
+
+    def early_fc1_adam(self) -> bool:
+        """Whether the single-launch step updates W_fc1 (98 % of the optimizer's bytes) inside the conv filter-gradient
+        launch, next to those latency-bound kernels, instead of in the optimizer launch after them: one replica (no
+        gradient hook), or the gather schedule, where every rank computes the global fc1 gradient itself.
+        ``DTF_EARLY_FC1_ADAM=0`` switches it off."""
+        if os.environ.get("DTF_EARLY_FC1_ADAM", "1") == "0":
+            return False
+        if self.cfg.gather_n > 0:
+            return True
+        return self.grad_hook is None and self.world == 1 and not self.cfg.G_fc1_dst and not self.cfg.G_src
 
     def gather_supported(self) -> bool:
         """The activation-gather schedule rides on the fused fc backward launch (batch <= 128, split-K data gradient)."""

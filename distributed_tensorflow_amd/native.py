@@ -139,6 +139,7 @@ def hip() -> C.CDLL:
         _sig(lib, "dtf_sgd", I, [C.POINTER(OptimParams), P])
         _sig(lib, "dtf_mnist_fwd_bwd", I, [C.POINTER(MnistEngineStruct), I, P])
         _sig(lib, "dtf_mnist_apply", I, [C.POINTER(MnistEngineStruct), P])
+        _sig(lib, "dtf_mnist_apply_part", I, [C.POINTER(MnistEngineStruct), I, P])
         _sig(lib, "dtf_mnist_eval", I, [C.POINTER(MnistEngineStruct), P, P, I, P, P, P, P])
         _sig(lib, "dtf_graph_begin", I, [P])
         _sig(lib, "dtf_graph_end", I, [P, C.POINTER(c_void_p)])
