@@ -78,6 +78,31 @@ def test_graph_replay_matches_direct_and_learns():
     assert np.isfinite(loss) and 0.0 <= acc <= 1.0
 
 
+@pytest.mark.parametrize("B", [100, 37, 200])
+def test_fused_step_matches_unfused_sequence(B):
+    """train_step() (one launch sequence: fc GEMMs fused, conv filter gradients fused, W_fc1's Adam update riding in the
+    latter, rest of the optimizer last) against fwd_bwd(3) + apply() (gradients materialised, one optimizer launch over
+    the whole arena): same parameters and moments up to fp32 atomic ordering, step by step."""
+    from distributed_tensorflow_amd.engine.mnist_engine import NativeMnistEngine
+    dd1, dd2 = _dataset(n=4000, seed=3), _dataset(n=4000, seed=3)
+    e1 = NativeMnistEngine(dd1, batch_size=B, seed=5, eval_chunk=500, lr=1e-3, double_softmax=False)
+    e2 = NativeMnistEngine(dd2, batch_size=B, seed=5, eval_chunk=500, lr=1e-3, double_softmax=False, use_graph=False)
+    assert e1.early_fc1_adam()
+    for _ in range(2):
+        e1.train_step()
+        e2.fwd_bwd(3)
+        e2.apply()
+        torch.cuda.synchronize()
+        dp = float((e1.P - e2.P).abs().max())
+        dm = float((e1.M - e2.M).abs().max() / e2.M.abs().max())
+        dv = float((e1.V - e2.V).abs().max() / e2.V.abs().max())
+        assert dp < 1e-4 and dm < 1e-4 and dv < 1e-4, (dp, dm, dv)  # (one Adam step moves a parameter by up to lr = 1e-3)
+    assert int(e1.step_t.item()) == 2 == int(e2.step_t.item())
+    # the atomically accumulated gradient segments are re-zeroed by both optimizer paths
+    lo = e1.layout["b_fc1"][0]
+    assert float(e1.G[lo:].abs().max()) == 0.0 and float(e2.G[lo:].abs().max()) == 0.0
+
+
 def test_multi_step_graph_matches_single_steps():
     """train_steps() replays 8 steps per graph launch; it must walk through the same batches, dropout masks and Adam
     steps as 8 single launches, also across an epoch boundary (reshuffle between chunks)."""
