@@ -143,7 +143,8 @@ def main():
             "config": {"model": "demo2 MNIST CNN (conv5x5x32-pool-conv5x5x64-pool-fc1024-dropout-fc10), Adam 1e-4",
                        "global_batch": global_batch, "seq_len": None, "parallelism": "dp%d" % world,
                        "per_gpu_batch": args.batch, "engine": args.engine, "hipgraph": not args.no_graph,
-                       "overlap_allreduce": not args.no_overlap, "gradient_transport": trainer.comm,
+                       "overlap_allreduce": (not args.no_overlap) if trainer._multi else None,
+                       "gradient_transport": trainer.comm if trainer._multi else None,
                        "dp_schedule": getattr(trainer, "schedule", None)},
             "final_test_accuracy": None if test_acc is None else round(float(test_acc), 4),
             "final_train_loss": last_loss,
