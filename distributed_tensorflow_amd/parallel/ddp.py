@@ -332,6 +332,7 @@ class DataParallelTrainer:
             for c in cands:
                 use(c)
                 self.prepare()
+                dist.barrier(group=self.group)  # graph capture takes a different time on every rank; the waits are short here
                 # one step from the snapshot: Adam's first moment is linear in the gradient, m' = b1*m + (1-b1)*g, which
                 # gives the reduced gradient this schedule produced, wherever it keeps it
                 self.train_steps(1)
