@@ -108,6 +108,48 @@ def test_conv1_forward_no_index(ops):
     assert relerr(out, ref) < 1e-2
 
 
+def test_conv1_forward_pool_ties_and_dead_windows(ops):
+    """Flat images make every interior 2x2 window a four-way tie; the argmax must still name ONE position of the
+    window, and un-pooling through it must conserve the gradient.  A negative bias on half of the channels makes those
+    windows all-zero after ReLU: they pool to zero and take no gradient."""
+    B = 4
+    imgs = torch.full((B, 784), 0.5, device=dev())
+    imgs[1].zero_()
+    w = torch.full((5, 5, 1, 32), 0.04, device=dev())
+    b = torch.cat([torch.full((16,), 0.1), torch.full((16,), -5.0)]).to(dev())
+    out, amax = ops.conv1_forward(imgs, w.view(25, 32).contiguous(), b)
+    ref = F.max_pool2d(torch.relu(_conv1_ref(imgs, w, b)), 2).permute(0, 2, 3, 1)
+    assert relerr(out, ref) < 1e-2
+    assert int(amax.max()) <= 3
+    assert float(out[..., 16:].float().abs().max()) == 0.0
+    dpool = torch.rand(B, 14, 14, 32, device=dev()) + 0.5
+    dy, db = ops.unpool(dpool, out, amax)
+    live = (out.float() > 0)
+    assert relerr(dy.float().reshape(B, 14, 2, 14, 2, 32).sum((2, 4)), dpool * live) < 1e-2
+    # exactly one position per live window carries the gradient
+    nz = (dy.float().reshape(B, 14, 2, 14, 2, 32) != 0).sum((2, 4))
+    assert torch.equal(nz, live.long())
+    assert relerr(db, (dpool * live).sum((0, 1, 2))) < 1e-4
+
+
+def test_conv_forward_at_evaluation_batch(ops):
+    """The evaluation path pushes the whole 10 000-image test set through the forward kernels in one call."""
+    torch.manual_seed(21)
+    B = 10000
+    imgs = torch.rand(B, 784, device=dev())
+    w1 = torch.randn(5, 5, 1, 32, device=dev()) * 0.1
+    b1 = torch.randn(32, device=dev()) * 0.1
+    p1, _ = ops.conv1_forward(imgs, w1.view(25, 32).contiguous(), b1)
+    ref1 = F.max_pool2d(torch.relu(_conv1_ref(imgs, w1, b1)), 2).permute(0, 2, 3, 1)
+    assert relerr(p1, ref1) < 1e-2
+    w2 = torch.randn(5, 5, 32, 64, device=dev()) * 0.05
+    b2 = torch.randn(64, device=dev()) * 0.1
+    p2, _ = ops.conv_bias_relu_pool(p1, w2.view(800, 64).contiguous(), b2, 5, 5)
+    c = F.conv2d(p1.float().permute(0, 3, 1, 2), r(w2).permute(3, 2, 0, 1), b2, padding=2)
+    ref2 = F.max_pool2d(torch.relu(c), 2).permute(0, 2, 3, 1)
+    assert relerr(p2, ref2) < 1e-2
+
+
 @pytest.mark.parametrize("B", [100, 3])
 def test_conv2_forward_pool(ops, B):
     torch.manual_seed(6)
