@@ -533,7 +533,7 @@ DTF_API int dtf_conv_dw_duo(const float* dpool2, const void* pool2, const void* 
     a.adam = *adam;
     a.adam.ticket = nullptr;  // (the step is advanced by the optimizer launch that covers the rest of the arena)
     // two workgroups of this launch fit on a CU (72 KB of LDS each): fill what the filter-gradient workgroups leave
-    // (measured at batch 100: 150 -> 117.7, 287 = fill -> 114.7, 400 -> 115.4, 800 -> 115.9 us per step)
+    // (measured at batch 100, 4 images per conv2 workgroup: 150 -> 117.7, 287 = fill -> 114.7, 400 -> 115.4, 800 -> 115.9 us per step)
     a.nadam = 512 - (a.n2 + a.n1) > 64 ? 512 - (a.n2 + a.n1) : 64;
   }
   hipLaunchKernelGGL(conv_dw_duo_kernel, dim3(a.n2 + a.n1 + a.nadam), dim3(320), DUO_LDS, st, a);

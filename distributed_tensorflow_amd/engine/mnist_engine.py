@@ -62,10 +62,14 @@ class NativeMnistEngine(_EngineBase):
     def __init__(self, dataset: Optional[DeviceDataset], *, batch_size: int = 100, lr: float = 1e-4,
                  keep_prob: float = 0.7, double_softmax: bool = True, seed: Optional[int] = None,
                  world: int = 1, eval_chunk: int = 5000, use_graph: bool = True,
-                 fc1_splits: int = 14, bwd_splits: int = 2, dw2_splits: int = 4, head_blocks: int = 0,
+                 fc1_splits: int = 14, bwd_splits: int = 2, dw2_splits: int = 5, head_blocks: int = 0,
                  beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, device="cuda"):
         if not torch.cuda.is_available():
             raise native.NativeError("NativeMnistEngine needs a GPU (MI355X); use EagerMnistEngine on CPU")
+        bwd_splits = int(os.environ.get("DTF_BWD_SPLITS", bwd_splits))  # (tuning knobs for A/B runs of bench.py)
+        fc1_splits = int(os.environ.get("DTF_FC1_SPLITS", fc1_splits))
+        dw2_splits = int(os.environ.get("DTF_DW2_IPW", dw2_splits))
+        head_blocks = int(os.environ.get("DTF_HEAD_BLOCKS", head_blocks))
         self.lib = native.hip()
         native.check(self.lib.dtf_conv2_lds_init() or self.lib.dtf_conv2_bwd_lds_init(),
                      "LDS kernel attribute setup")  # before any stream capture
@@ -108,7 +112,6 @@ class NativeMnistEngine(_EngineBase):
         s = native.MnistEngineStruct()
         s.B, s.maxB, s.spe, s.world = batch_size, self.maxB, self.spe, world
         s.double_softmax = int(double_softmax)
-        bwd_splits = int(os.environ.get("DTF_BWD_SPLITS", bwd_splits))  # (tuning knob for A/B runs of bench.py)
         s.fc1_splits, s.bwd_splits, s.dw2_splits = fc1_splits, bwd_splits, dw2_splits
         s.head_blocks = head_blocks if head_blocks > 0 else max(1, (batch_size + 1) // 2)
         s.ring = self.RING
