@@ -2,29 +2,50 @@
 // the update of the fc1 weights with the conv filter gradients (conv2_lds.hip) share it.
 //   lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  m,v EMA;  p -= lr_t*m/(sqrt(v)+eps)   (eps outside the bias correction)
 // Workgroup `block` of `nblocks`, `nthreads` threads each, grid-strides over p.n/4 float4 with U of them in flight per lane.
+// Returns the 1-based step t = *p.step + 1 it applied.
 #pragma once
 #include "common.h"
 #include "dtf_structs.h"
 
-__device__ __forceinline__ void adam_tf_body(const OptimParams& p, const int t, const int block, const int nblocks,
-                                             const int nthreads) {
-  const double b1p = pow((double)p.beta1, (double)t), b2p = pow((double)p.beta2, (double)t);
-  const float lr_t = (float)((double)p.lr * sqrt(1.0 - b2p) / (1.0 - b1p));
+// b^t for integer t >= 0 by repeated squaring in double: <= 62 multiplications (relative error ~1e-14), a fraction of
+// what the library pow costs -- the bias correction sits on the critical path of the short optimizer launch.
+__device__ __forceinline__ void beta_powers(double b1, double b2, int t, double& b1p, double& b2p) {
+  b1p = 1.0;
+  b2p = 1.0;
+  for (unsigned int e = (unsigned int)t; e; e >>= 1) {
+    if (e & 1u) { b1p *= b1; b2p *= b2; }
+    b1 *= b1;
+    b2 *= b2;
+  }
+}
+
+__device__ __forceinline__ int adam_tf_body(const OptimParams& p, const int block, const int nblocks, const int nthreads) {
   const float b1 = p.beta1, b2 = p.beta2, ob1 = 1.f - p.beta1, ob2 = 1.f - p.beta2;
   const long n4 = p.n >> 2;
   const float* __restrict__ gsrc = p.Gsrc ? p.Gsrc : p.G;
   constexpr int U = 4;  // 16 independent 16-B loads in flight per lane before the first use
-  for (long base = (long)block * nthreads * U + threadIdx.x; base < n4; base += (long)nblocks * nthreads * U) {
-    float4 g[U], m[U], v[U], w[U];
+  const long stride = (long)nblocks * nthreads * U;
+  long base = (long)block * nthreads * U + threadIdx.x;
+  float4 g[U], m[U], v[U], w[U];
+  auto load = [&](long at) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long i = base + (long)u * nthreads;
-      const long j = i < n4 ? i : base;  // clamped address, result discarded below
+      const long i = at + (long)u * nthreads;
+      const long j = i < n4 ? i : at;  // clamped address, result discarded below
       g[u] = reinterpret_cast<const float4*>(gsrc)[j];
       m[u] = reinterpret_cast<const float4*>(p.M)[j];
       v[u] = reinterpret_cast<const float4*>(p.V)[j];
       w[u] = reinterpret_cast<const float4*>(p.P)[j];
     }
+  };
+  if (base < n4) load(base);
+  // the step counter and the bias correction are needed for the update only: fetched and computed while the first
+  // batch of loads is in flight
+  const int t = *p.step + 1;
+  double b1p, b2p;
+  beta_powers((double)p.beta1, (double)p.beta2, t, b1p, b2p);
+  const float lr_t = (float)((double)p.lr * sqrt(1.0 - b2p) / (1.0 - b1p));
+  while (base < n4) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long i = base + (long)u * nthreads;
@@ -45,5 +66,8 @@ __device__ __forceinline__ void adam_tf_body(const OptimParams& p, const int t, 
       reinterpret_cast<float4*>(p.P)[i] = w[u];
       if (i * 4 >= p.zero_from) reinterpret_cast<float4*>(p.G)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    base += stride;
+    if (base < n4) load(base);
   }
+  return t;
 }

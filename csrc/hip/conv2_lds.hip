@@ -444,7 +444,7 @@ __global__ __launch_bounds__(320) void conv_dw_duo_kernel(const ConvDwDuo a) {
   if (id < a.n2)
     conv2_dw_body(smem, id % a.gx, id / a.gx, a.pool1, a.dpool2, a.pool2, a.amax2, a.dW2, a.B, a.ipw);
   else if (id >= a.n2 + a.n1)
-    adam_tf_body(a.adam, *a.adam.step + 1, id - a.n2 - a.n1, a.nadam, 320);
+    adam_tf_body(a.adam, id - a.n2 - a.n1, a.nadam, 320);
   else
     conv1_dw_body(reinterpret_cast<float*>(smem), id - a.n2, a.n1, a.images, a.perm, a.step_ptr, a.spe, a.B, a.dpool1,
                   a.amax1, a.dW1, a.db1);

@@ -27,8 +27,7 @@ __device__ __forceinline__ void finish_step(const OptimParams& p, int t) {
 }
 
 __global__ __launch_bounds__(256) void adam_tf_kernel(const OptimParams p) {
-  const int t = *p.step + 1;
-  adam_tf_body(p, t, blockIdx.x, gridDim.x, 256);
+  const int t = adam_tf_body(p, blockIdx.x, gridDim.x, 256);
   finish_step(p, t);
 }
 
