@@ -293,13 +293,20 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const uint16_t*
         s1[j] += red[(k * c8n + cg) * 16 + j];
         s2[j] += red[(k * c8n + cg) * 16 + 8 + j];
       }
-    float* slot = slots + (long)(blockIdx.x % DTF_STAT_SLOTS) * 2 * C;
+  }
+  // channel-contiguous atomics: a lane-strided add (lane = 8 channels) sends every destination line 8 requests per
+  // workgroup, and the L2 serialises requests to one line; through LDS each line gets one
+  __syncthreads();
+  if (active && ry == 0) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      atomicAdd(&slot[c0 + j], s1[j]);
-      atomicAdd(&slot[C + c0 + j], s2[j]);
+      red[c0 + j] = s1[j];
+      red[C + c0 + j] = s2[j];
     }
   }
+  __syncthreads();
+  float* slot = slots + (long)(blockIdx.x % DTF_STAT_SLOTS) * 2 * C;
+  for (int e = tid; e < 2 * C; e += 256) atomicAdd(&slot[e], red[e]);
 }
 
 DTF_API int dtf_bn_relu_bwd_reduce(const void* dy, int dy_cstride, const void* z, const float* bn, float* slots, long M,

@@ -103,11 +103,9 @@ __global__ __launch_bounds__(256) void retrain_head_fwd_kernel(const RetrainHead
       if (p.probs) p.probs[(long)row * p.C + c] = pr;
     }
   }
-  if (lane == 0) {
-    atomicAdd(&p.metrics[0], loss);
-    atomicAdd(&p.metrics[1], arg == y ? 1.f : 0.f);
-    if (p.pred) p.pred[row] = arg;
-  }
+  // (loss, arg and y are wave-uniform) both totals in one atomic instruction: they share a cache line with every other row's
+  if (lane < 2) atomicAdd(&p.metrics[lane], lane == 0 ? loss : (arg == y ? 1.f : 0.f));
+  if (lane == 0 && p.pred) p.pred[row] = arg;
 }
 
 DTF_API int dtf_retrain_head_fwd(const RetrainHeadParams* p, hipStream_t st) {
