@@ -132,8 +132,7 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
       // this rank's fc1 operands (bf16 pool2 [B,3136], dh [B,1024]) are complete: tell the peers, wait for theirs, and
       // pull theirs into local memory (one pass over each xGMI link)
       if (e->gather_bytes != (long)B * (3136 + 1024) * 2 || !e->gather_local) return -22;
-      DTF_TRY(dtf_ipc_sync(e->gather_comm, st));
-      DTF_TRY(dtf_ipc_gather_copy(e->gather_comm, e->gather_local, e->gather_bytes, 16, st));
+      DTF_TRY(dtf_ipc_sync_gather(e->gather_comm, e->gather_local, e->gather_bytes, 16, st));
     }
     if (trio_ok(e)) {
       // fc1 dW[3136][1024] = pool2^T * dh (stored: 12.8 MB, the one gradient that is never re-zeroed), fc2 dW[1024][10] =

@@ -38,7 +38,7 @@ struct IpcComm {
   long n_max;                  // capacity in floats (multiple of 4)
   unsigned char* base[MAX_RANKS];  // every rank's shared allocation as mapped into this process
   unsigned* epoch;             // device word (ordinary memory): epoch of the all-reduce in flight
-  unsigned* error;             // device word: number of expired waits
+  unsigned* error;             // device word: number of expired waits (== epoch + 1; epoch + 2 is an arrival ticket)
   unsigned long long timeout_ticks;  // wall_clock64 ticks (100 MHz)
 };
 
@@ -212,6 +212,50 @@ __global__ __launch_bounds__(256) void ipc_gather_copy_kernel(const IpcComm c, f
   }
 }
 
+// The two kernels above as ONE launch (a launch boundary costs ~2.5 us of a ~110 us step): workgroup 0 announces this
+// rank's operands to every peer; each workgroup then waits for ITS peer's announcement only and copies its share of that
+// peer's operands.  The epoch word is read by every workgroup before the last one to finish advances it (arrival
+// ticket in the device word after `error`), so no workgroup can see the new value early.  Same ordering contract as
+// dtf_ipc_sync + dtf_ipc_gather_copy: when the launch has completed, every peer has announced and been read.
+__global__ __launch_bounds__(256) void ipc_sync_gather_kernel(const IpcComm c, f32x4* __restrict__ dst, long n4,
+                                                             int blocks_per_peer) {
+  const unsigned e = *c.epoch + 1u;
+  unsigned* ticket = c.epoch + 2;
+  if (blockIdx.x == 0 && threadIdx.x < c.world)
+    __hip_atomic_store(&ready_flags(c.base[threadIdx.x])[c.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  const int slot = blockIdx.x / blocks_per_peer, sub = blockIdx.x % blocks_per_peer;
+  const int p = slot + (slot >= c.rank ? 1 : 0);  // peers only
+  if (p < c.world) {
+    if (threadIdx.x == 0) {
+      if (!wait_flag(&ready_flags(c.base[c.rank])[p], e, c.timeout_ticks) && sub == 0) atomicAdd(c.error, 1u);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: the peer's stage buffer is read below
+    }
+    __syncthreads();
+    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(stage_of(c.base[p]));
+    f32x4* __restrict__ d = dst + (long)p * n4;
+    for (long base = (long)sub * 256 * COPY_U + threadIdx.x; base < n4; base += (long)blocks_per_peer * 256 * COPY_U) {
+      f32x4 v[COPY_U];
+#pragma unroll
+      for (int u = 0; u < COPY_U; ++u) {
+        const long i = base + u * 256;
+        v[u] = src[i < n4 ? i : base];
+      }
+#pragma unroll
+      for (int u = 0; u < COPY_U; ++u) {
+        const long i = base + u * 256;
+        if (i < n4) d[i] = v[u];
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    const unsigned prev = atomicAdd(ticket, 1u);
+    if (prev == gridDim.x - 1) {
+      *ticket = 0u;
+      *c.epoch = e;
+    }
+  }
+}
+
 // dst <- the first n4 16-byte units of rank `peer`'s stage buffer (general-purpose all-gather / broadcast building block)
 __global__ __launch_bounds__(256) void ipc_copy_from_kernel(const IpcComm c, int peer, f32x4* __restrict__ dst, long n4) {
   copy_f4(dst, reinterpret_cast<const f32x4*>(stage_of(c.base[peer])), n4);
@@ -296,6 +340,22 @@ DTF_API int dtf_ipc_gather_copy(const void* comm, void* dst, long bytes, int blo
   if (blocks_per_peer > 64) blocks_per_peer = 64;
   hipLaunchKernelGGL(ipc_gather_copy_kernel, dim3((c.world - 1) * blocks_per_peer), dim3(256), 0, st, c,
                      reinterpret_cast<f32x4*>(dst), bytes / 16, blocks_per_peer);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// dtf_ipc_sync + dtf_ipc_gather_copy in one launch (see ipc_sync_gather_kernel).  The comm's device words must be
+// [epoch, error, ticket] (ticket zero-initialised), as IpcAllReduce allocates them.
+DTF_API int dtf_ipc_sync_gather(const void* comm, void* dst, long bytes, int blocks_per_peer, hipStream_t st) {
+  const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
+  if (!dst || bytes <= 0 || bytes % 16 || bytes / 4 > c.n_max || c.world < 1 || c.world > MAX_RANKS || c.rank < 0 ||
+      c.rank >= c.world || c.error != c.epoch + 1)
+    return -22;
+  if (blocks_per_peer < 1) blocks_per_peer = 16;
+  if (blocks_per_peer > 64) blocks_per_peer = 64;
+  const int grid = c.world > 1 ? (c.world - 1) * blocks_per_peer : 1;
+  hipLaunchKernelGGL(ipc_sync_gather_kernel, dim3(grid), dim3(256), 0, st, c, reinterpret_cast<f32x4*>(dst), bytes / 16,
+                     blocks_per_peer);
   DTF_CHECK_LAUNCH();
   return 0;
 }

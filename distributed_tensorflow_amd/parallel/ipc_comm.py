@@ -92,7 +92,7 @@ class IpcAllReduce:
                     bases[p] = ptr.value
                     self._mapped.append(ptr.value)
                 self._bases = [int(bases[p]) for p in range(self.world)]
-                self._words = torch.zeros(2, dtype=torch.int32, device=self.device)  # epoch, error
+                self._words = torch.zeros(4, dtype=torch.int32, device=self.device)  # epoch, error, arrival ticket, spare
                 self.comm = _IpcCommStruct(self.rank, self.world, self.n_max, bases, self._words.data_ptr(),
                                            self._words.data_ptr() + 4, int(timeout_s * 100e6))
                 torch.cuda.synchronize(self.device)
