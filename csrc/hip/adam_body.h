@@ -7,6 +7,23 @@
 #include "common.h"
 #include "dtf_structs.h"
 
+// The last workgroup to finish advances the step counter (arrival ticket), so a captured graph replays unchanged.
+__device__ __forceinline__ void finish_step(const OptimParams& p, int t) {
+  if (!p.ticket) return;  // a partial update of the arena: the launch covering the rest advances the step
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int prev = atomicAdd(p.ticket, 1u);
+    if (prev == gridDim.x - 1) {  // every workgroup has read *step and finished its updates
+      *p.ticket = 0u;
+      *p.step = t;
+      if (p.metrics_ring && p.ring > 0) {
+        p.metrics_ring[2 * (t % p.ring)] = 0.f;
+        p.metrics_ring[2 * (t % p.ring) + 1] = 0.f;
+      }
+    }
+  }
+}
+
 // b^t for integer t >= 0 by repeated squaring in double: <= 62 multiplications (relative error ~1e-14), a fraction of
 // what the library pow costs -- the bias correction sits on the critical path of the short optimizer launch.
 __device__ __forceinline__ void beta_powers(double b1, double b2, int t, double& b1p, double& b2p) {
@@ -19,6 +36,9 @@ __device__ __forceinline__ void beta_powers(double b1, double b2, int t, double&
   }
 }
 
+// MULTI: the gradient is the sum, in index order, of p.nsrc buffers p.Gsrcs[] (the ranks' exchange buffers of a one-shot
+// all-reduce: the reduction happens in the optimizer's own loads, bit-identical on every rank).
+template <bool MULTI = false>
 __device__ __forceinline__ int adam_tf_body(const OptimParams& p, const int block, const int nblocks, const int nthreads) {
   const float b1 = p.beta1, b2 = p.beta2, ob1 = 1.f - p.beta1, ob2 = 1.f - p.beta2;
   const long n4 = p.n >> 2;
@@ -32,7 +52,18 @@ __device__ __forceinline__ int adam_tf_body(const OptimParams& p, const int bloc
     for (int u = 0; u < U; ++u) {
       const long i = at + (long)u * nthreads;
       const long j = i < n4 ? i : at;  // clamped address, result discarded below
-      g[u] = reinterpret_cast<const float4*>(gsrc)[j];
+      if (MULTI) {
+        float4 part[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if (r < p.nsrc) part[r] = reinterpret_cast<const float4*>(p.Gsrcs[r])[j];
+        g[u] = part[0];
+#pragma unroll
+        for (int r = 1; r < 8; ++r)
+          if (r < p.nsrc) { g[u].x += part[r].x; g[u].y += part[r].y; g[u].z += part[r].z; g[u].w += part[r].w; }
+      } else {
+        g[u] = reinterpret_cast<const float4*>(gsrc)[j];
+      }
       m[u] = reinterpret_cast<const float4*>(p.M)[j];
       v[u] = reinterpret_cast<const float4*>(p.V)[j];
       w[u] = reinterpret_cast<const float4*>(p.P)[j];

@@ -14,6 +14,8 @@ DTF_API int dtf_fc_bwd_trio(const void* X0, const void* dY0, float* dW0, int M0,
                             int Kq, int splits, const void* const* gA, const void* const* gB, int granks, hipStream_t st);
 DTF_API int dtf_ipc_sync(const void* comm, hipStream_t st);
 DTF_API int dtf_ipc_gather_copy(const void* comm, void* dst, long bytes, int blocks_per_peer, hipStream_t st);
+DTF_API int dtf_ipc_publish(const void* comm, const float* src, long n, int blocks, hipStream_t st);
+DTF_API int dtf_ipc_adam_oneshot(const void* comm, const OptimParams* op, hipStream_t st);
 DTF_API int dtf_ipc_sync_gather(const void* comm, void* dst, long bytes, int blocks_per_peer, hipStream_t st);
 DTF_API int dtf_fc_dw_pair(const void* X0, const void* dY0, float* dW0, int M0, int N0, const void* X1, const void* dY1,
                            float* dW1, int M1, int N1, int K, hipStream_t st);

@@ -47,4 +47,6 @@ struct OptimParams {
   int ring;
   const float* Gsrc;     // optional: read the gradients from here instead of G (an all-reduce result buffer);
                          // the re-zeroing of [zero_from, n) still applies to G
+  const float* Gsrcs[8];  // fused one-shot all-reduce (dtf_ipc_adam_oneshot): gradient = sum of the first nsrc of these
+  int nsrc;
 };

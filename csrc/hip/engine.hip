@@ -172,7 +172,7 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
 }
 
 // which: 0 = whole arena; 2 = everything but W_fc1 (updated by the conv filter-gradient launch, see above) + step counter
-static int apply_range(const MnistEngine* e, int which, hipStream_t st) {
+static OptimParams optim_range(const MnistEngine* e, int which) {
   const long lo = which == 2 ? e->off_bfc1 : 0;
   OptimParams op{};
   op.P = e->P + lo; op.G = e->G + lo; op.M = e->M + lo; op.V = e->V + lo;
@@ -185,6 +185,10 @@ static int apply_range(const MnistEngine* e, int which, hipStream_t st) {
   op.metrics_ring = e->metrics_ring;
   op.ring = e->ring;
   op.Gsrc = e->G_src ? e->G_src + lo : nullptr;
+  return op;
+}
+static int apply_range(const MnistEngine* e, int which, hipStream_t st) {
+  const OptimParams op = optim_range(e, which);
   return dtf_adam_tf(&op, st);
 }
 
@@ -193,6 +197,15 @@ DTF_API int dtf_mnist_apply_part(const MnistEngine* e, int which, hipStream_t st
   if (which != 0 && which != 2) return -22;
   if (which == 2 && (e->off_Wfc1 != 0 || e->off_bfc1 % 4 || (e->n_arena - e->off_bfc1) % 4)) return -22;
   return apply_range(e, which, st);
+}
+
+// dtf_mnist_apply_part with the gradients of the range summed over the ranks inside the optimizer launch: every rank has
+// published G[range] with dtf_ipc_publish on `comm` earlier in the stream (gather schedule: the range after W_fc1).
+DTF_API int dtf_mnist_apply_part_ipc(const MnistEngine* e, int which, const void* comm, hipStream_t st) {
+  if ((which != 0 && which != 2) || !comm || e->G_src) return -22;
+  if (which == 2 && (e->off_Wfc1 != 0 || e->off_bfc1 % 4 || (e->n_arena - e->off_bfc1) % 4)) return -22;
+  const OptimParams op = optim_range(e, which);
+  return dtf_ipc_adam_oneshot(comm, &op, st);
 }
 
 // Inference / evaluation over n samples (contiguous or via `index`), chunked by the workspace size.

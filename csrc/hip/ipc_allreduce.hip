@@ -27,6 +27,8 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include "common.h"
+#include "dtf_structs.h"
+#include "adam_body.h"
 #include "dtf_api.h"
 
 namespace {
@@ -288,6 +290,23 @@ __global__ __launch_bounds__(256) void ipc_reduce_all_kernel(const IpcComm c, fl
     d4[i] = s0;
   }
 }
+
+// The one-shot all-reduce fused into the optimizer launch that consumes it: after the flag exchange the Adam kernel's own
+// gradient loads sum every rank's stage buffer (rank order: bit-identical everywhere), so neither the reduction kernel
+// nor its result buffer exist.  Same contract as ipc_reduce_all_kernel (the publish kernel precedes it in the stream).
+__global__ __launch_bounds__(256) void ipc_reduce_adam_kernel(const IpcComm c, const OptimParams p) {
+  const unsigned e = *c.epoch;
+  if (threadIdx.x < c.world) {
+    const int q = threadIdx.x;
+    if (blockIdx.x == 0)
+      __hip_atomic_store(&ready_flags(c.base[q])[c.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!wait_flag(&ready_flags(c.base[c.rank])[q], e, c.timeout_ticks) && blockIdx.x == 0) atomicAdd(c.error, 1u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  }
+  __syncthreads();
+  const int t = adam_tf_body<true>(p, blockIdx.x, gridDim.x, 256);
+  finish_step(p, t);
+}
 }  // namespace
 
 // ---- allocation / handle exchange (host)
@@ -410,6 +429,39 @@ DTF_API int dtf_ipc_allreduce_oneshot(const void* comm, const float* src, float*
   if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(ipc_publish_kernel, dim3(blocks), dim3(256), 0, st, c, src, n);
   hipLaunchKernelGGL(ipc_reduce_all_kernel, dim3(blocks), dim3(256), 0, st, c, dst, n);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// First half of dtf_ipc_allreduce_oneshot on its own: copy src into this rank's stage buffer (the flag exchange and
+// the reduction happen in the consumer, dtf_ipc_adam_oneshot).
+DTF_API int dtf_ipc_publish(const void* comm, const float* src, long n, int blocks, hipStream_t st) {
+  const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
+  if (!src || n <= 0 || n % 4 || n > c.n_max || c.world < 1 || c.world > MAX_RANKS || c.rank < 0 || c.rank >= c.world) return -22;
+  if (blocks < 1) blocks = 32;
+  const long want = (n / 4 + 256 * COPY_U - 1) / (256 * COPY_U);
+  if (blocks > want) blocks = (int)want;
+  hipLaunchKernelGGL(ipc_publish_kernel, dim3(blocks), dim3(256), 0, st, c, src, n);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// TF-Adam over op's range with the gradient taken as the sum of every rank's published buffer (op->n floats each, see
+// dtf_ipc_publish): op->G is only re-zeroed, op->Gsrc / Gsrcs are set here.  Same "another barrier before the next
+// publish" contract as dtf_ipc_allreduce_oneshot.
+DTF_API int dtf_ipc_adam_oneshot(const void* comm, const OptimParams* op, hipStream_t st) {
+  const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
+  if (c.world < 1 || c.world > MAX_RANKS || c.rank < 0 || c.rank >= c.world) return -22;
+  if (!op || op->n <= 0 || op->n % 4 || op->n > c.n_max || op->zero_from % 4 || !op->step) return -22;
+  OptimParams p = *op;
+  p.Gsrc = nullptr;
+  p.nsrc = c.world;
+  for (int r = 0; r < MAX_RANKS; ++r)
+    p.Gsrcs[r] = r < c.world ? reinterpret_cast<const float*>(c.base[r] + HDR_BYTES) : nullptr;
+  long blocks = (p.n / 4 + 1023) / 1024;  // 4 float4 per lane per pass, as the plain optimizer launch
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(ipc_reduce_adam_kernel, dim3((int)blocks), dim3(256), 0, st, c, p);
   DTF_CHECK_LAUNCH();
   return 0;
 }

@@ -10,22 +10,6 @@
 #include "adam_body.h"
 
 
-__device__ __forceinline__ void finish_step(const OptimParams& p, int t) {
-  if (!p.ticket) return;  // a partial update of the arena: the launch covering the rest advances the step
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned int prev = atomicAdd(p.ticket, 1u);
-    if (prev == gridDim.x - 1) {  // every workgroup has read *step and finished its updates
-      *p.ticket = 0u;
-      *p.step = t;
-      if (p.metrics_ring && p.ring > 0) {
-        p.metrics_ring[2 * (t % p.ring)] = 0.f;
-        p.metrics_ring[2 * (t % p.ring) + 1] = 0.f;
-      }
-    }
-  }
-}
-
 __global__ __launch_bounds__(256) void adam_tf_kernel(const OptimParams p) {
   const int t = adam_tf_body(p, blockIdx.x, gridDim.x, 256);
   finish_step(p, t);

@@ -236,6 +236,11 @@ class NativeMnistEngine(_EngineBase):
                     rc = self.lib.dtf_mnist_fwd_bwd(C.byref(self.cfg), 2 | early, st)
                 if rc == 0:
                     hook.after_part2(self.stream)
+            comm = getattr(hook, "apply_comm", None)
+            if rc == 0 and comm is not None:  # gather schedule: the optimizer launch reduces the published gradients itself
+                if not early:
+                    return -22  # (only the arena after W_fc1 is published; its own update must have happened above)
+                return self.lib.dtf_mnist_apply_part_ipc(C.byref(self.cfg), 2, C.byref(comm), st)
             return rc or self.lib.dtf_mnist_apply_part(C.byref(self.cfg), 2 if early else 0, st)
         if key.startswith("full*"):  # several consecutive steps in one graph (see train_steps)
             for _ in range(int(key[5:])):

@@ -47,7 +47,7 @@ class OptimParams(C.Structure):
         ("n", c_long), ("zero_from", c_long),
         ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("grad_scale", c_float),
         ("step", c_void_p), ("ticket", c_void_p), ("metrics_ring", c_void_p), ("ring", c_int),
-        ("Gsrc", c_void_p),
+        ("Gsrc", c_void_p), ("Gsrcs", c_void_p * 8), ("nsrc", c_int),
     ]
 
 
@@ -140,6 +140,7 @@ def hip() -> C.CDLL:
         _sig(lib, "dtf_mnist_fwd_bwd", I, [C.POINTER(MnistEngineStruct), I, P])
         _sig(lib, "dtf_mnist_apply", I, [C.POINTER(MnistEngineStruct), P])
         _sig(lib, "dtf_mnist_apply_part", I, [C.POINTER(MnistEngineStruct), I, P])
+        _sig(lib, "dtf_mnist_apply_part_ipc", I, [C.POINTER(MnistEngineStruct), I, P, P])
         _sig(lib, "dtf_mnist_eval", I, [C.POINTER(MnistEngineStruct), P, P, I, P, P, P, P])
         _sig(lib, "dtf_graph_begin", I, [P])
         _sig(lib, "dtf_graph_end", I, [P, C.POINTER(c_void_p)])

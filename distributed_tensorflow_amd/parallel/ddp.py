@@ -98,6 +98,9 @@ class _IpcGradHook:
         # gather mode (set_gather): the fc1 filter gradient, arena [0, rest_off), is computed globally from gathered
         # operands inside the step; only the rest of the arena is all-reduced
         self.rest_off = 0
+        # (the engine's DTF_EARLY_FC1_ADAM=0 debugging switch applies the whole arena in one optimizer launch, which then
+        # needs the rest of the arena reduced in place as before)
+        self.fused_apply = os.environ.get("DTF_EARLY_FC1_ADAM", "1") != "0"
         if overlap:
             self.side = torch.cuda.Stream(device=whole.device)
             self.ev_fork = torch.cuda.Event()
@@ -120,6 +123,12 @@ class _IpcGradHook:
         if rest_off:
             self.overlap = False
 
+    @property
+    def apply_comm(self):
+        """Non-None in gather mode: the engine's optimizer launch for the arena after W_fc1 must sum the ranks' published
+        gradients itself (``dtf_mnist_apply_part_ipc`` on this comm struct)."""
+        return self.ipc.comm if self.rest_off and self.fused_apply else None
+
     def after_part1(self, stream) -> None:
         if not self.overlap:
             return
@@ -130,9 +139,13 @@ class _IpcGradHook:
 
     def after_part2(self, stream) -> None:
         if self.rest_off:
-            # (one-shot form: its "next call only after another barrier" contract is met by the operand exchange's
-            # barrier after the next step's loss head)
-            self.ipc.all_reduce_oneshot(self.whole[self.rest_off:], stream=stream.cuda_stream)
+            # one-shot form (its "next call only after another barrier" contract is met by the operand exchange's
+            # barrier after the next step's loss head), with the reduction fused into the optimizer launch: only the
+            # copy into the exchange buffer happens here, see apply_comm
+            if self.fused_apply:
+                self.ipc.publish(self.whole[self.rest_off:], stream=stream.cuda_stream)
+            else:
+                self.ipc.all_reduce_oneshot(self.whole[self.rest_off:], stream=stream.cuda_stream)
             return
         if self.zc_off:
             self.ipc.all_reduce_zero_copy(self.whole[self.zc_off:], self.zc_off, self.whole.numel(),

@@ -40,6 +40,7 @@ def _signatures(lib) -> None:
     lib.dtf_ipc_all_gather.argtypes, lib.dtf_ipc_all_gather.restype = [P, P, P, L, I, P], I
     lib.dtf_ipc_broadcast.argtypes, lib.dtf_ipc_broadcast.restype = [P, P, L, I, I, P], I
     lib.dtf_ipc_allreduce_oneshot.argtypes, lib.dtf_ipc_allreduce_oneshot.restype = [P, P, P, L, I, P], I
+    lib.dtf_ipc_publish.argtypes, lib.dtf_ipc_publish.restype = [P, P, L, I, P], I
     lib.dtf_ipc_stage_ptr.argtypes, lib.dtf_ipc_stage_ptr.restype = [P], P
     lib.dtf_ipc_result_ptr.argtypes, lib.dtf_ipc_result_ptr.restype = [P, L], P
     lib._dtf_ipc_sigs = True
@@ -135,6 +136,17 @@ class IpcAllReduce:
         st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
         native.check(self.lib.dtf_ipc_allreduce_oneshot(C.byref(self.comm), src.data_ptr(), dst.data_ptr(), src.numel(),
                                                         blocks, st), "ipc_allreduce_oneshot")
+
+    def publish(self, src: torch.Tensor, stream: Optional[int] = None, blocks: int = 64) -> None:
+        """First half of ``all_reduce_oneshot``: copy ``src`` into this rank's exchange buffer.  The consumer does the flag
+        exchange and the reduction itself (``dtf_ipc_adam_oneshot``: the optimizer launch sums the ranks' buffers in its
+        own gradient loads)."""
+        if self.comm is None:
+            raise RuntimeError("IPC all-reduce is not usable on this rank: %s" % self.failure)
+        assert src.is_cuda and src.dtype == torch.float32 and src.is_contiguous()
+        assert src.numel() % 4 == 0 and src.numel() <= self.n_max
+        st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        native.check(self.lib.dtf_ipc_publish(C.byref(self.comm), src.data_ptr(), src.numel(), blocks, st), "ipc_publish")
 
     # ---- the rest of a small collective backend over the same buffers (SURVEY 7.2 step 6); not on the training hot path
     def _stream(self, stream: Optional[int]) -> int:
