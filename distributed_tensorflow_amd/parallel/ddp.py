@@ -538,7 +538,29 @@ class DataParallelTrainer:
     def prepare(self) -> None:
         """Capture the step graphs ahead of the first step (collective-free; every rank may call it)."""
         if self._native and (not self._multi or (self.sync and self.comm == "ipc")):
+            if self._multi and dist.is_initialized() and not self._stage_host:
+                import time
+                torch.cuda.synchronize(self.engine.device)  # (no capture next to a collective in flight, see below)
+                time.sleep(0.005)
             self.engine.prepare()
+        elif self._native and self._multi and self.sync:
+            self._capture_rccl_graphs()
+
+    def _capture_rccl_graphs(self) -> None:
+        """The RCCL schedule replays three graphs per step with collectives in between.  Capturing them lazily would put
+        a stream capture between two collectives of the first step, while the process group's watchdog thread polls the
+        events of the collective still in flight — seen to end in ``hipErrorCapturedEvent`` inside the watchdog (which
+        aborts the process) once in a few dozen runs.  So: all three captured up front, with the device idle."""
+        e = self.engine
+        if not getattr(e, "use_graph", False):
+            return
+        missing = [k for k in ("part1", "part2", "apply") if k not in e._graphs]
+        if missing:
+            import time
+            torch.cuda.synchronize(e.device)
+            time.sleep(0.005)  # (lets the watchdog retire the collectives that have just completed)
+            for k in missing:
+                e._capture(k)
 
     def train_steps(self, n: int) -> None:
         """``n`` synchronous steps; several per graph launch where the whole step (incl. the gradient all-reduce) is
@@ -567,6 +589,7 @@ class DataParallelTrainer:
                 e.launch("full")
             return
         if self._native:
+            self._capture_rccl_graphs()
             with torch.cuda.stream(e.stream):
                 with trace.range("fwd+head+fc_dW (graph part1)"):
                     e.launch("part1")

@@ -213,6 +213,7 @@ e1 = NativeMnistEngine(ds(), batch_size=100, seed=5, lr=5e-4)
 e2 = NativeMnistEngine(ds(), batch_size=100, seed=5, lr=5e-4)
 t1 = DataParallelTrainer(e1, force_collectives=True, overlap=True, comm="rccl")  # part1 | RCCL bucket A || part2 | RCCL bucket B | Adam
 t2 = DataParallelTrainer(e2)                                          # plain single-graph step
+t1.prepare(); t2.prepare()  # (all graph captures before the first collective is in flight)
 for _ in range(40):
     t1.train_step(); t2.train_step()
 torch.cuda.synchronize()
