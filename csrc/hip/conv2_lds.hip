@@ -281,22 +281,36 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_lds_kernel(const float* __
     if (c < DIMG_BYTES / 16) *reinterpret_cast<uint4*>(dimg + c * 16) = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
+  float gsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int task = tid + 256 * i;
     if (task < 392) {
       float gs[8];
       unpool_task_store(dimg, task, ug0[i], ug1[i], upv[i], uav[i], gs);
-      if (half == 0 && db2) {
+      if (i == half) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(&dbs[(task & 7) * 8 + j], gs[j]);
+        for (int j = 0; j < 8; ++j) gsum[j] = gs[j];
       }
+    }
+  }
+  // Bias gradient: both workgroups of an image un-pool all of it, so each contributes one of the two task rounds.
+  // The 8 lanes of a wave that share a channel chunk (lane & 7) are summed with shuffles first: per-task LDS atomics
+  // put 8 lanes on every address and cost the row-half-0 workgroups 3.5 us (phase timestamps), a quarter of the kernel.
+  if (db2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = gsum[j];
+      v += __shfl_xor(v, 8);
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lane < 8) atomicAdd(&dbs[lane * 8 + j], v);
     }
   }
 #pragma unroll
   for (int j = 0; j < 25; ++j) *reinterpret_cast<u32x4*>(wl + (tid + 256 * j) * 16) = wv[j];
   __syncthreads();
-  if (half == 0 && db2 && tid < 64) atomicAdd(&db2[tid], dbs[tid]);
+  if (db2 && tid < 64) atomicAdd(&db2[tid], dbs[tid]);
 
   const int tile = half * 4 + wave;
   if (tile >= 7) return;
@@ -305,6 +319,13 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_lds_kernel(const float* __
   m = m < 196 ? m : 195;
   const int y = m / 14, xx = m - y * 14;
   const int abase = (y * 18 + xx) * DPIX + h * 16;
+  // the ReLU mask of the layer below, needed by the epilogue only: in flight during the k loop
+  uint16_t mk[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    mk[i] = pool1[((long)b * 196 + (row < 196 ? row : 195)) * 32 + r];
+  }
   // software-pipelined k loop (see conv2_fwd_lds_kernel): fragments of k-step ks + PF are fetched before the MFMA of
   // k-step ks is issued; even and odd k-steps accumulate separately so that consecutive MFMAs are independent
   constexpr int PF = 3, RING = PF + 1, KS = 100;
@@ -336,8 +357,7 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_lds_kernel(const float* __
     const int row = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
     if (row < 196) {
       const long o = ((long)b * 196 + row) * 32 + r;
-      const uint16_t mk = pool1[o];
-      dpool1[o] = ((mk & 0x7fffu) != 0 && (mk & 0x8000u) == 0) ? acc[i] : 0.f;
+      dpool1[o] = ((mk[i] & 0x7fffu) != 0 && (mk[i] & 0x8000u) == 0) ? acc[i] : 0.f;
     }
   }
 }
