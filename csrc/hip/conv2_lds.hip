@@ -377,14 +377,18 @@ __device__ __forceinline__ void conv2_dw_body(char* __restrict__ smem, const int
   // per-lane LDS offsets of the transposing reads, identical for every image (13 k-steps x 2 reads)
   const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = (i16 & 3) * 4;
   const int mcol = 16 * (g & 1) + p4;  // A: cin column / B: cout column (before the n-tile offset)
-  int xoff[26], doff[26];
+  // (byte offsets < 64 K, two per register: with 52 full registers of offsets the launch exceeds 128 VGPRs, and a
+  // 5-wave workgroup above 128 VGPRs gets a CU to itself -- the optimizer workgroups of the fused launch then start
+  // only when a filter-gradient workgroup has finished, 9.7 us into the launch on average)
+  uint32_t xo2[13], do2[13];
 #pragma unroll
   for (int s = 0; s < 26; ++s) {
     const int pos = (s >> 1) * 16 + 8 * (g >> 1) + (s & 1) * 4 + q;
     const bool ok = pos < 196;
     const int y = ok ? pos / 14 : 0, xx = ok ? pos - (pos / 14) * 14 : 0;
-    xoff[s] = ((y + dy) * 18 + xx + dx) * PIX + mcol * 2;
-    doff[s] = (ok ? ((y + 2) * 18 + xx + 2) * DPIX : 0) + mcol * 2;  // padded k -> halo pixel 0 (zeros)
+    const uint32_t xo = ((y + dy) * 18 + xx + dx) * PIX + mcol * 2;
+    const uint32_t dofs = (ok ? ((y + 2) * 18 + xx + 2) * DPIX : 0) + mcol * 2;  // padded k -> halo pixel 0 (zeros)
+    if (s & 1) { xo2[s >> 1] |= xo << 16; do2[s >> 1] |= dofs << 16; } else { xo2[s >> 1] = xo; do2[s >> 1] = dofs; }
   }
   // zero both halo images once: interiors are fully rewritten per image, halos stay zero
   for (int c = tid; c < (IMG_BYTES + DIMG_BYTES) / 16; c += 320) *reinterpret_cast<uint4*>(smem + c * 16) = make_uint4(0, 0, 0, 0);
@@ -437,9 +441,15 @@ __device__ __forceinline__ void conv2_dw_body(char* __restrict__ smem, const int
       return __builtin_bit_cast(bf16x8, v8);
     };
     auto fetch = [&](const int ks, const int slot) {
-      aq[slot] = tr8(ximg + xoff[2 * ks], ximg + xoff[2 * ks + 1]);
-      b0q[slot] = tr8(dimg + doff[2 * ks], dimg + doff[2 * ks + 1]);
-      b1q[slot] = tr8(dimg + doff[2 * ks] + 64, dimg + doff[2 * ks + 1] + 64);
+      // (volatile: unpacked at the point of use; hoisted out of the image loop the 52 offsets would be registers again)
+      uint32_t x0, x1, d0, d1;
+      asm volatile("v_and_b32 %0, 0xffff, %1" : "=v"(x0) : "v"(xo2[ks]));
+      asm volatile("v_lshrrev_b32 %0, 16, %1" : "=v"(x1) : "v"(xo2[ks]));
+      asm volatile("v_and_b32 %0, 0xffff, %1" : "=v"(d0) : "v"(do2[ks]));
+      asm volatile("v_lshrrev_b32 %0, 16, %1" : "=v"(d1) : "v"(do2[ks]));
+      aq[slot] = tr8(ximg + x0, ximg + x1);
+      b0q[slot] = tr8(dimg + d0, dimg + d1);
+      b1q[slot] = tr8(dimg + d0 + 64, dimg + d1 + 64);
     };
 #pragma unroll
     for (int ks = 0; ks < PF; ++ks) fetch(ks, ks % RING);
@@ -485,7 +495,7 @@ struct ConvDwDuo {
 };
 constexpr int DUO_LDS = (IMG_BYTES + DIMG_BYTES) > CONV1_DW_LDS_FLOATS * 4 ? (IMG_BYTES + DIMG_BYTES) : CONV1_DW_LDS_FLOATS * 4;
 
-__global__ __launch_bounds__(320) void conv_dw_duo_kernel(const ConvDwDuo a) {
+__global__ __launch_bounds__(320, 4) void conv_dw_duo_kernel(const ConvDwDuo a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int id = blockIdx.x;
   if (id < a.n2)
