@@ -96,7 +96,8 @@ using TrioBdB = LoadRowK<float, 64, 256, 64, false>;
 // the plain path grew enough to lose a resident workgroup per CU, +9 us on the step)
 template <bool GATHER>
 __global__ __launch_bounds__(256, 2) void fc_bwd_trio_kernel(const GemmTrio g) {
-  __shared__ __attribute__((aligned(16))) uint16_t smem[(128 + 64) * (128 + 8)];  // the larger instantiation (BK = 128)
+  __shared__ __attribute__((aligned(16))) uint16_t smem[DTF_TN_LDS / 2];  // the largest role (>= (128 + 64) * (128 + 8))
+  static_assert(DTF_TN_LDS / 2 >= (128 + 64) * (128 + 8), "LDS of the generic roles");
   const int id = blockIdx.x;
   if (id < g.nblk_q) {
     const int mt = id % g.q_mt, r = id / g.q_mt;
@@ -107,10 +108,13 @@ __global__ __launch_bounds__(256, 2) void fc_bwd_trio_kernel(const GemmTrio g) {
     const int which = j >= g.pair.nblk0;
     const int k = which ? j - g.pair.nblk0 : j;
     const int mt = which ? g.pair.mt1 : g.pair.mt0;
-    if (GATHER && which == 0)
-      dtf_gemm_body_ranks<128, 64, 128, 4, 1, TrioDwA, TrioDwB, EpStoreF32>(g.pair.p[0], g.gA, g.gB, g.granks, (k % mt) * 128,
-                                                                            (k / mt) * 64, smem, smem + 128 * (128 + 8));
-    else
+    if (which == 0) {
+      // fc1 filter gradient: tiles staged as they are, transposing LDS reads (dtf_tn_body_tr)
+      const void* a1[1] = {g.pair.p[0].A};
+      const void* b1[1] = {g.pair.p[0].B};
+      dtf_tn_body_tr<EpStoreF32>(g.pair.p[0], GATHER ? g.gA : a1, GATHER ? g.gB : b1, GATHER ? g.granks : 1, (k % mt) * 128,
+                                 (k / mt) * 64, reinterpret_cast<char*>(smem));
+    } else
       dtf_gemm_body<128, 64, 128, 4, 1, TrioDwA, TrioDwB, EpStoreF32>(g.pair.p[which], (k % mt) * 128, (k / mt) * 64, 0, smem,
                                                                       smem + 128 * (128 + 8));
   }
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void fc_bwd_trio_kernel(const GemmTrio g) {
 DTF_API int dtf_fc_bwd_trio(const void* X0, const void* dY0, float* dW0, int M0, int N0, const void* X1, const void* dY1,
                             float* dW1, int M1, int N1, int K, const void* dYq, const float* Wq, float* dXq, int Mq, int Nq,
                             int Kq, int splits, const void* const* gA, const void* const* gB, int granks, hipStream_t st) {
-  if (M0 <= 0 || N0 <= 0 || M1 <= 0 || N1 <= 0 || K <= 0 || K > 128 || M0 % 2 || N0 % 2 || M1 % 2 || N1 % 2) return ERR_SHAPE;
+  if (M0 <= 0 || N0 <= 0 || M1 <= 0 || N1 <= 0 || K <= 0 || K > 128 || M0 % 8 || N0 % 8 || M1 % 2 || N1 % 2) return ERR_SHAPE;
   if (Mq <= 0 || Nq <= 0 || Kq <= 0 || Kq % 8 || splits < 2) return ERR_SHAPE;
   if (granks < 0 || granks > 8 || (granks > 0 && (!gA || !gB))) return ERR_SHAPE;
   GemmTrio g;

@@ -655,6 +655,95 @@ __device__ __forceinline__ void dtf_gemm_body_ranks(const GemmParams& p, const v
   EP::template run<TM, TN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, 0);
 }
 
+// Weight-gradient GEMM with the batch as K (K <= 128, one slab):  C[m][n] = sum over `nranks` operand pairs of A_r^T B_r,
+// A_r bf16 [K][lda] and B_r bf16 [K][ldb] row-major (features contiguous).  The tiles go into LDS AS THEY ARE -- a few
+// coalesced 16-byte loads per lane -- and the MFMA fragments are read with the transposing LDS load
+// (ds_read_b64_tr_b16), instead of transposing in registers on the way in: that loader needs 48 four-byte loads per
+// lane and spent 5.4 of the fc1 filter-gradient workgroup's 10.8 us issuing and waiting for them (phase timestamps).
+// 128 x 64 tile, 4 waves (32 rows each); LDS row pitches 320 / 192 bytes keep the 4-row read groups on distinct banks.
+// Requires M, N, lda, ldb multiples of 8 and 16-byte aligned operands.  smem: 128 * (320 + 192) bytes.
+constexpr int DTF_TN_PA = 320, DTF_TN_PB = 192, DTF_TN_LDS = 128 * (DTF_TN_PA + DTF_TN_PB);
+template <class EP>
+__device__ __forceinline__ void dtf_tn_body_tr(const GemmParams& p, const void* const* __restrict__ Ar,
+                                               const void* const* __restrict__ Br, const int nranks, const int m0,
+                                               const int n0, char* __restrict__ smem) {
+  typedef short s16x4_t __attribute__((ext_vector_type(4)));
+  typedef short s16x8_t __attribute__((ext_vector_type(8)));
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  char* As = smem;
+  char* Bs = smem + 128 * DTF_TN_PA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = p.K, kpad = (K + 15) & ~15, nks = kpad >> 4;
+  u32x4_t av[8], bv[4];
+  const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+  auto load = [&](const void* A, const void* B) {
+    const uint16_t* a16 = reinterpret_cast<const uint16_t*>(A);
+    const uint16_t* b16 = reinterpret_cast<const uint16_t*>(B);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = tid + 256 * i, row = c >> 4, cc = c & 15;
+      const bool ok = row < K && m0 + cc * 8 < p.M;
+      av[i] = *reinterpret_cast<const u32x4_t*>(a16 + (ok ? (long)row * p.lda + m0 + cc * 8 : 0L));
+      av[i] = ok ? av[i] : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i, row = c >> 3, cc = c & 7;
+      const bool ok = row < K && n0 + cc * 8 < p.N;
+      bv[i] = *reinterpret_cast<const u32x4_t*>(b16 + (ok ? (long)row * p.ldb + n0 + cc * 8 : 0L));
+      bv[i] = ok ? bv[i] : zero4;
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = tid + 256 * i, row = c >> 4, cc = c & 15;
+      if (row < kpad) *reinterpret_cast<u32x4_t*>(As + row * DTF_TN_PA + cc * 16) = av[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i, row = c >> 3, cc = c & 7;
+      if (row < kpad) *reinterpret_cast<u32x4_t*>(Bs + row * DTF_TN_PB + cc * 16) = bv[i];
+    }
+  };
+  auto tr8 = [&](const char* lo_p, const int pitch) {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lo_p));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lo_p + 4 * pitch));
+    const s16x8_t v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v8);
+  };
+  // lane mapping of the transposing read (as in conv2_dw_body): 16 lanes cover 4 k-rows x 16 columns
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = (i16 & 3) * 4;
+  const int mcol = 16 * (g & 1) + p4, krow = 8 * (g >> 1) + q;
+  const char* abase = As + krow * DTF_TN_PA + (wave * 32 + mcol) * 2;
+  const char* bbase = Bs + krow * DTF_TN_PB + mcol * 2;
+  f32x16 acc[1][2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[0][b][i] = 0.f;
+  load(Ar[0], Br[0]);
+  for (int rk = 0; rk < nranks; ++rk) {
+    __syncthreads();
+    store();
+    __syncthreads();
+    if (rk + 1 < nranks) load(Ar[rk + 1], Br[rk + 1]);
+    bf16x8 a_c = tr8(abase, DTF_TN_PA), b0_c = tr8(bbase, DTF_TN_PB), b1_c = tr8(bbase + 64, DTF_TN_PB);
+    for (int ks = 0; ks < nks; ++ks) {
+      bf16x8 a_n = a_c, b0_n = b0_c, b1_n = b1_c;
+      if (ks + 1 < nks) {
+        a_n = tr8(abase + (ks + 1) * 16 * DTF_TN_PA, DTF_TN_PA);
+        b0_n = tr8(bbase + (ks + 1) * 16 * DTF_TN_PB, DTF_TN_PB);
+        b1_n = tr8(bbase + (ks + 1) * 16 * DTF_TN_PB + 64, DTF_TN_PB);
+      }
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_c, b0_c, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_c, b1_c, acc[0][1], 0, 0, 0);
+      a_c = a_n; b0_c = b0_n; b1_c = b1_n;
+    }
+  }
+  EP::template run<1, 2>(p, acc, m0 + wave * 32, n0, lane, 0);
+}
+
 template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP>
 __global__ __launch_bounds__(64 * WM * WN) void dtf_gemm_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) uint16_t smem[(BM + BN) * DTF_LDS_STRIDE];
