@@ -333,12 +333,14 @@ class NativeMnistEngine(_EngineBase):
         """One full step (single-GPU: fwd+bwd+Adam as one hipGraph replay)."""
         self.launch("full")
 
-    def train_steps(self, n: int, chunk: int = 8) -> None:
+    def train_steps(self, n: int, chunk: int = 16) -> None:
         """``n`` full steps.  Everything a step needs (batch offset, dropout counter, Adam step, metric slot) lives in
         device memory, so ``chunk`` consecutive steps replay as ONE hipGraph launch: the ~6 us the command processor
-        needs between two graph launches is paid once per chunk (measured on the 0.13 ms step).  A chunk never spans an
+        needs between two graph launches is paid once per chunk (8 -> 16 steps per launch: 91.2 -> 90.7 us per step).  A chunk never spans an
         epoch boundary, where the permutation is regenerated between steps."""
         chunk = int(os.environ.get("DTF_STEPS_PER_GRAPH", chunk))
+        if self.dataset is not None:
+            chunk = min(chunk, self.spe)  # (a data set with fewer steps per epoch than a chunk still gets one graph per epoch)
         key = "full*%d" % chunk
         while n > 0:
             room = self.spe - (self._steps_done % self.spe) if self.dataset is not None else n
@@ -353,10 +355,12 @@ class NativeMnistEngine(_EngineBase):
                 self.train_step()
                 n -= 1
 
-    def prepare(self, chunk: int = 8) -> None:
+    def prepare(self, chunk: int = 16) -> None:
         """Capture the step graphs now (capturing records, it does not execute) so that no later step pays for it."""
         if self.use_graph:
             chunk = int(os.environ.get("DTF_STEPS_PER_GRAPH", chunk))
+            if self.dataset is not None:
+                chunk = min(chunk, self.spe)
             for key in ("full",) + (("full*%d" % chunk,) if chunk > 1 else ()):
                 if key not in self._graphs:
                     self._capture(key)

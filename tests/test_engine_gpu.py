@@ -104,14 +104,14 @@ def test_fused_step_matches_unfused_sequence(B):
 
 
 def test_multi_step_graph_matches_single_steps():
-    """train_steps() replays 8 steps per graph launch; it must walk through the same batches, dropout masks and Adam
+    """train_steps() replays several steps (here 8) per graph launch; it must walk through the same batches, dropout masks and Adam
     steps as 8 single launches, also across an epoch boundary (reshuffle between chunks)."""
     from distributed_tensorflow_amd.engine.mnist_engine import NativeMnistEngine
     dd1, dd2 = _dataset(n=1500, seed=2), _dataset(n=1500, seed=2)  # 15 steps per epoch
     e1 = NativeMnistEngine(dd1, batch_size=100, seed=11, eval_chunk=500, lr=1e-4)
     e2 = NativeMnistEngine(dd2, batch_size=100, seed=11, eval_chunk=500, lr=1e-4)
-    e1.prepare()
-    e1.train_steps(37)
+    e1.prepare(chunk=8)
+    e1.train_steps(37, chunk=8)
     for _ in range(37):
         e2.train_step()
     e1.stream.synchronize(); e2.stream.synchronize()
