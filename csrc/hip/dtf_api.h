@@ -58,3 +58,23 @@ DTF_API int dtf_conv2_bwd_lds(const float* dpool2, const void* pool2, const void
                               float* dpool1, float* dW, float* db2, int B, int ipw, hipStream_t st);
 DTF_API int dtf_tensor_stats(const float* x, long n, const double* pos_limits, int npos, double* sums, unsigned* counts,
                              hipStream_t st);
+
+// ---- exact-fp32 (reference precision) path: f32_fc.hip, f32_conv2.hip, mnist_kernels.hip
+DTF_API int dtf_fc_fwd_f32(const float* X, const float* W, float* out, int M, int N, int K, int splits, const float* bias,
+                           int relu, hipStream_t st);
+DTF_API int dtf_fc_bwd_data_f32(const float* dY, const float* W, float* dX, int M, int N, int K, int splits, hipStream_t st);
+DTF_API int dtf_fc_dw_f32(const float* X, int ldx, const float* dY, int ldy, float* dW, int M, int N, int K, int splits,
+                          hipStream_t st);
+DTF_API int dtf_fc_bwd_trio_f32(const float* X0, const float* dY0, float* dW0, int M0, int N0, const float* X1,
+                                const float* dY1, int ldy1, float* dW1, int M1, int N1, int K, const float* dYq,
+                                const float* Wq, float* dXq, int Mq, int Nq, int Kq, int splits, hipStream_t st);
+DTF_API int dtf_conv2_f32_init();
+DTF_API int dtf_conv1_fwd_f32(const float* images, const int* perm, const int* step_ptr, int spe, int B, const float* Wt,
+                              const float* bias, float* out, void* amax, hipStream_t st);
+DTF_API int dtf_conv2_fwd_f32(const float* x, const float* W, const float* bias, float* out, void* amax, int B, hipStream_t st);
+DTF_API int dtf_conv2_bwd_data_f32(const float* dpool2, const float* pool2, const void* amax2, const float* W,
+                                   const float* pool1, float* dpool1, float* db2, int B, hipStream_t st);
+DTF_API int dtf_conv_dw_duo_f32(const float* dpool2, const float* pool2, const void* amax2, const float* pool1, float* dW2,
+                                int B, const float* images, const int* perm, const int* step_ptr, int spe,
+                                const float* dpool1, const void* amax1, float* dW1, float* db1, const struct OptimParams* adam,
+                                hipStream_t st);

@@ -31,6 +31,7 @@ struct HeadParams {
   int* pred;              // optional int32 [B]
   float* zero_buf;        // optional: buffer zeroed as a side job (float4 granularity)
   long zero_n4;
+  int f32;                // h_drop / dh are fp32 [B][1024] and dz fp32 [B][16] (zero-padded rows) instead of bf16
 };
 
 struct OptimParams {

@@ -44,6 +44,9 @@ struct MnistEngine {
   void *wc2f, *wc2b;   // packed bf16 copies of conv2's filter (conv2_pack.h), rewritten by the first kernel of every forward
   void* gather_local;  // [gather_n][gather_bytes]: local copies of the peers' operands (what gather_A/B point at for peers)
   long gather_bytes;   // bytes of (pool2, dh) per rank
+  // reference precision (demo1/train.py computes in float32): pool1 / pool2 / h_drop / dh are fp32, dz is fp32 [B][16], and
+  // every GEMM-shaped op runs on the exact-fp32 MFMA (f32_gemm.h, f32_conv2.hip); 0 = bf16 operands, fp32 accumulate
+  int f32;
 };
 
 #define DTF_TRY(x)            \
@@ -54,6 +57,13 @@ struct MnistEngine {
 
 static int forward_to_slabs(const MnistEngine* e, const float* images, const int* perm, const int* step, int n,
                             int splits, bool need_argmax, hipStream_t st) {
+  if (e->f32) {
+    DTF_TRY(dtf_conv1_fwd_f32(images, perm, step, e->spe, n, e->P + e->off_Wc1, e->P + e->off_bc1, (float*)e->pool1,
+                              need_argmax ? e->amax1 : nullptr, st));
+    DTF_TRY(dtf_conv2_fwd_f32((const float*)e->pool1, e->P + e->off_Wc2, e->P + e->off_bc2, (float*)e->pool2,
+                              need_argmax ? e->amax2 : nullptr, n, st));
+    return dtf_fc_fwd_f32((const float*)e->pool2, e->P + e->off_Wfc1, e->slabs, n, 1024, 3136, splits, nullptr, 0, st);
+  }
   if (!e->wc2f || !e->wc2b) return -22;
   DTF_TRY(dtf_conv1_fwd_pack(images, perm, step, e->spe, n, e->P + e->off_Wc1, e->P + e->off_bc1, e->pool1,
                              need_argmax ? e->amax1 : nullptr, e->P + e->off_Wc2, e->wc2f, e->wc2b, st));
@@ -62,7 +72,7 @@ static int forward_to_slabs(const MnistEngine* e, const float* images, const int
   return 0;
 }
 
-static int effective_splits(int K, int splits, int BK = 64) {  // mirrors base_params() in gemm_api.hip
+static int effective_splits(int K, int splits, int BK = 64) {  // mirrors base_params() in gemm_api.hip / f32_fc.hip
   const int ksteps = (K + BK - 1) / BK;
   const int kchunk = ((ksteps + splits - 1) / splits) * BK;
   return (K + kchunk - 1) / kchunk;
@@ -73,7 +83,10 @@ static int effective_splits(int K, int splits, int BK = 64) {  // mirrors base_p
 // measured and rejected: every cross-queue edge costs 5-10 us on this ~120 us step, as much as the overlap saves.
 // Instead independent kernels are fused HORIZONTALLY into one launch on the single stream:
 //   head -> [fc1 dW | fc2 dW | fc1 bwd-data] -> conv2 bwd-data -> [conv2 dW | conv1 dW] -> Adam
-static bool trio_ok(const MnistEngine* e) { return e->B <= 128 && effective_splits(1024, e->bwd_splits) > 1; }
+static bool trio_ok(const MnistEngine* e) {
+  if (e->f32) return effective_splits(1024, e->bwd_splits, 32) > 1;  // (the fp32 filter-gradient GEMMs walk K = batch in slabs)
+  return e->B <= 128 && effective_splits(1024, e->bwd_splits) > 1;
+}
 
 DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st) {
   const int B = e_in->B;
@@ -83,6 +96,7 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
   MnistEngine loc = *e_in;
   const MnistEngine* e = &loc;
   if (loc.gather_n > 0) {
+    if (loc.f32) return -22;  // (the operand-gather schedule exchanges bf16 operands)
     if (!trio_ok(e_in) || loc.gather_rank < 0 || loc.gather_rank >= loc.gather_n || loc.gather_n > 8) return -22;
     loc.pool2 = const_cast<void*>(loc.gather_A[loc.gather_rank]);
     loc.dh = const_cast<void*>(loc.gather_B[loc.gather_rank]);
@@ -100,7 +114,8 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
     DTF_TRY(forward_to_slabs(e, e->images, e->perm, e->step, B, e->fc1_splits, true, st));
     HeadParams hp{};
     hp.slabs = e->slabs;
-    hp.nslab = effective_splits(3136, e->fc1_splits);
+    hp.nslab = effective_splits(3136, e->fc1_splits, e->f32 ? 32 : 64);
+    hp.f32 = e->f32;
     hp.slab_stride = (long)B * 1024;
     hp.b_fc1 = e->P + e->off_bfc1;
     hp.W_fc2 = e->P + e->off_Wfc2;
@@ -123,7 +138,7 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
     hp.metrics = e->metrics_ring;
     hp.metrics_ring = e->ring;
     // the split-K fc1 bwd-data accumulates into dpool2 with atomics: the head zeroes it (saves a memset node)
-    if (effective_splits(1024, e->bwd_splits) > 1) { hp.zero_buf = e->dpool2; hp.zero_n4 = (long)B * 3136 / 4; }
+    if (effective_splits(1024, e->bwd_splits, e->f32 ? 32 : 64) > 1) { hp.zero_buf = e->dpool2; hp.zero_n4 = (long)B * 3136 / 4; }
     DTF_TRY(dtf_head(&hp, e->head_blocks, st));
     // fc1 dW[3136][1024] = pool2^T * dh  (stored: 12.8 MB, the one gradient that is never re-zeroed) and
     // fc2 dW[1024][10] = h_drop^T * dz, as one grouped launch when the batch fits a single K slab
@@ -134,7 +149,17 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
       if (e->gather_bytes != (long)B * (3136 + 1024) * 2 || !e->gather_local) return -22;
       DTF_TRY(dtf_ipc_sync_gather(e->gather_comm, e->gather_local, e->gather_bytes, 16, st));
     }
-    if (trio_ok(e)) {
+    if (e->f32) {
+      const float* x2 = (const float*)e->pool2; const float* dh = (const float*)e->dh;
+      if (trio_ok(e)) {
+        DTF_TRY(dtf_fc_bwd_trio_f32(x2, dh, dW_fc1, 3136, 1024, (const float*)e->h_drop, (const float*)e->dz, 16,
+                                    e->G + e->off_Wfc2, 1024, 10, B, dh, e->P + e->off_Wfc1, e->dpool2, B, 3136, 1024,
+                                    e->bwd_splits, st));
+      } else {
+        DTF_TRY(dtf_fc_dw_f32((const float*)e->h_drop, 1024, (const float*)e->dz, 16, e->G + e->off_Wfc2, 1024, 10, B, 1, st));
+        DTF_TRY(dtf_fc_dw_f32(x2, 3136, dh, 1024, dW_fc1, 3136, 1024, B, 1, st));
+      }
+    } else if (trio_ok(e)) {
       // fc1 dW[3136][1024] = pool2^T * dh (stored: 12.8 MB, the one gradient that is never re-zeroed), fc2 dW[1024][10] =
       // h_drop^T * dz and the split-K fc1 data gradient dpool2 += dh * W_fc1^T as one launch
       DTF_TRY(dtf_fc_bwd_trio(e->pool2, e->dh, dW_fc1, 3136, 1024, e->h_drop, e->dz, e->G + e->off_Wfc2, 1024, 10,
@@ -149,12 +174,18 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
     }
   }
   if (parts & 2) {
-    if (!trio_ok(e))  // (otherwise part 1 already produced dpool2)
-      DTF_TRY(dtf_fc_bwd_data(e->dh, e->P + e->off_Wfc1, e->dpool2, B, 3136, 1024, e->bwd_splits, st));
+    if (!trio_ok(e)) {  // (otherwise part 1 already produced dpool2)
+      if (e->f32) DTF_TRY(dtf_fc_bwd_data_f32((const float*)e->dh, e->P + e->off_Wfc1, e->dpool2, B, 3136, 1024, e->bwd_splits, st));
+      else DTF_TRY(dtf_fc_bwd_data(e->dh, e->P + e->off_Wfc1, e->dpool2, B, 3136, 1024, e->bwd_splits, st));
+    }
     // un-pool + conv2 bwd-data (+db2) as one LDS-resident kernel, then both conv filter gradients as one launch
     const int ipw = e->dw2_splits > 0 && e->dw2_splits <= 16 ? e->dw2_splits : 4;
-    DTF_TRY(dtf_conv2_bwd_data_lds_packed(e->dpool2, e->pool2, e->amax2, e->wc2b, e->pool1, e->dpool1, e->G + e->off_bc2, B,
-                                          st));
+    if (e->f32)
+      DTF_TRY(dtf_conv2_bwd_data_f32(e->dpool2, (const float*)e->pool2, e->amax2, e->P + e->off_Wc2, (const float*)e->pool1,
+                                     e->dpool1, e->G + e->off_bc2, B, st));
+    else
+      DTF_TRY(dtf_conv2_bwd_data_lds_packed(e->dpool2, e->pool2, e->amax2, e->wc2b, e->pool1, e->dpool1, e->G + e->off_bc2, B,
+                                            st));
     OptimParams fc1{};
     if (early_adam) {
       fc1.P = e->P; fc1.G = e->G; fc1.M = e->M; fc1.V = e->V;
@@ -164,9 +195,14 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
       fc1.grad_scale = 1.0f / (float)(e->world > 0 ? e->world : 1);
       fc1.step = e->step;
     }
-    DTF_TRY(dtf_conv_dw_duo(e->dpool2, e->pool2, e->amax2, e->pool1, e->G + e->off_Wc2, B, ipw, e->images, e->perm, e->step,
-                            e->spe, e->dpool1, e->amax1, e->G + e->off_Wc1, e->G + e->off_bc1, early_adam ? &fc1 : nullptr,
-                            st));
+    if (e->f32)
+      DTF_TRY(dtf_conv_dw_duo_f32(e->dpool2, (const float*)e->pool2, e->amax2, (const float*)e->pool1, e->G + e->off_Wc2, B,
+                                  e->images, e->perm, e->step, e->spe, e->dpool1, e->amax1, e->G + e->off_Wc1,
+                                  e->G + e->off_bc1, early_adam ? &fc1 : nullptr, st));
+    else
+      DTF_TRY(dtf_conv_dw_duo(e->dpool2, e->pool2, e->amax2, e->pool1, e->G + e->off_Wc2, B, ipw, e->images, e->perm, e->step,
+                              e->spe, e->dpool1, e->amax1, e->G + e->off_Wc1, e->G + e->off_bc1, early_adam ? &fc1 : nullptr,
+                              st));
   }
   return 0;
 }
@@ -230,6 +266,7 @@ DTF_API int dtf_mnist_eval(const MnistEngine* e, const float* images, const int*
     hp.grad_scale = 0.f;
     hp.double_softmax = e->double_softmax;
     hp.training = 0;
+    hp.f32 = e->f32;
     hp.metrics = metrics;
     hp.metrics_ring = 0;
     hp.probs = probs ? probs + (long)off * 10 : nullptr;

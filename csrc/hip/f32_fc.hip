@@ -1,0 +1,122 @@
+// C ABI launchers of the exact-fp32 dense GEMMs (f32_gemm.h): the fc layers of the MNIST CNN at the reference's precision
+// (demo1/train.py:94-120: tf.matmul on float32).  Same roles and the same horizontal fusion as the bf16 launchers in
+// gemm_api.hip; operands and results are fp32 everywhere.
+#include "f32_gemm.h"
+
+namespace {
+constexpr int ERR_SHAPE = -22;
+
+inline GemmParams base_params32(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc,
+                                int splits, int BK) {
+  GemmParams p{};
+  p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  const int ksteps = dtf_cdiv(K, BK);
+  p.kchunk = dtf_cdiv(ksteps, splits) * BK;
+  p.slab_stride = (long)M * ldc;
+  return p;
+}
+inline int eff_splits32(const GemmParams& p) { return dtf_cdiv(p.K, p.kchunk); }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// 112 x 64 tile: the batch of 100 pads to 7 MFMA rows of 16; each of the 4 waves owns 16 output columns x 7 row tiles
+using FwdA = F32RowK<112, 256, 32, true>;
+using FwdB = F32ColK<64, 256, 32, false>;
+using BdA = F32RowK<112, 256, 32, true>;
+using BdB = F32RowK<64, 256, 32, false>;
+// filter gradients: K = batch, both operands row-contiguous; 128 x 64 tile, 4 waves of 32 x 64
+using DwA = F32ColK<128, 256, 20, true>;
+using DwB = F32ColK<64, 256, 20, false>;
+using DwBn = F32ColK<16, 256, 20, false>;  // N <= 16 (fc2: 10 classes, rows of the gradient padded to 16 floats)
+}  // namespace
+
+// out[z][M][N] (fp32 slabs) = X[M][K] (fp32 row-major) * W[K][N] (fp32, TF [in,out] layout)
+// splits == 1: bias/relu (optional) are applied; splits > 1: raw partial sums per slab.
+DTF_API int dtf_fc_fwd_f32(const float* X, const float* W, float* out, int M, int N, int K, int splits, const float* bias,
+                           int relu, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 4 || N % 4 || splits < 1 || !aligned16(X) || !aligned16(W)) return ERR_SHAPE;
+  GemmParams p = base_params32(X, W, out, M, N, K, K, N, N, splits, 32);
+  const int s = eff_splits32(p);
+  p.bias = (s == 1) ? bias : nullptr;
+  p.relu = (s == 1) ? relu : 0;
+  return dtf_launch_gemm32<112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store>(p, s, st);
+}
+
+// dX[M][N] (fp32) (+)= dY[M][K] * W[N][K]^T, W fp32 [N][K].  splits > 1 accumulates with atomics into a pre-zeroed dX.
+DTF_API int dtf_fc_bwd_data_f32(const float* dY, const float* W, float* dX, int M, int N, int K, int splits, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 4 || splits < 1 || !aligned16(dY) || !aligned16(W)) return ERR_SHAPE;
+  GemmParams p = base_params32(dY, W, dX, M, N, K, K, K, N, splits, 32);
+  const int s = eff_splits32(p);
+  if (s == 1) return dtf_launch_gemm32<112, 64, 32, 1, 4, BdA, BdB, Ep32Store>(p, 1, st);
+  return dtf_launch_gemm32<112, 64, 32, 1, 4, BdA, BdB, Ep32Atomic>(p, s, st);
+}
+
+// dW[M][N] (fp32) = X[K][M]^T * dY[K][N], X and dY fp32 row-major [batch][features] with row pitches ldx / ldy (multiples of
+// 4 floats; a pitch wider than the feature count must be readable up to the next multiple of 4).
+// splits > 1 accumulates atomically into a pre-zeroed dW.
+DTF_API int dtf_fc_dw_f32(const float* X, int ldx, const float* dY, int ldy, float* dW, int M, int N, int K, int splits,
+                          hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0 || ldx % 4 || ldy % 4 || ldx < M || ldy < N || splits < 1 || !aligned16(X) || !aligned16(dY))
+    return ERR_SHAPE;
+  GemmParams p = base_params32(X, dY, dW, M, N, K, ldx, ldy, N, splits, 20);
+  const int s = eff_splits32(p);
+  if (N <= 16) {
+    if (s == 1) return dtf_launch_gemm32<128, 16, 20, 4, 1, DwA, DwBn, Ep32Store>(p, 1, st);
+    return dtf_launch_gemm32<128, 16, 20, 4, 1, DwA, DwBn, Ep32Atomic>(p, s, st);
+  }
+  if (s == 1) return dtf_launch_gemm32<128, 64, 20, 4, 1, DwA, DwB, Ep32Store>(p, 1, st);
+  return dtf_launch_gemm32<128, 64, 20, 4, 1, DwA, DwB, Ep32Atomic>(p, s, st);
+}
+
+// The three GEMMs that follow the loss head in ONE launch (as dtf_fc_bwd_trio): the split-K fc1 data gradient and the
+// fc1 / fc2 filter gradients.
+namespace {
+struct GemmTrio32 {
+  GemmParams q, d0, d1;
+  int nblk_q, q_mt, q_nt;  // data-gradient blocks come first: m-tile fastest, then n-tile, then K split
+  int nblk0, mt0, mt1;     // then problem 0 (fc1 dW), then problem 1 (fc2 dW)
+};
+constexpr int TRIO32_LDS = (BdA::LDS + BdB::LDS) > (DwA::LDS + DwB::LDS) ? (BdA::LDS + BdB::LDS) : (DwA::LDS + DwB::LDS);
+
+__global__ __launch_bounds__(256) void fc_bwd_trio_f32_kernel(const GemmTrio32 g) {
+  __shared__ __attribute__((aligned(16))) float smem[TRIO32_LDS];
+  const int id = blockIdx.x;
+  if (id < g.nblk_q) {
+    const int mt = id % g.q_mt, r = id / g.q_mt;
+    dtf_gemm32_body<112, 64, 32, 1, 4, BdA, BdB, Ep32Atomic>(g.q, mt * 112, (r % g.q_nt) * 64, r / g.q_nt, smem, smem + BdA::LDS);
+  } else if (id < g.nblk_q + g.nblk0) {
+    const int k = id - g.nblk_q;
+    dtf_gemm32_body<128, 64, 20, 4, 1, DwA, DwB, Ep32Store>(g.d0, (k % g.mt0) * 128, (k / g.mt0) * 64, 0, smem, smem + DwA::LDS);
+  } else {
+    const int k = id - g.nblk_q - g.nblk0;
+    dtf_gemm32_body<128, 16, 20, 4, 1, DwA, DwBn, Ep32Store>(g.d1, (k % g.mt1) * 128, (k / g.mt1) * 16, 0, smem, smem + DwA::LDS);
+  }
+}
+}  // namespace
+
+// dW0[M0][N0] = X0^T dY0 (pitches M0 / N0), dW1[M1][N1] = X1^T dY1 (N1 <= 16, dY1 pitch ldy1) and
+// dX[Mq][Nq] += dYq[Mq][Kq] * Wq[Nq][Kq]^T (split over K, dX pre-zeroed) in one launch.  K = batch.
+DTF_API int dtf_fc_bwd_trio_f32(const float* X0, const float* dY0, float* dW0, int M0, int N0, const float* X1,
+                                const float* dY1, int ldy1, float* dW1, int M1, int N1, int K, const float* dYq,
+                                const float* Wq, float* dXq, int Mq, int Nq, int Kq, int splits, hipStream_t st) {
+  if (M0 <= 0 || N0 <= 0 || M1 <= 0 || N1 <= 0 || K <= 0 || M0 % 4 || N0 % 4 || M1 % 4 || N1 > 16 || ldy1 % 4 || ldy1 < N1)
+    return ERR_SHAPE;
+  if (Mq <= 0 || Nq <= 0 || Kq <= 0 || Kq % 4 || splits < 2) return ERR_SHAPE;
+  if (!aligned16(X0) || !aligned16(dY0) || !aligned16(X1) || !aligned16(dY1) || !aligned16(dYq) || !aligned16(Wq)) return ERR_SHAPE;
+  GemmTrio32 g;
+  g.d0 = base_params32(X0, dY0, dW0, M0, N0, K, M0, N0, N0, 1, 20);
+  g.d1 = base_params32(X1, dY1, dW1, M1, N1, K, M1, ldy1, N1, 1, 20);
+  g.mt0 = dtf_cdiv(M0, 128);
+  g.mt1 = dtf_cdiv(M1, 128);
+  g.nblk0 = g.mt0 * dtf_cdiv(N0, 64);
+  const int nblk1 = g.mt1 * dtf_cdiv(N1, 16);
+  g.q = base_params32(dYq, Wq, dXq, Mq, Nq, Kq, Kq, Kq, Nq, splits, 32);
+  const int s = eff_splits32(g.q);
+  if (s < 2) return ERR_SHAPE;  // the atomic epilogue is the only one instantiated here
+  g.q_mt = dtf_cdiv(Mq, 112);
+  g.q_nt = dtf_cdiv(Nq, 64);
+  g.nblk_q = g.q_mt * g.q_nt * s;
+  hipLaunchKernelGGL(fc_bwd_trio_f32_kernel, dim3(g.nblk_q + g.nblk0 + nblk1), dim3(256), 0, st, g);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}

@@ -21,10 +21,12 @@ constexpr int NC = 10;
 // ------------------------------------------------------------------ conv1 forward
 // one workgroup per (image, group of 8 output channels) (wave-uniform -> weights come through scalar loads).
 // x: fp32 [N,784]; Wt: fp32 [25][32] (HWIO, I=1); out: bf16 [B,14,14,32]; amax: uint8 [B,14,14,32].
+// F32OUT: the pooled activations are stored as fp32 [B,14,14,32] (reference precision path) instead of bf16.
+template <bool F32OUT>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ images, const int* __restrict__ perm,
                                                         const int* __restrict__ step_ptr, int spe, int B,
                                                         const float* __restrict__ Wt, const float* __restrict__ bias,
-                                                        uint16_t* __restrict__ out, uint8_t* __restrict__ amax,
+                                                        void* __restrict__ out_v, uint8_t* __restrict__ amax,
                                                         const float* __restrict__ Wc2, char* __restrict__ Wc2f,
                                                         char* __restrict__ Wc2b) {
   __shared__ __attribute__((aligned(16))) float img[32 * 32];  // rows/cols -2..29 (SAME padding halo)
@@ -87,6 +89,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
       }
     }
   uint32_t ov[4];
+  float of[8];
   uint32_t av[2] = {0, 0};
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -96,12 +99,20 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     for (int s = 1; s < 4; ++s)
       if (acc[s][j] > best) { best = acc[s][j]; arg = s; }
     const float o = fmaxf(best + wl[200 + j], 0.f);
+    of[j] = o;
     const uint32_t bits = f2bf(o);
     if (j & 1) ov[j >> 1] |= bits << 16; else ov[j >> 1] = bits;
     av[j >> 2] |= (uint32_t)arg << ((j & 3) * 8);
   }
   const long o = ((long)b * 196 + tid) * 32 + cg * 8;
-  *reinterpret_cast<uint4*>(out + o) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+  if (F32OUT) {
+    float* out = reinterpret_cast<float*>(out_v);
+    *reinterpret_cast<f32x4*>(out + o) = f32x4{of[0], of[1], of[2], of[3]};
+    *reinterpret_cast<f32x4*>(out + o + 4) = f32x4{of[4], of[5], of[6], of[7]};
+  } else {
+    uint16_t* out = reinterpret_cast<uint16_t*>(out_v);
+    *reinterpret_cast<uint4*>(out + o) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+  }
   if (amax) *reinterpret_cast<uint2*>(amax + o) = make_uint2(av[0], av[1]);
 }
 
@@ -111,8 +122,19 @@ DTF_API int dtf_conv1_fwd_pack(const float* images, const int* perm, const int* 
                                hipStream_t st) {
   if (B <= 0 || (perm && spe <= 0) || (Wc2 && (!Wc2f || !Wc2b))) return ERR_SHAPE;
   const int npack = Wc2 ? 25 : 0;  // one 16-byte chunk of each packed copy per thread
-  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(4 * B + npack), dim3(256), 0, st, images, perm, step_ptr, spe, B, Wt, bias,
-                     (uint16_t*)out, (uint8_t*)amax, Wc2, (char*)Wc2f, (char*)Wc2b);
+  hipLaunchKernelGGL(conv1_fwd_kernel<false>, dim3(4 * B + npack), dim3(256), 0, st, images, perm, step_ptr, spe, B, Wt, bias,
+                     out, (uint8_t*)amax, Wc2, (char*)Wc2f, (char*)Wc2b);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// fp32 pooled activations out [B,14,14,32] (reference-precision path; nothing to pack: the fp32 conv2 kernels read the
+// master weights)
+DTF_API int dtf_conv1_fwd_f32(const float* images, const int* perm, const int* step_ptr, int spe, int B, const float* Wt,
+                              const float* bias, float* out, void* amax, hipStream_t st) {
+  if (B <= 0 || (perm && spe <= 0)) return ERR_SHAPE;
+  hipLaunchKernelGGL(conv1_fwd_kernel<true>, dim3(4 * B), dim3(256), 0, st, images, perm, step_ptr, spe, B, Wt, bias,
+                     (void*)out, (uint8_t*)amax, (const float*)nullptr, (char*)nullptr, (char*)nullptr);
   DTF_CHECK_LAUNCH();
   return 0;
 }
@@ -208,6 +230,12 @@ DTF_API int dtf_unpool(const float* dpool, const void* pooled, const void* amax,
 
 // ------------------------------------------------------------------ head
 
+// (fast hardware exp/log on the bf16 path, the accurate library forms on the reference-precision path)
+template <bool F32> __device__ __forceinline__ float head_exp(float x) { return F32 ? expf(x) : __expf(x); }
+template <bool F32> __device__ __forceinline__ float head_log(float x) { return F32 ? logf(x) : __logf(x); }
+
+// F32: h_drop / dh / dz are stored as fp32 (dz rows padded to 16 floats) and nothing is rounded to bf16.
+template <bool F32>
 __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
   __shared__ float red[2][4][NC];
   __shared__ float db1s[HID];
@@ -263,6 +291,10 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
     // the fc2 GEMV consumes the same bf16-rounded activations the backward GEMMs will see
     uint32_t hb[2] = {pack_bf2(hv[0], hv[1]), pack_bf2(hv[2], hv[3])};
     float hr[4] = {bf2f(hb[0] & 0xffffu), bf2f(hb[0] >> 16), bf2f(hb[1] & 0xffffu), bf2f(hb[1] >> 16)};
+    if (F32) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hr[q] = hv[q];
+    }
     float part[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
@@ -285,7 +317,7 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
     }
     float pr[NC], psum = 0.f;
 #pragma unroll
-    for (int j = 0; j < NC; ++j) { pr[j] = __expf(z[j] - zmax); psum += pr[j]; }
+    for (int j = 0; j < NC; ++j) { pr[j] = head_exp<F32>(z[j] - zmax); psum += pr[j]; }
     const float pinv = 1.f / psum;
     int arg = 0;
     float pbest = -1.f;
@@ -301,7 +333,7 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
       // loss = -log softmax(p)[y]   (demo1/train.py:123,127: softmax applied twice)
       float q[NC], qsum = 0.f;
 #pragma unroll
-      for (int j = 0; j < NC; ++j) { q[j] = __expf(pr[j] - 1.f); qsum += q[j]; }  // p <= 1: stable shift
+      for (int j = 0; j < NC; ++j) { q[j] = head_exp<F32>(pr[j] - 1.f); qsum += q[j]; }  // p <= 1: stable shift
       const float qinv = 1.f / qsum;
       float gp[NC], dot = 0.f, qy = 0.f;
 #pragma unroll
@@ -311,7 +343,7 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
         gp[j] = (q[j] - (j == y ? 1.f : 0.f)) * p.grad_scale;
         dot = fmaf(gp[j], pr[j], dot);
       }
-      loss = -__logf(qy);
+      loss = -head_log<F32>(qy);
 #pragma unroll
       for (int j = 0; j < NC; ++j) dzv[j] = pr[j] * (gp[j] - dot);
     } else {
@@ -321,7 +353,7 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
         if (j == y) zy = z[j];
         dzv[j] = (pr[j] - (j == y ? 1.f : 0.f)) * p.grad_scale;
       }
-      loss = __logf(psum) - (zy - zmax);  // log-sum-exp form: exact even when p[y] underflows
+      loss = head_log<F32>(psum) - (zy - zmax);  // log-sum-exp form: exact even when p[y] underflows
     }
     loss_sum += loss;  // (every thread holds the row's logits: no broadcast needed for the block's totals)
     correct += (arg == y) ? 1.f : 0.f;
@@ -332,7 +364,10 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
         if (tid == j) p.probs[(long)row * NC + j] = pr[j];
     }
     if (p.training) {
-      *reinterpret_cast<uint2*>(p.h_drop + (long)row * HID + k) = make_uint2(hb[0], hb[1]);
+      if (F32)
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.h_drop) + (long)row * HID + k) = f32x4{hv[0], hv[1], hv[2], hv[3]};
+      else
+        *reinterpret_cast<uint2*>(p.h_drop + (long)row * HID + k) = make_uint2(hb[0], hb[1]);
       float dhv[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -342,10 +377,16 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
         dhv[q] = (keep[q] && hv[q] > 0.f) ? s * inv_keep : 0.f;
         accb1[q] += dhv[q];
       }
-      *reinterpret_cast<uint2*>(p.dh + (long)row * HID + k) = make_uint2(pack_bf2(dhv[0], dhv[1]), pack_bf2(dhv[2], dhv[3]));
+      if (F32)
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.dh) + (long)row * HID + k) = f32x4{dhv[0], dhv[1], dhv[2], dhv[3]};
+      else
+        *reinterpret_cast<uint2*>(p.dh + (long)row * HID + k) = make_uint2(pack_bf2(dhv[0], dhv[1]), pack_bf2(dhv[2], dhv[3]));
 #pragma unroll
       for (int j = 0; j < NC; ++j)
-        if (tid == j) p.dz[(long)row * NC + j] = f2bf(dzv[j]);
+        if (tid == j) {
+          if (F32) reinterpret_cast<float*>(p.dz)[(long)row * 16 + j] = dzv[j];
+          else p.dz[(long)row * NC + j] = f2bf(dzv[j]);
+        }
 #pragma unroll
       for (int j = 0; j < NC; ++j) accb2[j] += dzv[j];
     }
@@ -374,7 +415,10 @@ DTF_API int dtf_head(const HeadParams* hp, int blocks, hipStream_t st) {
   if (hp->B <= 0 || hp->nslab < 1 || blocks < 1 || hp->keep_prob <= 0.f) return ERR_SHAPE;
   if (hp->training && (!hp->h_drop || !hp->dh || !hp->dz || !hp->db_fc1 || !hp->db_fc2)) return ERR_SHAPE;
   if (blocks > hp->B) blocks = hp->B;
-  hipLaunchKernelGGL(head_kernel, dim3(blocks), dim3(256), 0, st, *hp);
+  if (hp->f32)
+    hipLaunchKernelGGL(head_kernel<true>, dim3(blocks), dim3(256), 0, st, *hp);
+  else
+    hipLaunchKernelGGL(head_kernel<false>, dim3(blocks), dim3(256), 0, st, *hp);
   DTF_CHECK_LAUNCH();
   return 0;
 }

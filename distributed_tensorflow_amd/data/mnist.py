@@ -267,7 +267,12 @@ class DeviceDataset:
         self.epoch += 1
 
     def steps_per_epoch(self, batch_size: int) -> int:
-        return max(1, self.shard_size // batch_size)
+        # the fused gather reads perm[(step % spe)*B + b] for every b < B: a batch larger than this rank's shard would
+        # read past the permutation (and then past the images), so it is an error, not a short batch
+        if batch_size > self.shard_size:
+            raise ValueError("batch_size %d exceeds this rank's shard of %d examples (%d examples over %d ranks)"
+                             % (batch_size, self.shard_size, self.num_examples, self.world))
+        return self.shard_size // batch_size
 
     def batch_indices(self, step_in_epoch: int, batch_size: int):
         s = step_in_epoch * batch_size

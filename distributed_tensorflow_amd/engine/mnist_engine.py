@@ -3,8 +3,9 @@
 ``NativeMnistEngine`` — the MI355X hot path.  It owns a flat fp32 parameter arena
 (``P``/``G``/``M``/``V``: weights, gradients, Adam slots; TF layouts, arena order =
 gradient-readiness order), the bf16 activation workspaces and a private HIP stream, and
-drives the C++ step executor (``csrc/hip/engine.hip``): 12 kernels + 1 memset per train
-step, replayed as a hipGraph.  Batches are gathered on-device from an HBM-resident
+drives the C++ step executor (``csrc/hip/engine.hip``): 8 kernels per train step, replayed as a
+hipGraph (16 steps per graph launch).  ``dtype="fp32"`` runs the whole step at the reference's
+precision (fp32 activations, exact-fp32 MFMA); ``dtype="bf16"`` uses bf16 MFMA operands.  Batches are gathered on-device from an HBM-resident
 dataset through a device permutation; loss/accuracy land in a device ring buffer that is
 read back only at logging points (the reference syncs every step, quirk Q5).
 
@@ -63,15 +64,23 @@ class NativeMnistEngine(_EngineBase):
                  keep_prob: float = 0.7, double_softmax: bool = True, seed: Optional[int] = None,
                  world: int = 1, eval_chunk: int = 5000, use_graph: bool = True,
                  fc1_splits: int = 14, bwd_splits: int = 2, dw2_splits: int = 5, head_blocks: int = 0,
-                 beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, device="cuda"):
+                 beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, device="cuda", dtype: str = "bf16"):
         if not torch.cuda.is_available():
             raise native.NativeError("NativeMnistEngine needs a GPU (MI355X); use EagerMnistEngine on CPU")
         bwd_splits = int(os.environ.get("DTF_BWD_SPLITS", bwd_splits))  # (tuning knobs for A/B runs of bench.py)
         fc1_splits = int(os.environ.get("DTF_FC1_SPLITS", fc1_splits))
         dw2_splits = int(os.environ.get("DTF_DW2_IPW", dw2_splits))
         head_blocks = int(os.environ.get("DTF_HEAD_BLOCKS", head_blocks))
+        if dtype not in ("bf16", "fp32"):
+            raise ValueError("dtype must be bf16 or fp32")
+        # fp32 = the reference's precision (demo1/train.py computes in float32): fp32 activations and activation gradients,
+        # every GEMM-shaped op on the exact-fp32 MFMA.  bf16 = bf16 MFMA operands, fp32 accumulation and master weights.
+        self.dtype = dtype
+        f32 = dtype == "fp32"
+        if f32:  # the fp32 kernels' own tile geometry (f32_fc.hip): 14 K-slabs of 224 forward, 4 of 256 backward
+            fc1_splits, bwd_splits = int(os.environ.get("DTF_FC1_SPLITS", 14)), int(os.environ.get("DTF_BWD_SPLITS", 4))
         self.lib = native.hip()
-        native.check(self.lib.dtf_conv2_lds_init() or self.lib.dtf_conv2_bwd_lds_init(),
+        native.check(self.lib.dtf_conv2_lds_init() or self.lib.dtf_conv2_bwd_lds_init() or self.lib.dtf_conv2_f32_init(),
                      "LDS kernel attribute setup")  # before any stream capture
         self.device = torch.device(device)
         self.dataset = dataset
@@ -83,7 +92,7 @@ class NativeMnistEngine(_EngineBase):
         self.stream = torch.cuda.Stream(device=self.device)
         self.layout, self.n_arena = arena_layout()
         dev = self.device
-        f32 = dict(dtype=torch.float32, device=dev)
+        is_f32, f32 = f32, dict(dtype=torch.float32, device=dev)
         self.P = torch.zeros(self.n_arena, **f32)
         self.G = torch.zeros(self.n_arena, **f32)
         self.M = torch.zeros(self.n_arena, **f32)
@@ -93,7 +102,7 @@ class NativeMnistEngine(_EngineBase):
         self.metrics_ring = torch.zeros(self.RING * 2, **f32)
         self.eval_metrics = torch.zeros(2, **f32)
         mb = self.maxB
-        bf = dict(dtype=torch.bfloat16, device=dev)
+        bf = f32 if is_f32 else dict(dtype=torch.bfloat16, device=dev)  # activations / activation gradients
         u8 = dict(dtype=torch.uint8, device=dev)
         self.ws = {
             "pool1": torch.zeros(mb * 196 * 32, **bf), "amax1": torch.zeros(mb * 196 * 32, **u8),
@@ -118,6 +127,7 @@ class NativeMnistEngine(_EngineBase):
         s.ring = self.RING
         s.lr, s.beta1, s.beta2, s.eps, s.keep_prob = lr, beta1, beta2, eps, keep_prob
         s.seed = self.seed
+        s.f32 = int(is_f32)
         if dataset is not None:
             s.images, s.labels, s.perm = dataset.images.data_ptr(), dataset.labels.data_ptr(), dataset.perm.data_ptr()
         s.P, s.G, s.M, s.V = (t.data_ptr() for t in (self.P, self.G, self.M, self.V))
@@ -178,6 +188,24 @@ class NativeMnistEngine(_EngineBase):
     @property
     def global_step(self) -> int:
         return self._steps_done
+
+    def reset_training(self, dataset: DeviceDataset, seed: Optional[int] = None) -> None:
+        """Start a fresh run on another device-resident split with this engine's buffers, kernels and gradient hooks:
+        re-initialised parameters (the same on every rank for the same ``seed``), zeroed optimizer state, step counter and
+        metric ring.  Drops the captured graphs (they hold the old split's addresses)."""
+        self.stream.synchronize()
+        self.dataset = dataset
+        self.spe = dataset.steps_per_epoch(self.batch_size)
+        self.cfg.spe = self.spe
+        self.cfg.images, self.cfg.labels, self.cfg.perm = (dataset.images.data_ptr(), dataset.labels.data_ptr(),
+                                                           dataset.perm.data_ptr())
+        with torch.cuda.stream(self.stream):
+            for t in (self.G, self.M, self.V, self.step_t, self.ticket, self.metrics_ring):
+                t.zero_()
+        self.stream.synchronize()
+        self._steps_done = 0
+        self.init_params(seed)
+        self._drop_graph()
 
     def set_lr(self, lr: float) -> None:
         self.cfg.lr = lr
@@ -277,7 +305,7 @@ class NativeMnistEngine(_EngineBase):
 
     def gather_supported(self) -> bool:
         """The activation-gather schedule rides on the fused fc backward launch (batch <= 128, split-K data gradient)."""
-        return self.batch_size <= 128 and self.cfg.bwd_splits > 1
+        return self.dtype == "bf16" and self.batch_size <= 128 and self.cfg.bwd_splits > 1
 
     def gather_bytes(self) -> Tuple[int, int]:
         """Bytes of the two fc1 filter-gradient operands a rank publishes: bf16 pool2 [B,3136] and dh [B,1024]."""
@@ -419,7 +447,8 @@ class EagerMnistEngine(_EngineBase):
 
     def __init__(self, dataset, *, batch_size: int = 100, lr: float = 1e-4, keep_prob: float = 0.7,
                  double_softmax: bool = True, seed: Optional[int] = None, world: int = 1, device="cpu",
-                 beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, **_unused):
+                 beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, philox_seed: Optional[int] = None,
+                 **_unused):
         self.device = torch.device(device)
         self.dataset = dataset
         self.batch_size, self.lr, self.keep_prob = batch_size, lr, keep_prob
@@ -435,6 +464,8 @@ class EagerMnistEngine(_EngineBase):
         self._ring = np.zeros((self.RING, 2), np.float64)
         self._gen = torch.Generator(device="cpu")
         self._gen.manual_seed(seed if seed is not None else int(np.random.SeedSequence().entropy % (2 ** 31)))
+        # philox_seed = a NativeMnistEngine's ``seed``: draw exactly that engine's dropout masks (utils/philox.py)
+        self.philox_seed = philox_seed
         self.load_params(mnist_cnn.init_params(seed))
 
     def param_views(self, arena=None):
@@ -485,7 +516,10 @@ class EagerMnistEngine(_EngineBase):
         leaf = self.P.detach().clone().requires_grad_(True)
         views = self.param_views(leaf)
         mask = None
-        if self.keep_prob < 1.0:
+        if self.keep_prob < 1.0 and self.philox_seed is not None:
+            from ..utils.philox import dropout_keep_mask
+            mask = torch.from_numpy(dropout_keep_mask(x.shape[0], self._steps_done, self.philox_seed, self.keep_prob)).to(self.device)
+        elif self.keep_prob < 1.0:
             mask = (torch.rand(x.shape[0], 1024, generator=self._gen) < self.keep_prob).float().to(self.device)
         logits = mnist_cnn.forward_logits(views, x, keep_prob=self.keep_prob, dropout_mask=mask, training=True)
         loss, pred = mnist_cnn.softmax_xent(logits, y.long(), double_softmax=self.double_softmax)
@@ -538,5 +572,6 @@ def make_engine(kind: str, dataset, **kw):
     if kind == "eager":
         kw.pop("use_graph", None)
         kw.pop("eval_chunk", None)
+        kw.pop("dtype", None)  # (plain PyTorch fp32)
         return EagerMnistEngine(dataset, **kw)
     raise ValueError("unknown engine %r" % kind)

@@ -38,6 +38,7 @@ class HeadParams(C.Structure):
         ("h_drop", c_void_p), ("dh", c_void_p), ("dz", c_void_p),
         ("db_fc2", c_void_p), ("db_fc1", c_void_p), ("metrics", c_void_p), ("metrics_ring", c_int),
         ("probs", c_void_p), ("pred", c_void_p), ("zero_buf", c_void_p), ("zero_n4", c_long),
+        ("f32", c_int),
     ]
 
 
@@ -70,6 +71,7 @@ class MnistEngineStruct(C.Structure):  # csrc/hip/engine.hip: struct MnistEngine
         ("gather_A", c_void_p * 8), ("gather_B", c_void_p * 8), ("gather_comm", c_void_p), ("gather_n", c_int), ("gather_rank", c_int),
         ("wc2f", c_void_p), ("wc2b", c_void_p),
         ("gather_local", c_void_p), ("gather_bytes", c_long),
+        ("f32", c_int),
     ]
 
 
@@ -142,6 +144,15 @@ def hip() -> C.CDLL:
         _sig(lib, "dtf_mnist_apply_part", I, [C.POINTER(MnistEngineStruct), I, P])
         _sig(lib, "dtf_mnist_apply_part_ipc", I, [C.POINTER(MnistEngineStruct), I, P, P])
         _sig(lib, "dtf_mnist_eval", I, [C.POINTER(MnistEngineStruct), P, P, I, P, P, P, P])
+        # exact-fp32 (reference precision) kernels: f32_fc.hip, f32_conv2.hip
+        _sig(lib, "dtf_fc_fwd_f32", I, [P, P, P, I, I, I, I, P, I, P])
+        _sig(lib, "dtf_fc_bwd_data_f32", I, [P, P, P, I, I, I, I, P])
+        _sig(lib, "dtf_fc_dw_f32", I, [P, I, P, I, P, I, I, I, I, P])
+        _sig(lib, "dtf_conv2_f32_init", I, [])
+        _sig(lib, "dtf_conv1_fwd_f32", I, [P, P, P, I, I, P, P, P, P, P])
+        _sig(lib, "dtf_conv2_fwd_f32", I, [P, P, P, P, P, I, P])
+        _sig(lib, "dtf_conv2_bwd_data_f32", I, [P, P, P, P, P, P, P, I, P])
+        _sig(lib, "dtf_conv_dw_duo_f32", I, [P, P, P, P, P, I, P, P, P, I, P, P, P, P, C.POINTER(OptimParams), P])
         _sig(lib, "dtf_graph_begin", I, [P])
         _sig(lib, "dtf_graph_end", I, [P, C.POINTER(c_void_p)])
         _sig(lib, "dtf_graph_launch", I, [P, P])

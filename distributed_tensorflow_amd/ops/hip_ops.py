@@ -225,3 +225,99 @@ def sgd_(P: torch.Tensor, G: torch.Tensor, step: torch.Tensor, ticket: torch.Ten
     op.lr, op.grad_scale = lr, grad_scale
     op.step, op.ticket, op.metrics_ring, op.ring = step.data_ptr(), ticket.data_ptr(), 0, 0
     native.check(native.hip().dtf_sgd(C.byref(op), _st()), "sgd")
+
+
+# ----------------------------------------------------------------------------- exact-fp32 (reference precision) ops
+# csrc/hip/f32_fc.hip, f32_conv2.hip: v_mfma_f32_16x16x4_f32, fp32 operands and accumulation (demo1/train.py computes in
+# float32); what NativeMnistEngine(dtype="fp32") runs.
+
+def fc_forward_f32(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
+                   splits: int = 1) -> torch.Tensor:
+    """``x[M,K] @ w[K,N]`` (both fp32) -> fp32 ``[S,M,N]`` split-K slabs (S==1: bias/relu applied)."""
+    _chk(x, torch.float32, "x")
+    _chk(w, torch.float32, "w")
+    M, K = x.shape
+    K2, N = w.shape
+    assert K == K2
+    ksteps = (K + 31) // 32  # BK of the kernel (f32_fc.hip)
+    kchunk = (ksteps + splits - 1) // splits * 32
+    s_eff = (K + kchunk - 1) // kchunk
+    out = torch.empty(s_eff, M, N, dtype=torch.float32, device=x.device)
+    native.check(native.hip().dtf_fc_fwd_f32(x.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, splits, native.ptr(bias),
+                                             int(relu), _st()), "fc_fwd_f32")
+    return out
+
+
+def fc_backward_data_f32(dy: torch.Tensor, w: torch.Tensor, splits: int = 1) -> torch.Tensor:
+    """``dy[M,K] @ w[N,K]^T`` (fp32) -> fp32 ``[M,N]``."""
+    _chk(dy, torch.float32, "dy")
+    _chk(w, torch.float32, "w")
+    M, K = dy.shape
+    N, K2 = w.shape
+    assert K == K2
+    out = torch.zeros(M, N, dtype=torch.float32, device=dy.device)
+    native.check(native.hip().dtf_fc_bwd_data_f32(dy.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, splits, _st()),
+                 "fc_bwd_data_f32")
+    return out
+
+
+def fc_backward_weight_f32(x: torch.Tensor, dy: torch.Tensor, n_valid: Optional[int] = None, splits: int = 1) -> torch.Tensor:
+    """``x[Kb,M]^T @ dy[Kb,N]`` (fp32, Kb = batch) -> fp32 ``[M,N]``.  ``n_valid``: use only the first columns of ``dy``
+    (rows padded to a multiple of 4 floats, e.g. the [B,16] logit-gradient buffer holding 10 classes)."""
+    _chk(x, torch.float32, "x")
+    _chk(dy, torch.float32, "dy")
+    Kb, M = x.shape
+    Kb2, ldy = dy.shape
+    N = ldy if n_valid is None else n_valid
+    assert Kb == Kb2 and N <= ldy
+    out = torch.zeros(M, N, dtype=torch.float32, device=x.device)
+    native.check(native.hip().dtf_fc_dw_f32(x.data_ptr(), M, dy.data_ptr(), ldy, out.data_ptr(), M, N, Kb, splits, _st()),
+                 "fc_dw_f32")
+    return out
+
+
+def conv1_forward_f32(images: torch.Tensor, w: torch.Tensor, b: torch.Tensor, index: Optional[torch.Tensor] = None
+                      ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """conv5x5(1->32)+bias+ReLU+pool with fp32 output ``[B,14,14,32]`` and the pool argmax."""
+    _chk(images, torch.float32, "images")
+    _chk(w, torch.float32, "w")
+    B = images.shape[0] if index is None else index.shape[0]
+    out = torch.empty(B, 14, 14, 32, dtype=torch.float32, device=images.device)
+    amax = torch.empty(B, 14, 14, 32, dtype=torch.uint8, device=images.device)
+    native.check(native.hip().dtf_conv1_fwd_f32(images.data_ptr(), native.ptr(index), 0, 1, B, w.data_ptr(), b.data_ptr(),
+                                                out.data_ptr(), amax.data_ptr(), _st()), "conv1_fwd_f32")
+    return out, amax
+
+
+def conv2_forward_f32(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """MNIST conv2 (5x5, 32->64, SAME) + bias + ReLU + 2x2 pool: fp32 ``[B,14,14,32]`` -> fp32 ``[B,7,7,64]`` + argmax."""
+    _chk(x, torch.float32, "x")
+    _chk(w, torch.float32, "w")
+    _chk(b, torch.float32, "b")
+    B = x.shape[0]
+    assert x.shape[1:] == (14, 14, 32) and w.numel() == 25 * 32 * 64 and b.numel() == 64
+    out = torch.empty(B, 7, 7, 64, dtype=torch.float32, device=x.device)
+    amax = torch.empty(B, 7, 7, 64, dtype=torch.uint8, device=x.device)
+    native.check(native.hip().dtf_conv2_fwd_f32(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), amax.data_ptr(), B,
+                                                _st()), "conv2_fwd_f32")
+    return out, amax
+
+
+def conv2_backward_f32(dpool2: torch.Tensor, pool2: torch.Tensor, amax2: torch.Tensor, w: torch.Tensor, pool1: torch.Tensor):
+    """MNIST conv2 backward at fp32 (un-pool + bwd-data + ReLU mask + db, and dW) -> (dpool1, dW, db2)."""
+    _chk(dpool2, torch.float32, "dpool2")
+    _chk(pool2, torch.float32, "pool2")
+    _chk(amax2, torch.uint8, "amax2")
+    _chk(w, torch.float32, "w")
+    _chk(pool1, torch.float32, "pool1")
+    B = dpool2.shape[0]
+    assert dpool2.shape[1:] == (7, 7, 64) and pool1.shape == (B, 14, 14, 32) and w.numel() == 25 * 32 * 64
+    dpool1 = torch.empty(B, 14, 14, 32, dtype=torch.float32, device=dpool2.device)
+    dW = torch.zeros(5, 5, 32, 64, dtype=torch.float32, device=dpool2.device)
+    db = torch.zeros(64, dtype=torch.float32, device=dpool2.device)
+    lib = native.hip()
+    native.check(lib.dtf_conv2_bwd_data_f32(dpool2.data_ptr(), pool2.data_ptr(), amax2.data_ptr(), w.data_ptr(),
+                                            pool1.data_ptr(), dpool1.data_ptr(), db.data_ptr(), B, _st()), "conv2_bwd_data_f32")
+    native.check(lib.dtf_conv_dw_duo_f32(dpool2.data_ptr(), pool2.data_ptr(), amax2.data_ptr(), pool1.data_ptr(), dW.data_ptr(),
+                                         B, 0, 0, 0, 1, 0, 0, 0, 0, None, _st()), "conv2_dw_f32")
+    return dpool1, dW, db
