@@ -4,10 +4,12 @@
 //
 // At 64 FLOP/clk/SIMD these kernels are bound by the MFMA pipe (2 GFLOP each at batch 100 = 12.8 us on all 1024 SIMDs), so
 // what matters is that every SIMD gets the same number of MFMAs and never waits:
-//  * forward / data gradient: one workgroup per (image, half of the output channels).  The halo'd image sits in LDS; the
-//    four waves split K (input-channel quarters of every tap), so each wave issues the same 1300 MFMAs on 26 / 13
-//    accumulator tiles, streams its own disjoint slice of the filter straight from L2 into registers one tap ahead (no
-//    barrier inside the k loop), and the four partial sums are combined through LDS at the end.
+//  * forward: one workgroup per 20 pooling windows of the whole batch (245 workgroups at batch 100), 8 waves = (output-
+//    channel half, input-channel quarter): every wave issues the same 500 MFMAs on 10 accumulator tiles.
+//  * data gradient: one workgroup per (image, half of the input channels), the four waves split K (output-channel quarters
+//    of every tap): 1300 MFMAs each on 13 accumulator tiles.
+//    In both, the halo'd image sits in LDS, a wave streams its own disjoint slice of the filter straight from L2 into
+//    registers one tap ahead (no barrier inside the k loop), and the partial sums are combined through LDS at the end.
 //  * filter gradient: one workgroup per (4 images, half of the output channels, filter row); per image the waves take
 //    the 49 position groups round-robin with a per-image rotation, so over the 4 images each wave issues exactly 49 x 20
 //    MFMAs; 250 workgroups at batch 100.
@@ -17,127 +19,184 @@
 #include "adam_body.h"
 #include "f32_gemm.h"
 
+// -DDTF_CONV_STAMPS (diagnostic builds only, scripts/dbg): thread 0 of every workgroup records (shader clock, 100 MHz
+// real-time clock) pairs at phase boundaries into g_conv_stamps[workgroup][32]
+#ifdef DTF_CONV_STAMPS
+__device__ unsigned long long* g_conv_stamps;
+DTF_API int dtf_dbg_set_conv_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps), &p, sizeof(p)); }
+#define CSTAMP(i) do { if (threadIdx.x == 0 && g_conv_stamps) { g_conv_stamps[blockIdx.x * 32 + 2 * (i)] = __builtin_amdgcn_s_memtime(); \
+  g_conv_stamps[blockIdx.x * 32 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+// per-wave: loop-end clock and HW_ID (SIMD / CU placement) at g_conv_stamps[workgroup][32 .. 47] / [48 .. 63]
+#define CSTAMP_WAVE() do { if ((threadIdx.x & 63) == 0 && g_conv_stamps) { \
+  g_conv_stamps[gridDim.x * 32 + blockIdx.x * 32 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime(); \
+  g_conv_stamps[gridDim.x * 32 + blockIdx.x * 32 + 16 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); } } while (0)
+#else
+#define CSTAMP(i) do { } while (0)
+#define CSTAMP_WAVE() do { } while (0)
+#endif
+
 namespace {
 constexpr int ERR_SHAPE = -22;
 constexpr int XP = 36;                  // floats per input halo pixel (32 ch + 4 pad)
 constexpr int XIMG = 18 * 18 * XP;      // 11 664 floats
 constexpr int DP = 68;                  // floats per dY halo pixel (64 ch + 4 pad)
 constexpr int DIMG = 18 * 18 * DP;      // 22 032 floats
-constexpr int FWD_RED = 4 * 26 * 256;   // cross-wave reduction: [wave][tile][lane][4]
-constexpr int FWD_LDS = (XIMG > FWD_RED ? XIMG : FWD_RED) * 4;
 constexpr int BWD_RED = 4 * 13 * 256;
 constexpr int BWD_LDS = ((DIMG > BWD_RED ? DIMG : BWD_RED) + 64) * 4;
 }  // namespace
 
 // ------------------------------------------------------------------ forward + bias + ReLU + 2x2 max-pool
-// grid (B, 2); 256 threads.  x fp32 [B,14,14,32]; W fp32 HWIO [800][64]; out fp32 [B,49,64]; amax uint8 [B,49,64]
-__global__ __launch_bounds__(256) void conv2_fwd_f32_kernel(const float* __restrict__ x, const float* __restrict__ W,
+// One workgroup = 20 consecutive pooling windows (80 output positions = 5 MFMA row tiles) of the batch's 49*B windows x all
+// 64 output channels; 49*B / 20 = 245 workgroups at batch 100, i.e. 96 % of the CUs get one (one workgroup per image half:
+// 200).  A range of 20 windows touches at most two images; both halo'd images are staged.  8 waves, two per SIMD, so one
+// wave's LDS-read latency and filter prefetch run in the shadow of the other's MFMAs: wave = (output-channel half, input-
+// channel quarter); the four K slices of a half are combined through LDS at the end.
+// grid ceil(49 B / 20); 512 threads.  x fp32 [B,14,14,32]; W fp32 HWIO [800][64]; out fp32 [B,49,64]; amax uint8 [B,49,64]
+namespace {
+constexpr int FWD_WIN = 20, FWD_MT = FWD_WIN / 4;
+constexpr int FWD_RED2 = 8 * FWD_MT * 2 * 256;  // [wave][tile][lane][4]
+constexpr int FWD_LDS2 = (2 * XIMG > FWD_RED2 ? 2 * XIMG : FWD_RED2) * 4;
+}  // namespace
+
+__global__ __launch_bounds__(512) void conv2_fwd_f32_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                             const float* __restrict__ bias, float* __restrict__ out,
-                                                            uint8_t* __restrict__ amax) {
+                                                            uint8_t* __restrict__ amax, const int B) {
   extern __shared__ __attribute__((aligned(16))) float smem32[];
   float* img = smem32;
-  const int b = blockIdx.x, n0 = blockIdx.y * 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int c0 = 8 * wave;  // this wave's input channels [c0, c0 + 8) of every tap
+  const int nh = wave >> 2, c0 = 8 * (wave & 3);  // output channels [32 nh, 32 nh + 32), input channels [c0, c0 + 8) of every tap
+  const int n0 = 32 * nh;
+  const int nwin = 49 * B;
+  const int gw0 = blockIdx.x * FWD_WIN;
+  const int b0 = gw0 / 49;
+  const int glast = min(gw0 + FWD_WIN, nwin) - 1;
+  const bool two = glast / 49 != b0;  // (workgroup-uniform)
+  CSTAMP(0);
 
   // B fragments of tap t: element (j, nt) = W[t*32 + c0 + 2q + j][n0 + 16 nt + r]
   const float* wbase = W + (long)(c0 + 2 * q) * 64 + n0 + r;
-  float bcur[4], bnxt[4];
+  // A whole filter row (5 taps) is fetched one row ahead, pinned with a scheduling barrier: left to itself the compiler
+  // sinks a one-tap-ahead prefetch to ~10 MFMAs before its use, and every tap then waits for L2 (45 instead of 32 cycles
+  // per MFMA measured with two waves per SIMD).
+  float bcur[5][4], bnxt[5][4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) bcur[e] = wbase[(e >> 1) * 64 + (e & 1) * 16];
+  for (int dx = 0; dx < 5; ++dx)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bcur[dx][e] = wbase[(long)dx * 2048 + (e >> 1) * 64 + (e & 1) * 16];
 
-  // ---- the halo'd image: 324 pixels x 8 float4 of payload, halo -> zero
-  f32x4 iv[11];
+  // ---- the halo'd image(s): 324 pixels x 8 float4 of payload each, halo -> zero
+  f32x4 iv[2][6];
 #pragma unroll
-  for (int i = 0; i < 11; ++i) {
-    const int c = tid + 256 * i;
-    const int pix = c >> 3, part = c & 7;
-    const int hy = pix / 18, hx = pix - hy * 18;
-    const int y = hy - 2, xx = hx - 2;
-    const bool ok = c < 2592 && (unsigned)y < 14u && (unsigned)xx < 14u;
-    iv[i] = *reinterpret_cast<const f32x4*>(x + (ok ? (((long)b * 14 + y) * 14 + xx) * 32 + part * 4 : 0L));
-    if (!ok) iv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < 2; ++s) {
+    if (s == 1 && !two) break;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int c = tid + 512 * i;
+      const int pix = c >> 3, part = c & 7;
+      const int hy = pix / 18, hx = pix - hy * 18;
+      const int y = hy - 2, xx = hx - 2;
+      const bool ok = c < 2592 && (unsigned)y < 14u && (unsigned)xx < 14u;
+      iv[s][i] = *reinterpret_cast<const f32x4*>(x + (ok ? (((long)(b0 + s) * 14 + y) * 14 + xx) * 32 + part * 4 : 0L));
+      if (!ok) iv[s][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
 #pragma unroll
-  for (int i = 0; i < 11; ++i) {
-    const int c = tid + 256 * i;
-    if (c < 2592) *reinterpret_cast<f32x4*>(img + (c >> 3) * XP + (c & 7) * 4) = iv[i];
+  for (int s = 0; s < 2; ++s) {
+    if (s == 1 && !two) break;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int c = tid + 512 * i;
+      if (c < 2592) *reinterpret_cast<f32x4*>(img + s * XIMG + (c >> 3) * XP + (c & 7) * 4) = iv[s][i];
+    }
   }
   __syncthreads();
+  CSTAMP(1);
 
   // rows in pool-window order: m = 4*window + sub, so a lane's four accumulator registers are one pooling window
-  int abase[13];
+  int abase[FWD_MT];
 #pragma unroll
-  for (int mt = 0; mt < 13; ++mt) {
-    int win = mt * 4 + (r >> 2);
-    win = win < 49 ? win : 48;  // the three padding windows of the last tile; their results are discarded
-    const int sub = r & 3;
+  for (int mt = 0; mt < FWD_MT; ++mt) {
+    int gw = gw0 + mt * 4 + (r >> 2);
+    gw = gw < nwin ? gw : nwin - 1;  // padding windows of the last workgroup; their results are discarded
+    const int slot = gw / 49 - b0, win = gw - (b0 + slot) * 49, sub = r & 3;
     const int py = win / 7, px = win - py * 7;
-    abase[mt] = ((2 * py + (sub >> 1)) * 18 + 2 * px + (sub & 1)) * XP + c0 + 2 * q;
+    abase[mt] = slot * XIMG + ((2 * py + (sub >> 1)) * 18 + 2 * px + (sub & 1)) * XP + c0 + 2 * q;
   }
-  f32x4 acc[13][2];
+  f32x4 acc[FWD_MT][2];
 #pragma unroll
-  for (int mt = 0; mt < 13; ++mt)
+  for (int mt = 0; mt < FWD_MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll 1
   for (int dy = 0; dy < 5; ++dy) {
+    const int dyn = dy < 4 ? dy + 1 : 4;  // (the last prefetch re-reads row 4)
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bnxt[dx][e] = wbase[(long)(dyn * 5 + dx) * 2048 + (e >> 1) * 64 + (e & 1) * 16];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int dx = 0; dx < 5; ++dx) {
-      const int tap = dy * 5 + dx;
-      const int tn = tap < 24 ? tap + 1 : 24;  // (the last prefetch re-reads tap 24)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bnxt[e] = wbase[(long)tn * 2048 + (e >> 1) * 64 + (e & 1) * 16];
       const int toff = (dy * 18 + dx) * XP;
-      float2 af[13];
+      float2 af[FWD_MT];
 #pragma unroll
-      for (int mt = 0; mt < 13; ++mt) af[mt] = *reinterpret_cast<const float2*>(img + abase[mt] + toff);
+      for (int mt = 0; mt < FWD_MT; ++mt) af[mt] = *reinterpret_cast<const float2*>(img + abase[mt] + toff);
 #pragma unroll
-      for (int mt = 0; mt < 13; ++mt) {
-        acc[mt][0] = mfma16f32(af[mt].x, bcur[0], acc[mt][0]);
-        acc[mt][1] = mfma16f32(af[mt].x, bcur[1], acc[mt][1]);
+      for (int mt = 0; mt < FWD_MT; ++mt) {
+        acc[mt][0] = mfma16f32(af[mt].x, bcur[dx][0], acc[mt][0]);
+        acc[mt][1] = mfma16f32(af[mt].x, bcur[dx][1], acc[mt][1]);
       }
 #pragma unroll
-      for (int mt = 0; mt < 13; ++mt) {
-        acc[mt][0] = mfma16f32(af[mt].y, bcur[2], acc[mt][0]);
-        acc[mt][1] = mfma16f32(af[mt].y, bcur[3], acc[mt][1]);
+      for (int mt = 0; mt < FWD_MT; ++mt) {
+        acc[mt][0] = mfma16f32(af[mt].y, bcur[dx][2], acc[mt][0]);
+        acc[mt][1] = mfma16f32(af[mt].y, bcur[dx][3], acc[mt][1]);
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bcur[e] = bnxt[e];
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bcur[dx][e] = bnxt[dx][e];
   }
 
-  // ---- combine the four K slices through LDS (the image is dead), then bias + ReLU + pool on register quads
+  // ---- combine the four K slices of each channel half through LDS (the images are dead), then bias + ReLU + pool on
+  // register quads; tile id = (nh * FWD_MT + mt) * 2 + nt, finalised by wave (id % 8)
+  CSTAMP(2);
+  CSTAMP_WAVE();
   __syncthreads();
+  CSTAMP(3);
   float* red = smem32;
+  constexpr int TPW = FWD_MT * 2;  // tiles per wave
 #pragma unroll
-  for (int mt = 0; mt < 13; ++mt)
+  for (int mt = 0; mt < FWD_MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
-      *reinterpret_cast<f32x4*>(red + ((wave * 26 + mt * 2 + nt) * 64 + lane) * 4) = acc[mt][nt];
+      *reinterpret_cast<f32x4*>(red + ((wave * TPW + mt * 2 + nt) * 64 + lane) * 4) = acc[mt][nt];
   __syncthreads();
-  for (int t = wave; t < 26; t += 4) {
-    f32x4 s = *reinterpret_cast<const f32x4*>(red + ((0 * 26 + t) * 64 + lane) * 4);
+  for (int id = wave; id < 2 * TPW; id += 8) {
+    const int h = id / TPW, t = id - h * TPW;
+    f32x4 s = *reinterpret_cast<const f32x4*>(red + (((4 * h) * TPW + t) * 64 + lane) * 4);
 #pragma unroll
     for (int w = 1; w < 4; ++w) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(red + ((w * 26 + t) * 64 + lane) * 4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(red + (((4 * h + w) * TPW + t) * 64 + lane) * 4);
       s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
     }
     const int mt = t >> 1, nt = t & 1;
-    const int win = mt * 4 + q, col = n0 + nt * 16 + r;
+    const int gw = gw0 + mt * 4 + q, col = 32 * h + nt * 16 + r;
     float best = s[0];
     int arg = 0;
 #pragma unroll
     for (int j = 1; j < 4; ++j)
       if (s[j] > best) { best = s[j]; arg = j; }
-    if (win < 49) {
-      const long o = ((long)b * 49 + win) * 64 + col;
+    if (gw < nwin) {
+      const long o = (long)gw * 64 + col;
       out[o] = fmaxf(best + bias[col], 0.f);
       if (amax) amax[o] = (uint8_t)arg;
     }
   }
+  CSTAMP(4);
 }
 
 // ------------------------------------------------------------------ un-pool helpers (fp32 activations)
@@ -187,7 +246,10 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_f32_kernel(const float* __
 
   // B fragment of (flipped) tap t': elements j = W[24 - t'][n0 + r][k0 + 4q + j]
   const float* wbase = W + (long)(n0 + r) * 64 + k0 + 4 * q;
-  f32x4 bcur = *reinterpret_cast<const f32x4*>(wbase + 24L * 2048), bnxt;
+  // (a whole filter row one row ahead, pinned: see conv2_fwd_f32_kernel)
+  f32x4 bcur[5], bnxt[5];
+#pragma unroll
+  for (int dx = 0; dx < 5; ++dx) bcur[dx] = *reinterpret_cast<const f32x4*>(wbase + (long)(24 - dx) * 2048);
 
   UnpoolTask32 ut[4];
 #pragma unroll
@@ -236,11 +298,12 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_f32_kernel(const float* __
 
 #pragma unroll 1
   for (int dy = 0; dy < 5; ++dy) {
+    const int dyn = dy < 4 ? dy + 1 : 4;
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) bnxt[dx] = *reinterpret_cast<const f32x4*>(wbase + (long)(24 - (dyn * 5 + dx)) * 2048);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int dx = 0; dx < 5; ++dx) {
-      const int tapp = dy * 5 + dx;
-      const int tn = tapp < 24 ? tapp + 1 : 24;
-      bnxt = *reinterpret_cast<const f32x4*>(wbase + (long)(24 - tn) * 2048);
       const int toff = (dy * 18 + dx) * DP;
       f32x4 af[13];
 #pragma unroll
@@ -248,9 +311,11 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_f32_kernel(const float* __
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int mt = 0; mt < 13; ++mt) acc[mt] = mfma16f32(af[mt][j], bcur[j], acc[mt]);
-      bcur = bnxt;
+        for (int mt = 0; mt < 13; ++mt) acc[mt] = mfma16f32(af[mt][j], bcur[dx][j], acc[mt]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) bcur[dx] = bnxt[dx];
   }
 
   __syncthreads();
@@ -425,7 +490,7 @@ static bool g_f32_attr_set = false;
 DTF_API int dtf_conv2_f32_init() {
   if (g_f32_attr_set) return 0;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_fwd_f32_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS2);
   if (e != hipSuccess) return (int)e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_bwd_data_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           BWD_LDS);
@@ -443,7 +508,8 @@ DTF_API int dtf_conv2_fwd_f32(const float* x, const float* W, const float* bias,
     const int rc = dtf_conv2_f32_init();
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(conv2_fwd_f32_kernel, dim3(B, 2), dim3(256), FWD_LDS, st, x, W, bias, out, (uint8_t*)amax);
+  hipLaunchKernelGGL(conv2_fwd_f32_kernel, dim3(dtf_cdiv(49L * B, FWD_WIN)), dim3(512), FWD_LDS2, st, x, W, bias, out,
+                     (uint8_t*)amax, B);
   DTF_CHECK_LAUNCH();
   return 0;
 }
@@ -484,7 +550,9 @@ DTF_API int dtf_conv_dw_duo_f32(const float* dpool2, const float* pool2, const v
   if (adam) {
     a.adam = *adam;
     a.adam.ticket = nullptr;  // (the step is advanced by the optimizer launch that covers the rest of the arena)
-    a.nadam = 256;
+    // every workgroup of the launch reserves the same 80 KB of LDS, so two fit on a CU: the optimizer workgroups fill the
+    // slots the two filter-gradient roles leave in one resident wave of 512 (more would queue behind them as a tail)
+    a.nadam = 512 - (a.n2 + a.n1) > 64 ? 512 - (a.n2 + a.n1) : 64;
   }
   hipLaunchKernelGGL(conv_dw_duo_f32_kernel, dim3(a.n2 + a.n1 + a.nadam), dim3(256), DUO32_LDS, st, a);
   DTF_CHECK_LAUNCH();

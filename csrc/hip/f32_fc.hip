@@ -20,8 +20,9 @@ inline int eff_splits32(const GemmParams& p) { return dtf_cdiv(p.K, p.kchunk); }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // 112 x 64 tile: the batch of 100 pads to 7 MFMA rows of 16; each of the 4 waves owns 16 output columns x 7 row tiles
-using FwdA = F32RowK<112, 256, 32, true>;
-using FwdB = F32ColK<64, 256, 32, false>;
+// forward: 8 waves, two sets of 4 sharing each slab (KW = 2, see dtf_gemm32_body)
+using FwdA = F32RowK<112, 512, 32, true>;
+using FwdB = F32ColK<64, 512, 32, false>;
 using BdA = F32RowK<112, 256, 32, true>;
 using BdB = F32RowK<64, 256, 32, false>;
 // filter gradients: K = batch, both operands row-contiguous; 128 x 64 tile, 4 waves of 32 x 64
@@ -39,8 +40,17 @@ DTF_API int dtf_fc_fwd_f32(const float* X, const float* W, float* out, int M, in
   const int s = eff_splits32(p);
   p.bias = (s == 1) ? bias : nullptr;
   p.relu = (s == 1) ? relu : 0;
-  return dtf_launch_gemm32<112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store>(p, s, st);
+  return dtf_launch_gemm32<112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store, 2, 2>(p, s, st);
 }
+
+#ifdef DTF_GEMM32_STAMPS
+DTF_API int dtf_fc_fwd_f32_stamps(const float* X, const float* W, float* out, int M, int N, int K, int splits, void* stamps,
+                                  hipStream_t st) {
+  GemmParams p = base_params32(X, W, out, M, N, K, K, N, N, splits, 32);
+  p.aux_out = stamps;
+  return dtf_launch_gemm32<112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store, 2, 2>(p, eff_splits32(p), st);
+}
+#endif
 
 // dX[M][N] (fp32) (+)= dY[M][K] * W[N][K]^T, W fp32 [N][K].  splits > 1 accumulates with atomics into a pre-zeroed dX.
 DTF_API int dtf_fc_bwd_data_f32(const float* dY, const float* W, float* dX, int M, int N, int K, int splits, hipStream_t st) {
@@ -76,20 +86,21 @@ struct GemmTrio32 {
   int nblk_q, q_mt, q_nt;  // data-gradient blocks come first: m-tile fastest, then n-tile, then K split
   int nblk0, mt0, mt1;     // then problem 0 (fc1 dW), then problem 1 (fc2 dW)
 };
-constexpr int TRIO32_LDS = (BdA::LDS + BdB::LDS) > (DwA::LDS + DwB::LDS) ? (BdA::LDS + BdB::LDS) : (DwA::LDS + DwB::LDS);
+constexpr int TRIO32_LDS = dtf_gemm32_lds<112, 64, BdA, BdB>() > dtf_gemm32_lds<128, 64, DwA, DwB>()
+                               ? dtf_gemm32_lds<112, 64, BdA, BdB>() : dtf_gemm32_lds<128, 64, DwA, DwB>();
 
 __global__ __launch_bounds__(256) void fc_bwd_trio_f32_kernel(const GemmTrio32 g) {
   __shared__ __attribute__((aligned(16))) float smem[TRIO32_LDS];
   const int id = blockIdx.x;
   if (id < g.nblk_q) {
     const int mt = id % g.q_mt, r = id / g.q_mt;
-    dtf_gemm32_body<112, 64, 32, 1, 4, BdA, BdB, Ep32Atomic>(g.q, mt * 112, (r % g.q_nt) * 64, r / g.q_nt, smem, smem + BdA::LDS);
+    dtf_gemm32_body<112, 64, 32, 1, 4, BdA, BdB, Ep32Atomic>(g.q, mt * 112, (r % g.q_nt) * 64, r / g.q_nt, smem);
   } else if (id < g.nblk_q + g.nblk0) {
     const int k = id - g.nblk_q;
-    dtf_gemm32_body<128, 64, 20, 4, 1, DwA, DwB, Ep32Store>(g.d0, (k % g.mt0) * 128, (k / g.mt0) * 64, 0, smem, smem + DwA::LDS);
+    dtf_gemm32_body<128, 64, 20, 4, 1, DwA, DwB, Ep32Store>(g.d0, (k % g.mt0) * 128, (k / g.mt0) * 64, 0, smem);
   } else {
     const int k = id - g.nblk_q - g.nblk0;
-    dtf_gemm32_body<128, 16, 20, 4, 1, DwA, DwBn, Ep32Store>(g.d1, (k % g.mt1) * 128, (k / g.mt1) * 16, 0, smem, smem + DwA::LDS);
+    dtf_gemm32_body<128, 16, 20, 4, 1, DwA, DwBn, Ep32Store>(g.d1, (k % g.mt1) * 128, (k / g.mt1) * 16, 0, smem);
   }
 }
 }  // namespace

@@ -111,51 +111,91 @@ struct F32ColK {
   }
 };
 
-// ------------------------------------------------------------------ epilogues (16x16 C/D map)
-#define DTF_EP32_FOREACH(body)                                                      \
-  _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                               \
-    const int row = mbase + tm * 16 + 4 * (lane >> 4) + i;                          \
-    const int col = nbase + tn * 16 + (lane & 15);                                  \
-    const float v = acc[tm][tn][i];                                                 \
-    body                                                                            \
-  }
-
+// ------------------------------------------------------------------ epilogues
+// The accumulator tiles are first assembled as a [BM][BN+4] fp32 image in LDS (see the body) and then written out by the
+// whole workgroup in full rows: 16 lanes cover 256 contiguous bytes.  (Straight from the 16x16 C/D fragments a store
+// instruction covers four 64-byte pieces of four rows; measured on the fc1 forward: 8 000 cycles for 28 such stores per
+// wave, a quarter of the kernel.)
 struct Ep32Store {  // C[z][m][n] = acc (+bias) (relu)
-  template <int TM, int TN>
-  static __device__ __forceinline__ void run(const GemmParams& p, f32x4 (&acc)[TM][TN], int mbase, int nbase, int lane, int z) {
+  template <int BM, int BN>
+  static __device__ __forceinline__ void tile(const GemmParams& p, const float* Cs, int m0, int n0, int z, int tid, int nt) {
     float* C = reinterpret_cast<float*>(p.C) + (long)z * p.slab_stride;
-    DTF_EP32_FOREACH(if (row < p.M && col < p.N) {
-      float o = v + (p.bias ? p.bias[col] : 0.f);
-      if (p.relu) o = fmaxf(o, 0.f);
-      C[(long)row * p.ldc + col] = o;
-    })
+    const bool vec = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    for (int c = tid; c < BM * (BN / 4); c += nt) {
+      const int row = c / (BN / 4), col = (c % (BN / 4)) * 4;
+      if (m0 + row >= p.M || n0 + col >= p.N) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * (BN + 4) + col);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (p.bias && n0 + col + j < p.N) v[j] += p.bias[n0 + col + j];
+        if (p.relu) v[j] = fmaxf(v[j], 0.f);
+      }
+      float* dst = C + (long)(m0 + row) * p.ldc + n0 + col;
+      if (vec && n0 + col + 3 < p.N) {
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n0 + col + j < p.N) dst[j] = v[j];
+      }
+    }
   }
 };
 
 struct Ep32Atomic {  // C[m][n] += acc
-  template <int TM, int TN>
-  static __device__ __forceinline__ void run(const GemmParams& p, f32x4 (&acc)[TM][TN], int mbase, int nbase, int lane, int) {
+  template <int BM, int BN>
+  static __device__ __forceinline__ void tile(const GemmParams& p, const float* Cs, int m0, int n0, int, int tid, int nt) {
     float* C = reinterpret_cast<float*>(p.C);
-    DTF_EP32_FOREACH(if (row < p.M && col < p.N) atomicAdd(&C[(long)row * p.ldc + col], v);)
+    for (int c = tid; c < BM * BN; c += nt) {  // one dword per lane: a wave instruction adds to 256 contiguous bytes
+      const int row = c / BN, col = c % BN;
+      if (m0 + row < p.M && n0 + col < p.N) atomicAdd(&C[(long)(m0 + row) * p.ldc + n0 + col], Cs[row * (BN + 4) + col]);
+    }
   }
 };
 
+// LDS floats a workgroup of the body below needs
+template <int BM, int BN, class AL, class BL>
+constexpr int dtf_gemm32_lds() {
+  return (AL::LDS + BL::LDS) > BM * (BN + 4) ? (AL::LDS + BL::LDS) : BM * (BN + 4);
+}
+
 // ------------------------------------------------------------------ the kernel body
-// As: AL::LDS floats, Bs: BL::LDS floats (16-byte aligned).  Workgroup = WM x WN waves, each (BM/WM) x (BN/WN).
-template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP>
+// smem: dtf_gemm32_lds() floats (16-byte aligned).  Workgroup = KW x WM x WN waves: WM x WN waves tile the BM x BN output,
+// each (BM/WM) x (BN/WN), and KW such sets share every staged slab, set s multiplying its k-groups s, s+KW, ...  With one
+// workgroup per CU (these GEMMs are a single wave of workgroups) KW = 2 puts two waves on every SIMD, so the LDS-read
+// latencies, address arithmetic and staging of one run in the shadow of the other's MFMAs (one wave per SIMD: the
+// multiply phase of a slab took 2 850 cycles for 1 792 cycles of MFMA, phase stamps of scripts/dbg/fc_fwd_stamps.py).
+// The sets' partial sums are added in a fixed order in the LDS output image.
+// PF register sets of staged slabs are in flight ahead of the one being multiplied.
+// -DDTF_GEMM32_STAMPS (diagnostic builds only, scripts/dbg): thread 0 of every workgroup records the shader clock at the
+// phase boundaries of its slab loop into p.aux_out[workgroup][64]
+#ifdef DTF_GEMM32_STAMPS
+#define DTF_STAMP(i) do { const int _i = (i); if (threadIdx.x == 0 && _i < 64) stamps[_i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DTF_STAMP(i) do { } while (0)
+#endif
+template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int PF = 2, int KW = 1>
 __device__ __forceinline__ void dtf_gemm32_body(const GemmParams& p, const int m0, const int n0, const int z,
-                                                float* __restrict__ As, float* __restrict__ Bs) {
-  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+                                                float* __restrict__ smem) {
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16, NT = 64 * WM * WN * KW;
   constexpr bool PLAIN = AL::KMAJOR && BL::KMAJOR;
   static_assert(TM >= 1 && TN >= 1 && BM % (WM * 16) == 0 && BN % (WN * 16) == 0, "tile");
   static_assert(PLAIN ? (BK % 4 == 0) : (BK % 16 == 0), "slab depth");
   static_assert(TM * TN >= 2, "the 16x16x4 f32 MFMA needs two independent accumulators to issue back to back");
+  float* __restrict__ As = smem;
+  float* __restrict__ Bs = smem + AL::LDS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  const int ks = wave / (WM * WN), wmn = wave % (WM * WN);
+  const int wm = wmn / WN, wn = wmn % WN;
   const int r = lane & 15, q = lane >> 4;
   const int kbeg = z * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
+#ifdef DTF_GEMM32_STAMPS
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(p.aux_out) +
+                               ((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 64;
+  int si = 0;
+#endif
+  DTF_STAMP(si++);
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -165,65 +205,100 @@ __device__ __forceinline__ void dtf_gemm32_body(const GemmParams& p, const int m
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[a][b][i] = 0.f;
 
-  AL al;
-  BL bl;
-  al.init(p, m0, tid);
-  bl.init(p, n0, tid);
-  al.load(kbeg, kend, tid);
-  bl.load(kbeg, kend, tid);
-  const int arow = wm * (BM / WM) + r, brow = wn * (BN / WN) + r;
-  for (int k = kbeg; k < kend; k += BK) {
-    __syncthreads();
-    al.store(As, tid);
-    bl.store(Bs, tid);
-    __syncthreads();
-    if (k + BK < kend) {
-      al.load(k + BK, kend, tid);
-      bl.load(k + BK, kend, tid);
+  AL al[PF];
+  BL bl[PF];
+#pragma unroll
+  for (int s = 0; s < PF; ++s) {
+    al[s].init(p, m0, tid);
+    bl[s].init(p, n0, tid);
+    if (s == 0 || kbeg + s * BK < kend) {
+      al[s].load(kbeg + s * BK, kend, tid);
+      bl[s].load(kbeg + s * BK, kend, tid);
     }
-    if constexpr (PLAIN) {
+  }
+  const int arow = wm * (BM / WM) + r, brow = wn * (BN / WN) + r;
+  for (int k = kbeg; k < kend; k += PF * BK) {
 #pragma unroll
-      for (int s = 0; s < BK / 4; ++s) {
-        float af[TM], bf[TN];
-#pragma unroll
-        for (int a = 0; a < TM; ++a) af[a] = As[(4 * s + q) * AL::PITCH + arow + a * 16];
-#pragma unroll
-        for (int b = 0; b < TN; ++b) bf[b] = Bs[(4 * s + q) * BL::PITCH + brow + b * 16];
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b) acc[a][b] = mfma16f32(af[a], bf[b], acc[a][b]);
+    for (int s = 0; s < PF; ++s) {
+      if (s > 0 && k + s * BK >= kend) break;  // (workgroup-uniform)
+      __syncthreads();
+      DTF_STAMP(si++);
+      al[s].store(As, tid);
+      bl[s].store(Bs, tid);
+      __syncthreads();
+      DTF_STAMP(si++);
+      if (k + (s + PF) * BK < kend) {
+        al[s].load(k + (s + PF) * BK, kend, tid);
+        bl[s].load(k + (s + PF) * BK, kend, tid);
       }
-    } else {
+      if constexpr (PLAIN) {
 #pragma unroll
-      for (int g = 0; g < BK / 16; ++g) {
-        f32x4 af[TM], bf[TN];
+        for (int t0 = 0; t0 < BK / 4; t0 += KW) {
+          const int t = t0 + ks;
+          if (KW > 1 && t >= BK / 4) break;
+          float af[TM], bf[TN];
 #pragma unroll
-        for (int a = 0; a < TM; ++a) af[a] = AL::frag(As, arow + a * 16, q, g);
+          for (int a = 0; a < TM; ++a) af[a] = As[(4 * t + q) * AL::PITCH + arow + a * 16];
 #pragma unroll
-        for (int b = 0; b < TN; ++b) bf[b] = BL::frag(Bs, brow + b * 16, q, g);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
+          for (int b = 0; b < TN; ++b) bf[b] = Bs[(4 * t + q) * BL::PITCH + brow + b * 16];
 #pragma unroll
           for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int b = 0; b < TN; ++b) acc[a][b] = mfma16f32(af[a][j], bf[b][j], acc[a][b]);
+            for (int b = 0; b < TN; ++b) acc[a][b] = mfma16f32(af[a], bf[b], acc[a][b]);
+        }
+      } else {
+#pragma unroll
+        for (int g0 = 0; g0 < BK / 16; g0 += KW) {
+          const int g = g0 + ks;
+          if (KW > 1 && g >= BK / 16) break;
+          f32x4 af[TM], bf[TN];
+#pragma unroll
+          for (int a = 0; a < TM; ++a) af[a] = AL::frag(As, arow + a * 16, q, g);
+#pragma unroll
+          for (int b = 0; b < TN; ++b) bf[b] = BL::frag(Bs, brow + b * 16, q, g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+              for (int b = 0; b < TN; ++b) acc[a][b] = mfma16f32(af[a][j], bf[b][j], acc[a][b]);
+        }
       }
     }
   }
-  EP::template run<TM, TN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, z);
+  DTF_STAMP(si++);
+  // ---- assemble the output image in LDS (the staged slabs are dead): set KW-1 stores, the others add in descending order
+  float* Cs = smem;
+#pragma unroll
+  for (int s = KW - 1; s >= 0; --s) {
+    __syncthreads();
+    if (ks == s) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float* c = Cs + (wm * (BM / WM) + a * 16 + 4 * q + i) * (BN + 4) + wn * (BN / WN) + b * 16 + r;
+            *c = (s == KW - 1) ? acc[a][b][i] : *c + acc[a][b][i];
+          }
+    }
+  }
+  __syncthreads();
+  EP::template tile<BM, BN>(p, Cs, m0, n0, z, tid, NT);
+  DTF_STAMP(si++);
 }
 
-template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP>
-__global__ __launch_bounds__(64 * WM * WN) void dtf_gemm32_kernel(const GemmParams p) {
-  __shared__ __attribute__((aligned(16))) float smem[AL::LDS + BL::LDS];
-  dtf_gemm32_body<BM, BN, BK, WM, WN, AL, BL, EP>(p, blockIdx.x * BM, blockIdx.y * BN, blockIdx.z, smem, smem + AL::LDS);
+template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int PF = 2, int KW = 1>
+__global__ __launch_bounds__(64 * WM * WN * KW) void dtf_gemm32_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[dtf_gemm32_lds<BM, BN, AL, BL>()];
+  dtf_gemm32_body<BM, BN, BK, WM, WN, AL, BL, EP, PF, KW>(p, blockIdx.x * BM, blockIdx.y * BN, blockIdx.z, smem);
 }
 
-template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP>
+template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int PF = 2, int KW = 1>
 static inline int dtf_launch_gemm32(const GemmParams& p, int splits, hipStream_t st) {
   dim3 grid(dtf_cdiv(p.M, BM), dtf_cdiv(p.N, BN), splits);
-  hipLaunchKernelGGL((dtf_gemm32_kernel<BM, BN, BK, WM, WN, AL, BL, EP>), grid, dim3(64 * WM * WN), 0, st, p);
+  hipLaunchKernelGGL((dtf_gemm32_kernel<BM, BN, BK, WM, WN, AL, BL, EP, PF, KW>), grid, dim3(64 * WM * WN * KW), 0, st, p);
   DTF_CHECK_LAUNCH();
   return 0;
 }
