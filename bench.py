@@ -241,7 +241,11 @@ def main():
             "extra_" + (extra["dtype"] if extra else "other_dtype"): extra,
             "replicas_in_sync": in_sync,
             "ipc_nranks": trainer.ipc.world if trainer.ipc is not None else 0,
-            "rccl_nranks": world if (trainer._multi and dist.is_initialized() and dist.get_backend() == "nccl") else 0,
+            "rccl_nranks": (trainer.rccl.world if trainer.rccl is not None else
+                            (world if (trainer._multi and dist.is_initialized() and dist.get_backend() == "nccl") else 0)),
+            "rccl_in_step_graph": bool(trainer._rccl_graph) if trainer._multi else None,
+            "skipped_steps": eng.skipped_steps() if hasattr(eng, "skipped_steps") else None,
+            "dp_startup_log": getattr(trainer, "startup_log", None),
             "dp_schedule_us_at_startup": getattr(trainer, "schedule_us", None),
             "dp_startup_seconds": getattr(trainer, "startup_seconds", None),
             "ipc_wait_timeouts": timeouts,

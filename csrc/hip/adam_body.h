@@ -8,17 +8,25 @@
 #include "dtf_structs.h"
 
 // The last workgroup to finish advances the step counter (arrival ticket), so a captured graph replays unchanged.
+// A skipped step (p.skip raised, see dtf_structs.h) leaves the counter where it is -- the same batch is retried -- clears
+// that step's metric slot again, counts the skip and lowers the flag.
 __device__ __forceinline__ void finish_step(const OptimParams& p, int t) {
   if (!p.ticket) return;  // a partial update of the arena: the launch covering the rest advances the step
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned int prev = atomicAdd(p.ticket, 1u);
-    if (prev == gridDim.x - 1) {  // every workgroup has read *step and finished its updates
+    if (prev == gridDim.x - 1) {  // every workgroup has read *step (and the skip flag) and finished its updates
       *p.ticket = 0u;
-      *p.step = t;
+      const bool skipped = p.skip && __hip_atomic_load(p.skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+      const int next = skipped ? t - 1 : t;
+      *p.step = next;
+      if (skipped) {
+        p.skip[1] += 1u;
+        __hip_atomic_store(p.skip, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       if (p.metrics_ring && p.ring > 0) {
-        p.metrics_ring[2 * (t % p.ring)] = 0.f;
-        p.metrics_ring[2 * (t % p.ring) + 1] = 0.f;
+        p.metrics_ring[2 * (next % p.ring)] = 0.f;
+        p.metrics_ring[2 * (next % p.ring) + 1] = 0.f;
       }
     }
   }
@@ -69,6 +77,18 @@ __device__ __forceinline__ int adam_tf_body(const OptimParams& p, const int bloc
       w[u] = reinterpret_cast<const float4*>(p.P)[j];
     }
   };
+  // (agent-scope load: in the fused exchange + optimizer launch the flag is raised by another workgroup of this launch)
+  const bool skip = p.skip && __hip_atomic_load(p.skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+  if (skip) {  // do not apply: only discard the accumulated gradient segments
+    const int t = *p.step + 1;
+    for (; base < n4; base += stride)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long i = base + (long)u * nthreads;
+        if (i < n4 && i * 4 >= p.zero_from) reinterpret_cast<float4*>(p.G)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    return t;
+  }
   if (base < n4) load(base);
   // the step counter and the bias correction are needed for the update only: fetched and computed while the first
   // batch of loads is in flight

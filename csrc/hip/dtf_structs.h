@@ -50,4 +50,7 @@ struct OptimParams {
                          // the re-zeroing of [zero_from, n) still applies to G
   const float* Gsrcs[8];  // fused one-shot all-reduce (dtf_ipc_adam_oneshot): gradient = sum of the first nsrc of these
   int nsrc;
+  unsigned* skip;         // optional device words [skip flag, skipped-step count]: flag != 0 = this step's gradient exchange
+                          // had an expired wait somewhere (ipc_allreduce.hip): leave P/M/V and the step counter alone, only
+                          // discard the accumulated gradients; the launch that owns the ticket clears the flag
 };

@@ -47,6 +47,8 @@ struct MnistEngine {
   // reference precision (demo1/train.py computes in float32): pool1 / pool2 / h_drop / dh are fp32, dz is fp32 [B][16], and
   // every GEMM-shaped op runs on the exact-fp32 MFMA (f32_gemm.h, f32_conv2.hip); 0 = bf16 operands, fp32 accumulate
   int f32;
+  // device words [skip flag, skipped-step count] shared with the IPC gradient exchange (OptimParams::skip); may be null
+  unsigned* skip;
 };
 
 #define DTF_TRY(x)            \
@@ -194,6 +196,7 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
       fc1.lr = e->lr; fc1.beta1 = e->beta1; fc1.beta2 = e->beta2; fc1.eps = e->eps;
       fc1.grad_scale = 1.0f / (float)(e->world > 0 ? e->world : 1);
       fc1.step = e->step;
+      fc1.skip = e->skip;
     }
     if (e->f32)
       DTF_TRY(dtf_conv_dw_duo_f32(e->dpool2, (const float*)e->pool2, e->amax2, (const float*)e->pool1, e->G + e->off_Wc2, B,
@@ -221,6 +224,7 @@ static OptimParams optim_range(const MnistEngine* e, int which) {
   op.metrics_ring = e->metrics_ring;
   op.ring = e->ring;
   op.Gsrc = e->G_src ? e->G_src + lo : nullptr;
+  op.skip = e->skip;
   return op;
 }
 static int apply_range(const MnistEngine* e, int which, hipStream_t st) {

@@ -40,12 +40,16 @@ struct IpcComm {
   long n_max;                  // capacity in floats (multiple of 4)
   unsigned char* base[MAX_RANKS];  // every rank's shared allocation as mapped into this process
   unsigned* epoch;             // device word (ordinary memory): epoch of the all-reduce in flight
-  unsigned* error;             // device word: number of expired waits (== epoch + 1; epoch + 2 is an arrival ticket)
+  unsigned* error;             // device word: number of expired waits (== epoch + 1; epoch + 2 is an arrival ticket,
+                               // epoch + 3 the error total of all ranks this rank has acted on, epoch + 4 a decision tag)
   unsigned long long timeout_ticks;  // wall_clock64 ticks (100 MHz)
+  unsigned* skip;              // optional device words shared with the optimizer (OptimParams::skip): [0] != 0 = "a wait
+                               // of this step's exchange expired somewhere: do not apply this step", [1] = steps skipped
 };
 
 __device__ __forceinline__ unsigned* ready_flags(unsigned char* b) { return reinterpret_cast<unsigned*>(b); }
 __device__ __forceinline__ unsigned* done_flags(unsigned char* b) { return reinterpret_cast<unsigned*>(b + 64); }
+__device__ __forceinline__ unsigned* err_pub(unsigned char* b) { return reinterpret_cast<unsigned*>(b + 128); }
 __device__ __forceinline__ float* stage_of(unsigned char* b) { return reinterpret_cast<float*>(b + HDR_BYTES); }
 __device__ __forceinline__ float* result_of(unsigned char* b, long n_max) { return reinterpret_cast<float*>(b + HDR_BYTES) + n_max; }
 
@@ -60,6 +64,42 @@ __device__ __forceinline__ bool wait_flag(const unsigned* flag, unsigned want, u
     __builtin_amdgcn_s_sleep(8);
   }
   return true;
+}
+
+// ---- expired waits: never apply a partial sum.
+// A wait that expires lets the kernel proceed (the grid must drain), so the data it guards may be incomplete.  Every rank
+// keeps a PUBLIC count of its expired waits in its shared header; at the end of an exchange one thread per rank adds up
+// all ranks' counts and, if the total moved since it last looked, raises the skip word the optimizer launch honours:
+// the step is not applied (parameters, moments and step counter stay; accumulated gradients are discarded).  A rank
+// publishes its count at the end of the phase in which the wait expired, i.e. before it signals the next phase, so a
+// peer that gets through the later phases on that rank's (incomplete) data sees the count.  The one hole — a wait that
+// expires in the LAST phase is known to that rank only — leaves the others with complete sums: nobody applies a partial
+// one, the replicas may differ by one whole update, and DataParallelTrainer.ensure_healthy() re-synchronises them.
+// Call from every thread of the block after the phase's waits; `recorder`: this block accounts for the rank.
+__device__ __forceinline__ void settle_waits(const IpcComm& c, const bool timed_out, const bool recorder, const bool decide) {
+  __shared__ unsigned nerr;
+  if (threadIdx.x == 0) nerr = 0u;
+  __syncthreads();
+  if (timed_out) atomicAdd(&nerr, 1u);
+  __syncthreads();
+  if (recorder && threadIdx.x == 0) {
+    unsigned mine = __hip_atomic_load(c.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (nerr) {
+      mine += nerr;
+      __hip_atomic_store(c.error, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(err_pub(c.base[c.rank]), mine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (decide && c.skip) {
+      unsigned sum = mine;
+      for (int p = 0; p < c.world; ++p)
+        if (p != c.rank) sum += __hip_atomic_load(err_pub(c.base[p]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      unsigned* seen = c.epoch + 3;
+      if (sum != *seen) {
+        *seen = sum;
+        __hip_atomic_store(c.skip, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
 }
 
 // Grid-strided copy with COPY_U independent 16-byte loads in flight per lane: at <= 128 workgroups a one-load-per-
@@ -87,23 +127,18 @@ __global__ __launch_bounds__(256) void ipc_publish_kernel(const IpcComm c, const
 }
 
 __global__ __launch_bounds__(256) void ipc_reduce_kernel(const IpcComm c, long n) {
-  __shared__ int ok_all;
   const unsigned e = *c.epoch;
-  if (threadIdx.x == 0) ok_all = 1;
-  __syncthreads();
+  bool expired = false;
   if (threadIdx.x < c.world) {
     const int p = threadIdx.x;
     // workgroup 0 signals (the publish kernel has completed: stream order); no workgroup depends on another one of
     // this grid, so the grid needs no co-residency
     if (blockIdx.x == 0)
       __hip_atomic_store(&ready_flags(c.base[p])[c.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (!wait_flag(&ready_flags(c.base[c.rank])[p], e, c.timeout_ticks)) {
-      ok_all = 0;
-      if (blockIdx.x == 0) atomicAdd(c.error, 1u);
-    }
+    expired = !wait_flag(&ready_flags(c.base[c.rank])[p], e, c.timeout_ticks);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: the peers' stage buffers are read below
   }
-  __syncthreads();
+  settle_waits(c, expired, blockIdx.x == 0, false);
   const long n4 = n >> 2;
   const long chunk = (n4 + c.world - 1) / c.world;
   const long lo = (long)c.rank * chunk, hi = lo + chunk < n4 ? lo + chunk : n4;
@@ -135,15 +170,16 @@ __global__ __launch_bounds__(256) void ipc_reduce_kernel(const IpcComm c, long n
 
 __global__ __launch_bounds__(256) void ipc_collect_kernel(const IpcComm c, float* __restrict__ dst, long n) {
   const unsigned e = *c.epoch;
+  bool expired = false;
   if (threadIdx.x < c.world) {
     const int p = threadIdx.x;
     // K2 has completed (stream order), so this rank's slice is written everywhere: publish that, then wait for all
     if (blockIdx.x == 0)
       __hip_atomic_store(&done_flags(c.base[p])[c.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (!wait_flag(&done_flags(c.base[c.rank])[p], e, c.timeout_ticks) && blockIdx.x == 0) atomicAdd(c.error, 1u);
+    expired = !wait_flag(&done_flags(c.base[c.rank])[p], e, c.timeout_ticks);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   }
-  __syncthreads();
+  settle_waits(c, expired, blockIdx.x == 0, true);
   copy_f4(reinterpret_cast<f32x4*>(dst), reinterpret_cast<const f32x4*>(result_of(c.base[c.rank], c.n_max)), n >> 2);
 }
 
@@ -160,12 +196,14 @@ __global__ __launch_bounds__(256) void ipc_publish_rest_kernel(const IpcComm c, 
 // peer says the same; the kernels that follow on the stream may read result[] and overwrite stage[]
 __global__ __launch_bounds__(64) void ipc_done_kernel(const IpcComm c) {
   const unsigned e = *c.epoch;
+  bool expired = false;
   if (threadIdx.x < c.world) {
     const int p = threadIdx.x;
     __hip_atomic_store(&done_flags(c.base[p])[c.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (!wait_flag(&done_flags(c.base[c.rank])[p], e, c.timeout_ticks)) atomicAdd(c.error, 1u);
+    expired = !wait_flag(&done_flags(c.base[c.rank])[p], e, c.timeout_ticks);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   }
+  settle_waits(c, expired, true, true);
 }
 
 // ---- activation exchange ("gather" schedule).  For a wide dense layer at small batch the operands of the filter-
@@ -181,12 +219,14 @@ __global__ __launch_bounds__(64) void ipc_done_kernel(const IpcComm c) {
 __global__ __launch_bounds__(64) void ipc_sync_kernel(const IpcComm c) {
   const unsigned e = *c.epoch + 1u;  // (one wave: every lane reads before lane 0 writes)
   if (threadIdx.x == 0) *c.epoch = e;
+  bool expired = false;
   if (threadIdx.x < c.world) {
     const int p = threadIdx.x;
     __hip_atomic_store(&ready_flags(c.base[p])[c.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (!wait_flag(&ready_flags(c.base[c.rank])[p], e, c.timeout_ticks)) atomicAdd(c.error, 1u);
+    expired = !wait_flag(&ready_flags(c.base[c.rank])[p], e, c.timeout_ticks);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   }
+  settle_waits(c, expired, true, true);
 }
 
 // After the barrier: pull every peer's operands (stage[0, n4) in 16-byte units) into local memory, dst[p][n4], once.  The
@@ -251,9 +291,21 @@ __global__ __launch_bounds__(256) void ipc_sync_gather_kernel(const IpcComm c, f
   }
   if (threadIdx.x == 0) {
     const unsigned prev = atomicAdd(ticket, 1u);
-    if (prev == gridDim.x - 1) {
+    if (prev == gridDim.x - 1) {  // every workgroup's waits are over: publish this rank's error count, look at the peers'
       *ticket = 0u;
       *c.epoch = e;
+      const unsigned mine = __hip_atomic_load(c.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(err_pub(c.base[c.rank]), mine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (c.skip) {
+        unsigned sum = mine;
+        for (int q = 0; q < c.world; ++q)
+          if (q != c.rank) sum += __hip_atomic_load(err_pub(c.base[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        unsigned* seen = c.epoch + 3;
+        if (sum != *seen) {
+          *seen = sum;
+          __hip_atomic_store(c.skip, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
     }
   }
 }
@@ -268,14 +320,15 @@ __global__ __launch_bounds__(256) void ipc_copy_from_kernel(const IpcComm c, int
 // at N x the read volume.  No "done" handshake: see dtf_ipc_allreduce_oneshot for the contract.
 __global__ __launch_bounds__(256) void ipc_reduce_all_kernel(const IpcComm c, float* __restrict__ dst, long n) {
   const unsigned e = *c.epoch;
+  bool expired = false;
   if (threadIdx.x < c.world) {
     const int p = threadIdx.x;
     if (blockIdx.x == 0)
       __hip_atomic_store(&ready_flags(c.base[p])[c.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (!wait_flag(&ready_flags(c.base[c.rank])[p], e, c.timeout_ticks) && blockIdx.x == 0) atomicAdd(c.error, 1u);
+    expired = !wait_flag(&ready_flags(c.base[c.rank])[p], e, c.timeout_ticks);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   }
-  __syncthreads();
+  settle_waits(c, expired, blockIdx.x == 0, true);
   const long n4 = n >> 2;
   f32x4* d4 = reinterpret_cast<f32x4*>(dst);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -296,14 +349,30 @@ __global__ __launch_bounds__(256) void ipc_reduce_all_kernel(const IpcComm c, fl
 // nor its result buffer exist.  Same contract as ipc_reduce_all_kernel (the publish kernel precedes it in the stream).
 __global__ __launch_bounds__(256) void ipc_reduce_adam_kernel(const IpcComm c, const OptimParams p) {
   const unsigned e = *c.epoch;
+  bool expired = false;
   if (threadIdx.x < c.world) {
     const int q = threadIdx.x;
     if (blockIdx.x == 0)
       __hip_atomic_store(&ready_flags(c.base[q])[c.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (!wait_flag(&ready_flags(c.base[c.rank])[q], e, c.timeout_ticks) && blockIdx.x == 0) atomicAdd(c.error, 1u);
+    expired = !wait_flag(&ready_flags(c.base[c.rank])[q], e, c.timeout_ticks);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   }
-  __syncthreads();
+  settle_waits(c, expired, blockIdx.x == 0, true);
+  // The whole launch must take ONE apply-or-skip decision: workgroup 0 (dispatched first; the grid is co-resident) takes it
+  // above and tags it with the epoch, the others wait for the tag (bounded like every wait here).
+  if (c.skip) {
+    unsigned* tag = c.epoch + 4;
+    if (blockIdx.x == 0) {
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(tag, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (threadIdx.x == 0) {
+        if (!wait_flag(tag, e, c.timeout_ticks)) __hip_atomic_store(c.skip, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+    }
+  }
   const int t = adam_tf_body<true>(p, blockIdx.x, gridDim.x, 256);
   finish_step(p, t);
 }
@@ -369,7 +438,7 @@ DTF_API int dtf_ipc_sync_gather(const void* comm, void* dst, long bytes, int blo
   const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
   if (!dst || bytes <= 0 || bytes % 16 || bytes / 4 > c.n_max || c.world < 1 || c.world > MAX_RANKS || c.rank < 0 ||
       c.rank >= c.world || c.error != c.epoch + 1)
-    return -22;
+    return -22;  // (device words: [epoch, error, ticket, seen, tag, spare], as IpcAllReduce allocates them)
   if (blocks_per_peer < 1) blocks_per_peer = 16;
   if (blocks_per_peer > 64) blocks_per_peer = 64;
   const int grid = c.world > 1 ? (c.world - 1) * blocks_per_peer : 1;

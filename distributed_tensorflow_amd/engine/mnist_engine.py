@@ -99,6 +99,9 @@ class NativeMnistEngine(_EngineBase):
         self.V = torch.zeros(self.n_arena, **f32)
         self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        # [skip flag, skipped-step count]: raised by the IPC gradient exchange when one of its waits expired, honoured and
+        # cleared by the optimizer launch (a step with an incomplete gradient sum is never applied)
+        self.skip_t = torch.zeros(2, dtype=torch.int32, device=dev)
         self.metrics_ring = torch.zeros(self.RING * 2, **f32)
         self.eval_metrics = torch.zeros(2, **f32)
         mb = self.maxB
@@ -128,6 +131,7 @@ class NativeMnistEngine(_EngineBase):
         s.lr, s.beta1, s.beta2, s.eps, s.keep_prob = lr, beta1, beta2, eps, keep_prob
         s.seed = self.seed
         s.f32 = int(is_f32)
+        s.skip = self.skip_t.data_ptr()
         if dataset is not None:
             s.images, s.labels, s.perm = dataset.images.data_ptr(), dataset.labels.data_ptr(), dataset.perm.data_ptr()
         s.P, s.G, s.M, s.V = (t.data_ptr() for t in (self.P, self.G, self.M, self.V))
@@ -206,6 +210,18 @@ class NativeMnistEngine(_EngineBase):
         self._steps_done = 0
         self.init_params(seed)
         self._drop_graph()
+
+    def skipped_steps(self) -> int:
+        """Optimizer launches that did not apply their step because a wait of the gradient exchange had expired
+        (synchronises).  The device step counter does not advance on such a step; ``resync_step_counter`` realigns the
+        host mirror."""
+        self.stream.synchronize()
+        return int(self.skip_t[1].item())
+
+    def resync_step_counter(self) -> int:
+        self.stream.synchronize()
+        self._steps_done = int(self.step_t.item())
+        return self._steps_done
 
     def set_lr(self, lr: float) -> None:
         self.cfg.lr = lr

@@ -48,7 +48,7 @@ class OptimParams(C.Structure):
         ("n", c_long), ("zero_from", c_long),
         ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("grad_scale", c_float),
         ("step", c_void_p), ("ticket", c_void_p), ("metrics_ring", c_void_p), ("ring", c_int),
-        ("Gsrc", c_void_p), ("Gsrcs", c_void_p * 8), ("nsrc", c_int),
+        ("Gsrc", c_void_p), ("Gsrcs", c_void_p * 8), ("nsrc", c_int), ("skip", c_void_p),
     ]
 
 
@@ -71,7 +71,7 @@ class MnistEngineStruct(C.Structure):  # csrc/hip/engine.hip: struct MnistEngine
         ("gather_A", c_void_p * 8), ("gather_B", c_void_p * 8), ("gather_comm", c_void_p), ("gather_n", c_int), ("gather_rank", c_int),
         ("wc2f", c_void_p), ("wc2b", c_void_p),
         ("gather_local", c_void_p), ("gather_bytes", c_long),
-        ("f32", c_int),
+        ("f32", c_int), ("skip", c_void_p),
     ]
 
 

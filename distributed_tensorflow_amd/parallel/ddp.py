@@ -158,6 +158,37 @@ class _IpcGradHook:
         self.ipc.all_reduce(self.b, stream=stream.cuda_stream)
 
 
+class _RcclGradHook:
+    """Gradient all-reduce of the native MNIST step over the native RCCL communicator (``parallel/rccl_comm.py``): the
+    ncclAllReduce calls are enqueued on the engine's stream(s) inside the step, so they are captured into the step's
+    hipGraph and the whole data-parallel step is one graph launch.  With ``overlap`` the fc bucket (12.9 MB, final after
+    step part 1) is reduced on a forked stream while the conv backward runs on the main one, as in ``_IpcGradHook``."""
+
+    apply_comm = None
+
+    def __init__(self, rccl, bucket_a: torch.Tensor, bucket_b: torch.Tensor, whole: torch.Tensor, overlap: bool):
+        self.rccl, self.a, self.b, self.whole, self.overlap = rccl, bucket_a, bucket_b, whole, overlap
+        if overlap:
+            self.side = torch.cuda.Stream(device=whole.device)
+            self.ev_fork = torch.cuda.Event()
+            self.ev_join = torch.cuda.Event()
+
+    def after_part1(self, stream) -> None:
+        if not self.overlap:
+            return
+        self.ev_fork.record(stream)
+        self.side.wait_event(self.ev_fork)
+        self.rccl.all_reduce(self.a, stream=self.side)
+        self.ev_join.record(self.side)
+
+    def after_part2(self, stream) -> None:
+        if not self.overlap:
+            self.rccl.all_reduce(self.whole, stream=stream)
+            return
+        stream.wait_event(self.ev_join)
+        self.rccl.all_reduce(self.b, stream=stream)
+
+
 class DataParallelTrainer:
     """Drives an engine (native or eager) under synchronous or emulated-async data parallelism."""
 
@@ -182,6 +213,7 @@ class DataParallelTrainer:
         # devices) is staged through host memory explicitly; RCCL reduces the arena slices in place.
         self._stage_host = (dist.is_initialized() and self._native and dist.get_backend(group) == "gloo")
         self._multi = self.world > 1 or self._force
+        self._pg_stream = None
         if self._multi:
             self.broadcast_state()
         # gradient transport: "ipc" = direct two-shot all-reduce over IPC-mapped peer memory (all xGMI links at once, and
@@ -190,6 +222,9 @@ class DataParallelTrainer:
         # native and the start-up self-test against the process group's own all-reduce passes, else rccl.
         self.comm = "rccl"
         self.ipc = None
+        self.rccl = None           # native RCCL communicator (collectives captured into the step graph)
+        self._rccl_graph = False   # the current schedule is that one
+        self._pg_stream = None
         self.transport_us = None
         if comm not in ("auto", "ipc", "rccl"):
             raise ValueError("comm must be auto, ipc or rccl")
@@ -197,10 +232,57 @@ class DataParallelTrainer:
         self.schedule = None
         self.ipc_act = None
         self._shared_gpu = False
+        import time
+        t_start = self._t_start = time.perf_counter()
+        self.startup_log = []
+        if self._multi and self._native and sync and not self._stage_host and comm in ("auto", "rccl"):
+            self._try_rccl()
         if self._multi and self._native and sync and comm in ("auto", "ipc"):
             self._try_ipc(required=(comm == "ipc"))
             if self.comm == "ipc":
                 self._tune_schedule(allow_rccl=(comm == "auto"))
+        if self._multi and self._native and sync and self.comm != "ipc" and self.rccl is not None:
+            self._ipc_hook, self._fc1_end = None, 0
+            self._use_schedule("rccl")
+        self.startup_seconds = round(time.perf_counter() - t_start, 3) if self._multi else 0.0
+        if self._multi and self.rank == 0:
+            print("data-parallel start-up: %.2f s; transport %s, schedule %s%s" % (
+                self.startup_seconds, self.comm, self.schedule,
+                "".join("\n  " + l for l in self.startup_log)), flush=True)
+
+    def _note(self, msg: str) -> None:
+        self.startup_log.append(msg)
+
+    def _try_rccl(self) -> None:
+        """Create the native RCCL communicator (collective).  Every rank reports whether its part worked; if any failed
+        all of them drop it and the process group's own collectives are used instead."""
+        import time
+        t0 = time.perf_counter()
+        from .rccl_comm import RcclCommunicator
+        ok, err, comm = 1, "", None
+        if dist.get_backend(self.group) != "nccl":
+            return
+        try:
+            comm = RcclCommunicator.create(self.rank, self.world, self.engine.device,
+                                           key="rccl/%d" % int(os.environ.get("DTF_RCCL_GENERATION", "0")))
+            with self._ctx():
+                x = torch.full((1024,), float(self.rank + 1), device=self.engine.device)
+                comm.all_reduce(x)
+            self.engine.stream.synchronize()
+            if float(x[0].item()) != self.world * (self.world + 1) / 2.0:
+                ok, err = 0, "native all-reduce returned %r" % float(x[0].item())
+        except Exception as e:  # noqa: BLE001
+            ok, err = 0, repr(e)
+        with self._ctx():
+            flag = torch.tensor([ok], dtype=torch.int32, device=self.engine.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()):
+            self.rccl = comm
+            self._note("native RCCL communicator: %d ranks, library %s, %.2f s" % (self.world, comm.version, time.perf_counter() - t0))
+        else:
+            if comm is not None:
+                comm.close(abort=True)
+            self._note("native RCCL communicator not used (%s)" % (err or "a peer failed"))
 
     def _time_transports(self, iters: int = 8, grids=(32, 64, 128)):
         """(ipc, process-group) microseconds per all-reduce of the gradient arena, max over ranks.  The IPC kernels'
@@ -244,7 +326,8 @@ class DataParallelTrainer:
             # (IpcAllReduce and self_test keep every rank on the same sequence of collectives even when a local HIP
             # call fails, and self_test's verdict is already agreed across ranks)
             from .ipc_comm import IpcAllReduce
-            self.ipc = IpcAllReduce(self.engine.G.numel(), self.engine.device, group=self.group)
+            self.ipc = IpcAllReduce(self.engine.G.numel(), self.engine.device, group=self.group,
+                                    skip_ptr=self.engine.skip_t.data_ptr() if hasattr(self.engine, "skip_t") else 0)
             ok = self.ipc.self_test()
             err = self.ipc.failure or "self-test against the process group's all-reduce failed on some rank"
             if ok:
@@ -269,7 +352,7 @@ class DataParallelTrainer:
             if self.rank == 0:
                 print("IPC all-reduce not used (%s); gradients go through %s" % (err, dist.get_backend(self.group)), flush=True)
 
-    def _tune_schedule(self, allow_rccl: bool, steps: int = 160) -> None:
+    def _tune_schedule(self, allow_rccl: bool, steps: int = 64) -> None:
         """Pick the step schedule by running it.  Whether forking the fc-bucket all-reduce onto a second queue beats
         reducing the whole arena in-stream depends on what a cross-queue dependency costs against what the xGMI
         transfer takes at this world size (5-10 us per edge was measured on one GPU; the transfer time cannot be
@@ -290,7 +373,8 @@ class DataParallelTrainer:
         gather_ok = zc_ok and hasattr(e, "gather_supported") and e.gather_supported() and forced in ("auto", "ipc-gather")
         if gather_ok and self.ipc_act is None:
             from .ipc_comm import IpcAllReduce
-            self.ipc_act = IpcAllReduce(sum(e.gather_bytes()) // 4, e.device, group=self.group)
+            self.ipc_act = IpcAllReduce(sum(e.gather_bytes()) // 4, e.device, group=self.group,
+                                        skip_ptr=e.skip_t.data_ptr() if hasattr(e, "skip_t") else 0)
             gather_ok = self.ipc_act.self_test()
             if gather_ok:
                 self.ipc_act.set_timeout(float(os.environ.get("DTF_IPC_TIMEOUT_S", "30")))
@@ -337,12 +421,31 @@ class DataParallelTrainer:
                     for t, s0 in zip((e.P, e.M, e.V, e.step_t), snap):
                         t.copy_(s0)
                     e.metrics_ring.zero_()  # (the per-step loss/accuracy slots the trial steps accumulated into)
+                    if hasattr(e, "skip_t"):
+                        e.skip_t.zero_()
                 e.stream.synchronize()
                 e._steps_done = done0
 
             set_timeouts(2.0)  # a schedule that cannot make progress on this machine must cost seconds, not minutes
             errs_seen, broken = [0.0], set()
+            budget = float(os.environ.get("DTF_DP_STARTUP_BUDGET_S", "5"))
+
+            def over_budget() -> bool:
+                """Start-up (self-tests + trials so far) has used its budget on some rank (agreed across ranks)."""
+                t = torch.tensor([1.0 if time.perf_counter() - self._t_start > budget else 0.0], dtype=torch.float64,
+                                 device="cpu" if self._stage_host else e.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                return float(t.item()) > 0
+
             for c in cands:
+                # bounded start-up: once the budget is spent only the reference schedule is still tried
+                if times and c != "ipc-inline" and forced == "auto" and over_budget():
+                    self._note("%s: not tried (start-up budget of %.0f s spent)" % (c, budget))
+                    broken.add(c)
+                    times.append(float("inf"))
+                    grads.append(None)
+                    continue
+                t_c = time.perf_counter()
                 use(c)
                 self.prepare()
                 dist.barrier(group=self.group)  # graph capture takes a different time on every rank; the waits are short here
@@ -352,6 +455,7 @@ class DataParallelTrainer:
                 with self._ctx():
                     grads.append((e.M - b1 * snap[1]) / (1.0 - b1))
                 if c != "rccl" and new_timeouts(errs_seen):
+                    self._note("%s: an in-kernel wait expired (2 s bound): not eligible" % c)
                     broken.add(c)
                     times.append(float("inf"))
                     restore()
@@ -366,13 +470,15 @@ class DataParallelTrainer:
                     times.append((time.perf_counter() - t0) / steps * 1e6)
                 else:
                     times.append(float(len(times)))  # untimed: keep the order of preference
+                self._note("%s: %s us/step, trial took %.2f s" % (c, ("%.1f" % times[-1]) if timed else "untimed",
+                                                               time.perf_counter() - t_c))
                 restore()
             # every schedule computes the same gradient up to summation order (same batch, same dropout mask: both are
             # keyed by the step): a candidate that is far from the staged in-stream all-reduce — the path the start-up
             # self-test validated against the process group — is broken on this machine and is not eligible
             ref = grads[cands.index("ipc-inline")]
             with self._ctx():
-                off = [float((g - ref).norm() / (ref.norm() + 1e-30)) for g in grads]
+                off = [float("inf") if g is None else float((g - ref).norm() / (ref.norm() + 1e-30)) for g in grads]
             del grads
             t = torch.tensor(times + off, dtype=torch.float64, device="cpu" if self._stage_host else e.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
@@ -397,11 +503,19 @@ class DataParallelTrainer:
     def _use_schedule(self, c: str) -> None:
         e, hook, fc1_end = self.engine, self._ipc_hook, self._fc1_end
         zc, ga = c == "ipc-zerocopy", c == "ipc-gather"
-        e.set_grad_redirect(self.ipc.stage_ptr if zc else 0, self.ipc.result_ptr if zc else 0)
+        if self.ipc is not None or zc:
+            e.set_grad_redirect(self.ipc.stage_ptr if zc else 0, self.ipc.result_ptr if zc else 0)
         if hasattr(e, "set_gather"):
             e.set_gather(self.ipc_act if ga else None)
+        self._rccl_graph = False
         if c == "rccl":
-            e.set_grad_hook(None)
+            if self.rccl is not None:  # native communicator: the collectives are part of the step graph
+                (a0, a1), (b0, b1) = e.bucket_bounds()
+                e.set_grad_hook(_RcclGradHook(self.rccl, e.G[a0:a1], e.G[b0:b1], e.G,
+                                              self.overlap and os.environ.get("DTF_RCCL_OVERLAP", "1") != "0"))
+                self._rccl_graph = True
+            else:
+                e.set_grad_hook(None)
             self.comm = "rccl"
         else:
             hook.set_overlap(c == "ipc-overlap")
@@ -426,15 +540,45 @@ class DataParallelTrainer:
             print("IPC exchange: %d wait(s) timed out; falling back to the process group's all-reduce" % int(t.item()),
                   flush=True)
         self._use_schedule("rccl")
-        self.broadcast_state()
+        self.broadcast_state()  # (also realigns the host's step mirror: a skipped step did not advance the device counter)
         return False
 
     # ------------------------------------------------------------------ collectives
     def _ctx(self):
-        if self._native:
-            return torch.cuda.stream(self.engine.stream)
+        """Context for process-group collectives and the torch ops around them: they run on a stream of their own that is
+        ordered after everything enqueued on the engine's stream so far, and the engine's stream continues after them.
+        ROOT CAUSE this removes: the process group records its own synchronisation events on whatever stream is current
+        when a collective is issued, and its watchdog thread keeps querying them; issued on the engine's stream, such an
+        event could still be held by the watchdog when that stream went into graph capture, and the query then failed
+        with hipErrorCapturedEvent and aborted the process (once in a few dozen runs; round 1 papered over it with a
+        5 ms sleep).  The engine's stream now only ever carries events this code owns."""
         import contextlib
-        return contextlib.nullcontext()
+        if not self._native:
+            return contextlib.nullcontext()
+
+        @contextlib.contextmanager
+        def isolated():
+            e = self.engine
+            if self._pg_stream is None:
+                self._pg_stream = torch.cuda.Stream(device=e.device)
+            self._pg_stream.wait_stream(e.stream)
+            with torch.cuda.stream(self._pg_stream):
+                yield
+            e.stream.wait_stream(self._pg_stream)
+        return isolated()
+
+    def _reduce_async(self, t: torch.Tensor):
+        """Asynchronous process-group all-reduce of ``t``, ordered after the engine's stream, issued on the collective
+        stream (see ``_ctx``); returns the work handle (None when the backend is host-staged and therefore synchronous)."""
+        e = self.engine
+        if self._stage_host:
+            with torch.cuda.stream(e.stream):
+                return self._reduce(t)
+        if self._pg_stream is None:
+            self._pg_stream = torch.cuda.Stream(device=e.device)
+        self._pg_stream.wait_stream(e.stream)
+        with torch.cuda.stream(self._pg_stream):
+            return dist.all_reduce(t, group=self.group, async_op=True)
 
     def _reduce(self, t: torch.Tensor, op=None, async_op: bool = False):
         """all-reduce ``t`` in place on the engine's stream (host-staged when the backend cannot take device memory)."""
@@ -481,6 +625,12 @@ class DataParallelTrainer:
             self.ipc.close()
             self.ipc = None
             self.comm = "rccl"
+        if self.rccl is not None:
+            if self._rccl_graph:
+                self.engine.set_grad_hook(None)  # (drops the graphs that hold the communicator's kernels)
+                self._rccl_graph = False
+            self.rccl.close()
+            self.rccl = None
 
     def transport_errors(self) -> int:
         """Expired in-kernel waits of the IPC exchanges so far (synchronises); 0 when IPC is not in use."""
@@ -537,36 +687,32 @@ class DataParallelTrainer:
     # ------------------------------------------------------------------ stepping
     def prepare(self) -> None:
         """Capture the step graphs ahead of the first step (collective-free; every rank may call it)."""
-        if self._native and (not self._multi or (self.sync and self.comm == "ipc")):
-            if self._multi and dist.is_initialized() and not self._stage_host:
-                import time
-                torch.cuda.synchronize(self.engine.device)  # (no capture next to a collective in flight, see below)
-                time.sleep(0.005)
+        if self._native and (not self._multi or (self.sync and self._one_graph())):
             self.engine.prepare()
         elif self._native and self._multi and self.sync:
             self._capture_rccl_graphs()
 
+    def _one_graph(self) -> bool:
+        """The whole data-parallel step (gradient exchange included) is kernels / RCCL calls on the engine's streams."""
+        return self.comm == "ipc" or self._rccl_graph
+
     def _capture_rccl_graphs(self) -> None:
-        """The RCCL schedule replays three graphs per step with collectives in between.  Capturing them lazily would put
-        a stream capture between two collectives of the first step, while the process group's watchdog thread polls the
-        events of the collective still in flight — seen to end in ``hipErrorCapturedEvent`` inside the watchdog (which
-        aborts the process) once in a few dozen runs.  So: all three captured up front, with the device idle."""
+        """The process-group schedule (no native communicator: gloo, or RCCL that could not be bound) replays three graphs
+        per step with ``torch.distributed`` collectives in between; all three are captured up front.
+        The process group's collectives never run on the engine's stream (see ``_pg``), which is what used to end,
+        once in a few dozen runs, in ``hipErrorCapturedEvent`` inside the process group's watchdog thread."""
         e = self.engine
         if not getattr(e, "use_graph", False):
             return
-        missing = [k for k in ("part1", "part2", "apply") if k not in e._graphs]
-        if missing:
-            import time
-            torch.cuda.synchronize(e.device)
-            time.sleep(0.005)  # (lets the watchdog retire the collectives that have just completed)
-            for k in missing:
+        for k in ("part1", "part2", "apply"):
+            if k not in e._graphs:
                 e._capture(k)
 
     def train_steps(self, n: int) -> None:
         """``n`` synchronous steps; several per graph launch where the whole step (incl. the gradient all-reduce) is
         plain kernels on the engine's stream (single replica, or the IPC transport)."""
         e = self.engine
-        if self._native and (not self._multi or (self.sync and self.comm == "ipc")):
+        if self._native and (not self._multi or (self.sync and self._one_graph())):
             e.train_steps(n)
             return
         for _ in range(n):
@@ -584,8 +730,8 @@ class DataParallelTrainer:
                     self._reduce(e.P)
                     e.P.div_(self.world)
             return
-        if self.comm == "ipc":
-            with trace.range("fwd+bwd | IPC all-reduce | Adam (one graph)"):
+        if self._native and self._one_graph():
+            with trace.range("fwd+bwd | %s all-reduce | Adam (one graph)" % self.comm.upper()):
                 e.launch("full")
             return
         if self._native:
@@ -595,17 +741,19 @@ class DataParallelTrainer:
                     e.launch("part1")
                 if self.overlap:
                     with trace.range("all-reduce bucket A (fc grads) || conv backward (graph part2)"):
-                        wa = self._reduce(self._bucket_a, async_op=True)
+                        wa = self._reduce_async(self._bucket_a)
                         e.launch("part2")
                     with trace.range("all-reduce bucket B (conv grads)"):
-                        wb = self._reduce(self._bucket_b, async_op=True)
+                        wb = self._reduce_async(self._bucket_b)
                         if wa is not None:
-                            wa.wait()
+                            wa.wait()  # (the engine's stream waits for the collective's end event)
                             wb.wait()
                 else:
                     with trace.range("conv backward (graph part2) + all-reduce"):
                         e.launch("part2")
-                        self._reduce(e.G)
+                        w = self._reduce_async(e.G)
+                        if w is not None:
+                            w.wait()
                 with trace.range("fused Adam (graph apply)"):
                     e.launch("apply")
         else:

@@ -22,7 +22,7 @@ MAX_RANKS = 8
 
 class _IpcCommStruct(C.Structure):  # csrc/hip/ipc_allreduce.hip: struct IpcComm
     _fields_ = [("rank", C.c_int), ("world", C.c_int), ("n_max", C.c_long), ("base", C.c_void_p * MAX_RANKS),
-                ("epoch", C.c_void_p), ("error", C.c_void_p), ("timeout_ticks", C.c_ulonglong)]
+                ("epoch", C.c_void_p), ("error", C.c_void_p), ("timeout_ticks", C.c_ulonglong), ("skip", C.c_void_p)]
 
 
 def _signatures(lib) -> None:
@@ -47,7 +47,10 @@ def _signatures(lib) -> None:
 
 
 class IpcAllReduce:
-    def __init__(self, n_max: int, device, group=None, timeout_s: float = 2.0, blocks: int = 64):
+    def __init__(self, n_max: int, device, group=None, timeout_s: float = 2.0, blocks: int = 64, skip_ptr: int = 0):
+        """``skip_ptr``: device address of the engine's [skip flag, skipped-step count] words: when a wait of an exchange
+        expires on any rank, every rank that can know raises the flag and the optimizer launch does not apply the step
+        (``csrc/hip/ipc_allreduce.hip``: settle_waits)."""
         if not dist.is_initialized():
             raise RuntimeError("IpcAllReduce needs an initialised torch.distributed group for the handle exchange")
         self.lib = native.hip()
@@ -93,9 +96,10 @@ class IpcAllReduce:
                     bases[p] = ptr.value
                     self._mapped.append(ptr.value)
                 self._bases = [int(bases[p]) for p in range(self.world)]
-                self._words = torch.zeros(4, dtype=torch.int32, device=self.device)  # epoch, error, arrival ticket, spare
+                # epoch, error, arrival ticket, error total acted on, decision tag, spare
+                self._words = torch.zeros(6, dtype=torch.int32, device=self.device)
                 self.comm = _IpcCommStruct(self.rank, self.world, self.n_max, bases, self._words.data_ptr(),
-                                           self._words.data_ptr() + 4, int(timeout_s * 100e6))
+                                           self._words.data_ptr() + 4, int(timeout_s * 100e6), skip_ptr or None)
                 torch.cuda.synchronize(self.device)
             except Exception as e:  # noqa: BLE001
                 self.failure = repr(e)
@@ -237,13 +241,18 @@ class IpcAllReduce:
         return bool(int(flag.item()))
 
     def close(self) -> None:
+        """Collective: every rank of the group calls it, whether or not its own allocation / mapping succeeded (a rank
+        that skipped the barrier would leave the others' next collective mismatched)."""
+        if getattr(self, "_closed", False):
+            return
+        self._closed = True
+        torch.cuda.synchronize(self.device)
+        if dist.is_initialized():
+            dist.barrier(group=self.group)
+        for p in self._mapped:
+            self.lib.dtf_ipc_close_handle(p)
+        self._mapped = []
         if getattr(self, "_own", None):
-            torch.cuda.synchronize(self.device)
-            if dist.is_initialized():
-                dist.barrier(group=self.group)
-            for p in self._mapped:
-                self.lib.dtf_ipc_close_handle(p)
-            self._mapped = []
             self.lib.dtf_ipc_free(self._own)
             self._own = None
-            self.comm = None
+        self.comm = None

@@ -180,7 +180,9 @@ def test_native_data_parallel_path_two_ranks_one_gpu(tmp_path, comm):
         comm = "ipc"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", port, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5",
-           "--backend", "gloo", "--train-size", "4000", "--comm", comm]
+           "--backend", "gloo", "--train-size", "4000", "--comm", comm, "--ref-steps", "0"]
+    if schedule == "ipc-gather":  # (exchanges bf16 operands: a schedule of the bf16 engine; the others run the fp32 headline engine)
+        cmd += ["--dtype", "bf16"]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]

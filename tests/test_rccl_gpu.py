@@ -1,0 +1,145 @@
+"""Native RCCL communicator (``csrc/hip/rccl_comm.hip``) and the survivability of the data-parallel step (GPU only).
+
+One test box has one GPU, so the communicator is exercised as a 1-rank group (the full code path: unique id through our
+rendezvous store, ncclCommInitRank, collectives captured into a hipGraph) and the multi-rank protocols with 2 ranks
+sharing the GPU over the IPC exchange.  Reference behaviour being replaced: ``/root/reference/demo2/train.py:13-29,166-184``.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rccl_communicator_single_rank_collectives_and_graph_capture():
+    from distributed_tensorflow_amd import native
+    from distributed_tensorflow_amd.parallel.cluster import StoreClient, StoreServer
+    from distributed_tensorflow_amd.parallel.rccl_comm import RcclCommunicator
+    assert RcclCommunicator.available()
+    server = StoreServer(0)
+    client = StoreClient("127.0.0.1", server.port)
+    comm = RcclCommunicator.create(0, 1, "cuda:0", store=client, key="rccl/test")
+    assert client.get("rccl/test", timeout_s=1.0) is not None and comm.world == 1 and comm.version >= 20000
+    x = torch.arange(4096, dtype=torch.float32, device="cuda")
+    y = x.clone()
+    comm.all_reduce(y)
+    comm.all_reduce_multi([y[:1024], y[1024:]])
+    comm.broadcast(y, root=0)
+    g = comm.all_gather(y)
+    torch.cuda.synchronize()
+    assert torch.equal(y, x) and g.shape == (1, 4096) and torch.equal(g[0], x)
+    assert comm.async_error() is None
+    # the collective is a plain enqueue on the caller's stream: captured into a hipGraph and replayed
+    lib = native.hip()
+    st = torch.cuda.Stream()
+    buf = torch.ones(1 << 20, device="cuda")
+    st.synchronize()
+    import ctypes as C
+    native.check(lib.dtf_graph_begin(st.cuda_stream), "begin")
+    with torch.cuda.stream(st):
+        buf.mul_(2.0)
+        comm.all_reduce(buf, stream=st)
+        buf.add_(1.0)
+    h = C.c_void_p()
+    native.check(lib.dtf_graph_end(st.cuda_stream, C.byref(h)), "end")
+    assert float(buf[0].item()) == 1.0  # capturing records, it does not execute
+    for _ in range(3):
+        native.check(lib.dtf_graph_launch(h, st.cuda_stream), "launch")
+    st.synchronize()
+    assert float(buf[0].item()) == 15.0 and float(buf[-1].item()) == 15.0  # ((1*2+1)*2+1)*2+1
+    lib.dtf_graph_free(h)
+    comm.close()
+    client.close()
+    server.stop()
+
+
+def _run_bench(extra, env_extra=None, nproc=1, timeout=300):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
+    if nproc > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+               "127.0.0.1", "--master-port", env["MASTER_PORT"], os.path.join(REPO, "bench.py"), "--gpus", str(nproc)]
+    else:
+        cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1"]
+    r = subprocess.run(cmd + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]), r.stdout
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_rccl_schedule_is_one_graph_launch_single_rank_group(dtype):
+    """``bench.py --dp-path``: a 1-rank RCCL group takes the multi-rank code path; with the native communicator the
+    collectives are inside the step graph (the JSON says so) and the step costs little more than the plain one."""
+    out, log = _run_bench(["--dp-path", "--comm", "rccl", "--steps", "600", "--warmup", "100", "--dtype", dtype,
+                           "--extra-dtype", "none", "--ref-steps", "0", "--train-size", "8000"],
+                          {"MASTER_PORT": "29641"})
+    assert out["config"]["gradient_transport"] == "rccl" and out["config"]["dp_schedule"] == "rccl"
+    assert out["rccl_in_step_graph"] is True and out["rccl_nranks"] == 1 and out["dtype"] == dtype
+    assert out["dp_startup_seconds"] is not None and out["dp_startup_seconds"] < 5.0, log[-2000:]
+    assert out["replicas_in_sync"] is True and out["final_train_loss"] < 2.35
+    assert out["ms_per_step"] < (0.130 if dtype == "bf16" else 0.200), out["ms_per_step"]
+
+
+_STALLED_PEER = r"""
+import json, os, sys, time
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from distributed_tensorflow_amd.data import mnist
+from distributed_tensorflow_amd.engine.mnist_engine import NativeMnistEngine
+from distributed_tensorflow_amd.parallel.ddp import DataParallelTrainer, init_process_group
+rank, world = init_process_group("gloo")
+torch.cuda.set_device(0)
+imgs, labels = mnist.synthetic_mnist(4000, seed=1)
+d = mnist.DataSet(mnist._scale_flatten(imgs), mnist.dense_to_one_hot(labels), seed=1)
+dd = mnist.DeviceDataset(d, "cuda:0", rank=rank, world=world, seed=1)
+eng = NativeMnistEngine(dd, batch_size=100, seed=5, lr=1e-4, device="cuda:0")
+tr = DataParallelTrainer(eng, comm="ipc")
+tr.prepare()
+tr.train_steps(5)
+torch.cuda.synchronize()
+P0, step0 = eng.P.clone(), int(eng.step_t.item())
+dist.barrier()
+if rank == 1:
+    time.sleep(1.5)   # a peer that stalls for longer than the exchange's bound (0.4 s)
+tr.train_step()
+torch.cuda.synchronize()
+out = {"rank": rank, "skipped": eng.skipped_steps(), "unchanged": bool(torch.equal(eng.P, P0)),
+       "step_before": step0, "step_after": int(eng.step_t.item()), "errors": tr.transport_errors(),
+       "grad_discarded": float(eng.G[eng.layout["b_fc1"][0]:].abs().max().item()) == 0.0}
+dist.barrier()
+out["healthy"] = tr.ensure_healthy()            # collective: agrees on the failure, falls back, re-broadcasts the state
+out["transport_after"] = tr.comm
+tr.train_steps(5)
+out["in_sync"] = tr.replicas_in_sync()
+out["host_step"], out["device_step"] = eng.global_step, int(eng.step_t.item())
+print("RESULT " + json.dumps(out), flush=True)
+dist.barrier()
+tr.close()
+dist.destroy_process_group()
+"""
+
+
+def test_expired_ipc_wait_skips_the_optimizer_on_every_rank(tmp_path):
+    """A peer that stalls past the in-kernel bound: the waiting rank's exchange times out, NO rank applies that step
+    (parameters bit-identical to before, step counter not advanced, gradient discarded), the trainer then falls back to the
+    process group and training continues with replicas in sync (VERDICT r1 'Next round' 2c)."""
+    script = tmp_path / "stalled_peer.py"
+    script.write_text(_STALLED_PEER)
+    env = dict(os.environ, MASTER_PORT="29643", HSA_ENABLE_IPC_MODE_LEGACY="0", DTF_DP_SCHEDULE="ipc-inline",
+               DTF_IPC_TIMEOUT_S="0.4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29643", str(script), REPO]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    res = [json.loads(l.split("RESULT ", 1)[1]) for l in r.stdout.splitlines() if "RESULT " in l]
+    assert len(res) == 2, r.stdout[-3000:]
+    for o in res:
+        assert o["skipped"] == 1 and o["unchanged"] and o["step_after"] == o["step_before"] and o["grad_discarded"], o
+        assert o["healthy"] is False and o["transport_after"] == "rccl" and o["in_sync"] is True, o
+        assert o["host_step"] == o["device_step"] == o["step_before"] + 5, o
+    assert max(o["errors"] for o in res) >= 1 and min(o["errors"] for o in res) == 0, res
