@@ -113,6 +113,13 @@ struct Server {
       if (!write_all(fd, &status, 8)) break;
       if (!payload.empty() && !write_all(fd, payload.data(), payload.size())) break;
     }
+    {
+      // forget the descriptor before closing it: the number may be reused by the process, and stop() shuts down every
+      // descriptor still on the list
+      std::lock_guard<std::mutex> l(mu);
+      for (size_t i = 0; i < fds.size(); ++i)
+        if (fds[i] == fd) { fds.erase(fds.begin() + (long)i); break; }
+    }
     ::close(fd);
   }
 

@@ -94,11 +94,12 @@ def run(FLAGS, distributed: bool) -> int:
     if kind == "auto":
         kind = "native" if device.type == "cuda" else "eager"
     engine = make_engine(kind, train_dd, batch_size=FLAGS.batch_size, lr=FLAGS.learning_rate, keep_prob=FLAGS.keep_prob,
-                         double_softmax=FLAGS.double_softmax, seed=FLAGS.seed, device=device, use_graph=FLAGS.use_graph)
+                         double_softmax=FLAGS.double_softmax, seed=FLAGS.seed, device=device, use_graph=FLAGS.use_graph,
+                         dtype=FLAGS.dtype)
     trainer = DataParallelTrainer(engine, sync=FLAGS.sync, async_period=FLAGS.async_period,
                                   comm=getattr(FLAGS, "comm", "auto"))
-    _log(rank, "engine=%s device=%s world=%d global_batch=%d sync=%s" % (
-        kind, device, world, FLAGS.batch_size * world, FLAGS.sync))
+    _log(rank, "engine=%s dtype=%s device=%s world=%d global_batch=%d sync=%s" % (
+        kind, FLAGS.dtype if kind == "native" else "fp32", device, world, FLAGS.batch_size * world, FLAGS.sync))
 
     writer = None
     if rank == 0:
@@ -108,9 +109,17 @@ def run(FLAGS, distributed: bool) -> int:
         writer = FileWriter(FLAGS.log_dir, graph)
 
     sv: Optional[Supervisor] = None
+    store = store_server = None
     if distributed:
+        # the stop flag and the heartbeats travel out of band, through the job's rendezvous store
+        if world > 1:
+            store = server.connect_store() if server is not None else None
+            if store is None:
+                store, store_server = cl.job_store(rank, world)
         sv = Supervisor(trainer, is_chief=(rank == 0), logdir=FLAGS.log_dir, save_model_secs=FLAGS.save_model_secs,
-                        summary_writer=writer, log_fn=lambda m: _log(rank, m))
+                        summary_writer=writer, log_fn=lambda m: _log(rank, m), store=store,
+                        heartbeat_period_s=float(os.environ.get("DTF_HEARTBEAT_PERIOD_S", "1.0")),
+                        fatal_grace_s=float(os.environ.get("DTF_FATAL_GRACE_S", "20")))
         sv.prepare_or_wait_for_session()
         sv.start_standard_services()
 
@@ -122,8 +131,9 @@ def run(FLAGS, distributed: bool) -> int:
     start_time = time.time()
     step = start_step
     rc = 0
+    burst = 1
     try:
-        while step < FLAGS.training_steps and not (sv is not None and sv.should_stop()):
+        while step < FLAGS.training_steps and not (sv is not None and sv.should_stop(steps=burst)):
             if FLAGS.fault_inject_step >= 0 and step == FLAGS.fault_inject_step and rank == world - 1:
                 raise RuntimeError("injected fault at step %d" % step)
             # run up to the next point where the host has something to do (evaluation, summary flush, fault
@@ -134,7 +144,12 @@ def run(FLAGS, distributed: bool) -> int:
                         512 - (step - flushed), 64)
             if FLAGS.fault_inject_step > step:
                 burst = min(burst, FLAGS.fault_inject_step - step)
-            trainer.train_steps(max(1, burst))
+            burst = max(1, burst)
+            trainer.train_steps(burst)
+            if trainer.ipc is not None and trainer.comm == "ipc" and not trainer.ensure_healthy():
+                # an in-kernel wait of the direct exchange expired on some rank: that step was skipped on every rank that
+                # could know, the job has agreed on it, fallen back to the collective path and re-synchronised the replicas
+                _log(rank, "gradient exchange fell back to %s at step %d" % (trainer.comm, engine.global_step))
             step = engine.global_step
             last = step - 1
             if step - flushed >= 512:
@@ -175,14 +190,25 @@ def run(FLAGS, distributed: bool) -> int:
             _log(rank, "Throughput: %.1f images/sec (%d steps x global batch %d)" % (
                 done * FLAGS.batch_size * world / max(1e-9, elapsed), done, FLAGS.batch_size * world))
         if sv is not None:
+            # (a rank that failed does not write; on a coordinated stop the chief, whose loop ended through
+            # should_stop(), saves the last consistent state)
             sv.stop(final_save=(rc == 0 or world == 1))
         elif rank == 0:
             path = ckpt.Saver(engine, with_global_step=False).save(FLAGS.checkpoint_path)
             _log(rank, "Saved checkpoint " + path)
         if writer is not None:
             writer.close()
+        if store is not None:
+            store.close()
+        if store_server is not None:
+            store_server.stop()
         if server is not None:
             server.report_done()
+    stopped_early = sv is not None and rc == 0 and engine.global_step < FLAGS.training_steps
+    if stopped_early:
+        _log(rank, "stopped at global step %d of %d (%s)" % (engine.global_step, FLAGS.training_steps,
+                                                             sv.stop_reason or "stop requested"))
+        return 3  # (no barrier: the rank that failed is not coming)
     if world > 1:
         import torch.distributed as dist
         if dist.is_initialized() and rc == 0:

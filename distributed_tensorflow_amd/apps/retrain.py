@@ -59,16 +59,76 @@ def _log(rank: int, msg: str) -> None:
         print(msg, flush=True)
 
 
-def _head_summary(head, prefix_scalars, logits_probs=None):
+def _head_summary(head, prefix_scalars, batch=None):
+    """What ``merged`` holds for the retrain graph (``retrain1/retrain.py:249-258,271-283,295``): the variable
+    summaries of the new layer, the ``pre_activations`` / ``activations`` histograms of ``batch`` = (bottlenecks [B,2048])
+    and the cross-entropy / accuracy scalars."""
+    import torch
     from ..utils.summary import Summary, variable_summaries
     s = Summary()
     s.merge(variable_summaries("final_training_ops/weights", head.weights))
     s.merge(variable_summaries("final_training_ops/biases", head.biases))
+    if batch is not None:
+        with torch.no_grad():
+            logits = batch.to(head.device, torch.float32) @ head.weights + head.biases
+            s.histogram("final_training_ops/Wx_plus_b/pre_activations", logits)
+            s.histogram("final_training_ops/activations", torch.softmax(logits, 1))
     for k, v in prefix_scalars.items():
         s.scalar(k, v)
-    if logits_probs is not None:
-        s.histogram("activations", logits_probs)
     return s
+
+
+class _HeadSaver:
+    """``tf.train.Saver`` over the variables the retrain2 Supervisor checkpoints (``retrain2/retrain2.py:418,426``):
+    ``final_weights``, ``final_biases`` and the global step, under their TF names."""
+
+    def __init__(self, head, max_to_keep: int = 5):
+        self.head, self.max_to_keep, self._kept = head, max_to_keep, []
+
+    def save(self, save_path: str, global_step=None) -> str:
+        from ..utils import checkpoint as ckpt
+        path = save_path if global_step is None else "%s-%d" % (save_path, global_step)
+        ckpt.save_tensors(path, self.head.tf_tensors())
+        ckpt.update_checkpoint_state(os.path.dirname(os.path.abspath(path)) or ".", path)
+        self._kept.append(path)
+        while self.max_to_keep and len(self._kept) > self.max_to_keep:
+            old = self._kept.pop(0)
+            if old != path and os.path.exists(old):
+                os.remove(old)
+        return path
+
+    def restore(self, path: str) -> int:
+        from ..utils import checkpoint as ckpt
+        self.head.load_tf_tensors(ckpt.load_tensors(path))
+        return self.head.global_step
+
+
+class _HeadTrainer:
+    """The little of a trainer the Supervisor needs, over a ``RetrainHead``: rank/world, the stop-flag reduction and the
+    chief's broadcast of parameters + global step."""
+
+    def __init__(self, head, rank: int, world: int):
+        self.engine, self.rank, self.world = head, rank, world
+
+    def broadcast_state(self, src: int = 0) -> None:
+        import torch
+        import torch.distributed as dist
+        from ..parallel.ddp import broadcast_
+        broadcast_(self.engine.P, src=src)
+        t = torch.tensor([self.engine.global_step], dtype=torch.int64,
+                         device="cpu" if dist.get_backend() == "gloo" else self.engine.device)
+        dist.broadcast(t, src=src)
+        self.engine.global_step = int(t.item())
+
+    def any_rank(self, flag: bool) -> bool:
+        if self.world == 1:
+            return bool(flag)
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32,
+                         device="cpu" if dist.get_backend() == "gloo" else self.engine.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(int(t.item()))
 
 
 def run(FLAGS, distributed: bool) -> int:
@@ -206,39 +266,122 @@ def run(FLAGS, distributed: bool) -> int:
         train_writer = FileWriter(os.path.join(FLAGS.summaries_dir, "train"), graph)
         validation_writer = FileWriter(os.path.join(FLAGS.summaries_dir, "validation"))
 
-    # Supervisor-equivalent for the head (retrain2): resume from ./retrain_logs/../logs is not part of the reference
+    # retrain2 wraps the loop in a Supervisor (retrain2/retrain2.py:423-431,445,508): the chief restores the newest
+    # ./logs/model.ckpt-<step> (head + global step) and everyone receives it, the chief autosaves every
+    # --save_model_secs, the loop runs on the restored global step and polls should_stop(), sv.stop() saves at the end.
+    sv = None
+    store = store_server = None
+    if distributed:
+        from ..parallel.supervisor import Supervisor
+        if world > 1:
+            store = server.connect_store() if server is not None else None
+            if store is None:
+                store, store_server = cl.job_store(rank, world)
+        sv = Supervisor(_HeadTrainer(head, rank, world), is_chief=(rank == 0), logdir=FLAGS.log_dir,
+                        saver=_HeadSaver(head), save_model_secs=FLAGS.save_model_secs, summary_writer=train_writer,
+                        log_fn=lambda m: _log(rank, m), store=store,
+                        heartbeat_period_s=float(os.environ.get("DTF_HEARTBEAT_PERIOD_S", "1.0")),
+                        fatal_grace_s=float(os.environ.get("DTF_FATAL_GRACE_S", "20")))
+        sv.prepare_or_wait_for_session()
+        sv.start_standard_services()
+
+    # Per-step summaries (retrain1/retrain.py:440-446 runs `merged` on the training batch AND on a validation batch on
+    # every step and writes both): cross-entropy and accuracy of every step accumulate in a device ring and reach the two
+    # writers at logging points, each under its true step index; the variable summaries and the pre_activations /
+    # activations histograms are written at the logging points.
+    RING = 1024
+    ring = torch.zeros(RING, 4, dtype=torch.float32, device=device)  # train ce-sum, train correct, val ce-sum, val correct
+    head.use_metrics_ring(ring)
+    flushed = head.global_step
+
+    def flush_ring(upto: int) -> None:
+        nonlocal flushed
+        if upto <= flushed:
+            return
+        t = ring.clone()
+        if world > 1:  # (collective: every rank flushes at the same steps)
+            from ..parallel.ddp import all_reduce_
+            all_reduce_(t)
+            t /= world
+        host = t.cpu().numpy()
+        if train_writer is not None:
+            for st in range(flushed, upto):
+                r = host[st % RING]
+                train_writer.add_scalars({"cross_entropy": r[0] / FLAGS.train_batch_size,
+                                          "accuracy": r[1] / FLAGS.train_batch_size}, st)
+                validation_writer.add_scalars({"cross_entropy": r[2] / max(1, FLAGS.validation_batch_size),
+                                               "accuracy": r[3] / max(1, FLAGS.validation_batch_size)}, st)
+        ring.zero_()
+        flushed = upto
+
     start_time = time.time()
     steps = FLAGS.training_steps
-    for i in range(steps):
-        if distortion.enabled:
-            feats, labels = get_random_distorted_bottlenecks(index, FLAGS.train_batch_size, "training", backbone,
-                                                             preproc, distortion, rng)
-            B = head.train_step(feats, labels, None)
-            train_src = (feats, labels, None)
-        else:
-            rows = cache.sample_rows("training", FLAGS.train_batch_size, seed=seed + rank)
-            B = head.train_step(cache.values, cache.labels, rows)
-            train_src = (cache.values, cache.labels, rows)
-        is_last_step = (i + 1 == steps)
-        log_now = (i % FLAGS.eval_step_interval) == 0 or is_last_step
-        if log_now or (train_writer is not None and i % max(1, FLAGS.eval_step_interval) == 0):
-            # metrics of the training batch after the update (what the reference's second sess.run reports)
-            ce, train_acc = head.evaluate(*train_src)
+    i = head.global_step if sv is not None else 0
+    start_step = i
+    rc = 0
+    try:
+        while i < steps and not (sv is not None and sv.should_stop()):
+            if FLAGS.fault_inject_step >= 0 and i == FLAGS.fault_inject_step and rank == world - 1:
+                raise RuntimeError("injected fault at step %d" % i)
+            if distortion.enabled:
+                feats, labels = get_random_distorted_bottlenecks(index, FLAGS.train_batch_size, "training", backbone,
+                                                                 preproc, distortion, rng)
+                head.train_step(feats, labels, None, ring_slot=i % RING)
+                train_src = (feats, labels, None)
+            else:
+                rows = cache.sample_rows("training", FLAGS.train_batch_size, seed=seed + rank)
+                head.train_step(cache.values, cache.labels, rows, ring_slot=i % RING)
+                train_src = (cache.values, cache.labels, rows)
+            # the validation batch of this step (every step, like the reference's second sess.run(merged, ...))
             vrows = cache.sample_rows("validation", FLAGS.validation_batch_size, seed=seed + 977)
-            vce, val_acc = head.evaluate(cache.values, cache.labels, vrows)
-            if world > 1:
-                import torch.distributed as dist
-                t = torch.tensor([ce, train_acc, vce, val_acc], dtype=torch.float64,
-                                 device="cpu" if dist.get_backend() == "gloo" else device)
-                dist.all_reduce(t)
-                ce, train_acc, vce, val_acc = (t / world).tolist()
-            if train_writer is not None:
-                train_writer.add_summary(_head_summary(head, {"cross_entropy": ce, "accuracy": train_acc}), i)
-                validation_writer.add_summary(_head_summary(head, {"cross_entropy": vce, "accuracy": val_acc}), i)
+            if vrows.numel() > 0:
+                head.accumulate_metrics(cache.values, cache.labels, vrows, ring_slot=i % RING, column=2)
+            is_last_step = (i + 1 == steps)
+            log_now = (i % FLAGS.eval_step_interval) == 0 or is_last_step
+            if log_now or (i + 1 - flushed) >= RING:
+                flush_ring(i + 1)
             if log_now:
+                # metrics of the training batch after the update (what the reference's extra sess.run reports)
+                ce, train_acc = head.evaluate(*train_src)
+                vce, val_acc = head.evaluate(cache.values, cache.labels, vrows) if vrows.numel() > 0 else (float("nan"),) * 2
+                if world > 1:
+                    import torch.distributed as dist
+                    t = torch.tensor([ce, train_acc, vce, val_acc], dtype=torch.float64,
+                                     device="cpu" if dist.get_backend() == "gloo" else device)
+                    dist.all_reduce(t)
+                    ce, train_acc, vce, val_acc = (t / world).tolist()
+                if train_writer is not None:
+                    tb = train_src[0] if train_src[2] is None else train_src[0].index_select(0, train_src[2].long())
+                    train_writer.add_summary(_head_summary(head, {}, tb), i)
+                    vb = cache.values.index_select(0, vrows.long()) if vrows.numel() > 0 else None
+                    validation_writer.add_summary(_head_summary(head, {}, vb), i)
                 _log(rank, "%s: Step %d: Train accuracy = %.1f%% Cross entropy = %f Validation accuracy = %.1f%%%s" % (
                     datetime.now(), i, train_acc * 100, ce, val_acc * 100,
                     " (N=%d)" % FLAGS.validation_batch_size if distributed else ""))
+            i += 1
+    except BaseException as e:  # noqa: BLE001
+        rc = 1
+        if sv is not None:
+            sv.request_stop(e)
+        _log(0, "rank %d: retraining aborted: %r" % (rank, e))
+        if sv is None or world == 1:
+            raise
+    finally:
+        if sv is not None:
+            sv.stop(final_save=True)
+    if rc != 0 or (sv is not None and i < steps):
+        # a coordinated stop (a peer failed, or stop was requested): the chief has saved; relaunching resumes from there
+        _log(rank, "stopped at global step %d of %d (%s)" % (i, steps, (sv.stop_reason if sv is not None else None) or "exception"))
+        if rank == 0 and train_writer is not None:
+            train_writer.close()
+            validation_writer.close()
+        if store is not None:
+            store.close()
+        if store_server is not None:
+            store_server.stop()
+        if server is not None:
+            server.report_done()
+        return rc or 3
     if device.type == "cuda":
         torch.cuda.synchronize()
     train_time = time.time() - start_time
@@ -258,15 +401,23 @@ def run(FLAGS, distributed: bool) -> int:
         test_accuracy = float("nan")
         _log(rank, "Final test accuracy = n/a (empty testing split)")
     _log(rank, "Training time: %3.2fs" % train_time)
-    if steps:
+    if steps > start_step:
         _log(rank, "Head training throughput: %.1f bottleneck-images/sec (global batch %d)" % (
-            steps * FLAGS.train_batch_size * world / max(train_time, 1e-9), FLAGS.train_batch_size * world))
+            (steps - start_step) * FLAGS.train_batch_size * world / max(train_time, 1e-9), FLAGS.train_batch_size * world))
 
     if rank == 0:
         tensors = dict(head.tf_tensors())
         tensors["_dtf/final_tensor_name"] = np.frombuffer(FLAGS.final_tensor_name.encode(), np.uint8).copy()
         tensors["_dtf/backbone"] = np.frombuffer(backbone_kind.encode(), np.uint8).copy()
         tensors["_dtf/backbone_seed"] = np.asarray(seed, np.int64)
+        # the frozen graph holds the whole network (retrain1/retrain.py:470-473: convert_variables_to_constants over the
+        # imported Inception graph + the new layer): the backbone's folded filters and biases travel in the bundle, so
+        # test.py reproduces the features the head was trained on whatever the weights' origin (pretrained .pb, .npz, or
+        # random-init + calibrated batch-norm statistics)
+        if backbone_kind == "inception":
+            tensors.update(net.export_folded())
+        else:
+            tensors["backbone/tiny/proj"] = backbone.proj.detach().cpu().numpy()
         tensors["_dtf/labels"] = np.frombuffer("\n".join(image_lists.keys()).encode(), np.uint8).copy()
         ckpt.save_tensors(FLAGS.output_graph, tensors)
         # the frozen head as a real GraphDef too (reference tensor names), for TensorFlow-side tooling
@@ -280,6 +431,10 @@ def run(FLAGS, distributed: bool) -> int:
         train_writer.close()
         validation_writer.close()
     _log(rank, "Total time: %3.2fs:" % (time.time() - begin_time))
+    if store is not None:
+        store.close()
+    if store_server is not None:
+        store_server.stop()
     if server is not None:
         server.report_done()
     if world > 1:

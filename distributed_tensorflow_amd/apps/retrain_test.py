@@ -46,9 +46,15 @@ def run(args) -> List[str]:
         if not use_cuda:
             raise RuntimeError("this bundle was trained on the Inception-v3 backbone, which needs the GPU path")
         from ..models.inception_v3 import InceptionV3
-        backbone = InceptionV3(device, seed=seed).forward
+        net = InceptionV3(device, seed=seed)
+        if "backbone/conv/folded_weights" not in t:
+            raise RuntimeError("%s carries no backbone (written by an older build): re-run retrain.py" % args.graph)
+        net.load_folded(t)  # the bundle is self-contained, like the reference's frozen graph (retrain1/test.py:26-39)
+        backbone = net.forward
     else:
         backbone = TinyBackbone(device, seed=seed)
+        if "backbone/tiny/proj" in t:
+            backbone.proj = torch.from_numpy(np.asarray(t["backbone/tiny/proj"], np.float32)).to(device)
     files = walk_images(args.imgs, (".jpg", ".jpeg"))
     if not files:
         raise FileNotFoundError("no JPEG images under %r" % args.imgs)

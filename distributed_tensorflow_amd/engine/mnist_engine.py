@@ -145,6 +145,10 @@ class NativeMnistEngine(_EngineBase):
         self.cfg = s
         self._graphs = {}
         self.grad_hook = None
+        # stream capture vs. snapshots from other threads (the Supervisor's autosave thread calls state_dict()): work
+        # enqueued on a capturing stream would be recorded into the step graph, and synchronising it invalidates the capture
+        import threading
+        self._capture_lock = threading.RLock()
         torch.cuda.synchronize(self.device)  # allocations/zero-fills ran on the default stream
         self.init_params(seed)
 
@@ -174,10 +178,12 @@ class NativeMnistEngine(_EngineBase):
         return int(n)
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
-        # snapshot in stream order (between two steps) so a saver thread never sees a half-applied update
-        with torch.cuda.stream(self.stream):
-            sd = {"P": self.P.clone(), "M": self.M.clone(), "V": self.V.clone(), "step": self.step_t.clone()}
-        self.stream.synchronize()
+        # snapshot in stream order (between two steps) so a saver thread never sees a half-applied update; never while
+        # the training thread has a capture open on the stream
+        with self._capture_lock:
+            with torch.cuda.stream(self.stream):
+                sd = {"P": self.P.clone(), "M": self.M.clone(), "V": self.V.clone(), "step": self.step_t.clone()}
+            self.stream.synchronize()
         return sd
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
@@ -254,13 +260,14 @@ class NativeMnistEngine(_EngineBase):
         """Capture one segment of the step into a hipGraph: ``full`` (fwd+bwd+Adam), ``part1``
         (forward + head + fc grads), ``part2`` (conv backward) or ``apply`` (Adam)."""
         st = self.stream.cuda_stream
-        self.stream.synchronize()
-        native.check(self.lib.dtf_graph_begin(st), "graph begin")
-        rc = self._enqueue(key, st)
-        h = C.c_void_p()
-        rc2 = self.lib.dtf_graph_end(st, C.byref(h))
-        native.check(rc or rc2, "graph capture (%s)" % key)
-        self._graphs[key] = h
+        with self._capture_lock:
+            self.stream.synchronize()
+            native.check(self.lib.dtf_graph_begin(st), "graph begin")
+            rc = self._enqueue(key, st)
+            h = C.c_void_p()
+            rc2 = self.lib.dtf_graph_end(st, C.byref(h))
+            native.check(rc or rc2, "graph capture (%s)" % key)
+            self._graphs[key] = h
 
     def _enqueue(self, key: str, st: int) -> int:
         """Enqueue the kernels of one step segment on stream ``st`` (directly or under capture)."""

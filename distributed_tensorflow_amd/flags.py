@@ -47,7 +47,9 @@ def add_framework_flags(p: argparse.ArgumentParser) -> None:
                    help="collective backend: auto | nccl (RCCL over xGMI) | gloo | local")
     p.add_argument("--num_gpus", type=int, default=0,
                    help="spawn this many local ranks (0 = use the cluster flags / torchrun env)")
-    p.add_argument("--dtype", type=str, default="bf16", help="MFMA input dtype: bf16 | fp32")
+    p.add_argument("--dtype", type=str, default="fp32", choices=["fp32", "bf16"],
+                   help="compute precision of the native MNIST engine: fp32 = the reference's (fp32 activations, exact-fp32 "
+                        "MFMA); bf16 = bf16 MFMA operands with fp32 accumulation and master weights")
     p.add_argument("--seed", type=int, default=None, help="RNG seed (reference is unseeded)")
     p.add_argument("--synthetic", type="bool", nargs="?", const=True, default=None,
                    help="force synthetic data of the reference shapes (default: auto when blobs are missing)")
@@ -151,6 +153,8 @@ def build_retrain_parser(distributed: bool) -> argparse.ArgumentParser:
     p.add_argument("--finetune_batch_size", type=int, default=32, help="Per-GPU batch of the fine-tune step.")
     p.add_argument("--finetune_optimizer", type=str, default="sgd", choices=["sgd", "adam"])
     p.add_argument("--bucket_mb", type=float, default=25.0, help="Gradient all-reduce bucket size (fine-tune DP).")
+    p.add_argument("--log_dir", type=str, default="./logs",
+                   help="Supervisor logdir of retrain2 (retrain2/retrain2.py:424: ./logs/model.ckpt-<global_step>)")
     p.add_argument("--synthetic_classes", type=int, default=5)
     p.add_argument("--synthetic_images_per_class", type=int, default=40)
     add_framework_flags(p)

@@ -241,6 +241,33 @@ class InceptionV3:
                 self.params[name][k] = t
         self._packed.clear()
 
+    def export_folded(self) -> "OrderedDict[str, torch.Tensor]":
+        """The inference state of the backbone: per conv layer the BN-folded HWIO filter as bf16 (exactly the bits the HIP
+        conv consumes) and the fp32 bias, ~44 MB — what a self-contained retrained bundle stores
+        (``retrain1/retrain.py:470-473`` freezes backbone + head into one file)."""
+        out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        for name in self.graph.convs:
+            w, b = self.folded(name)
+            out["backbone/%s/folded_weights" % name] = w.to(torch.bfloat16).contiguous()
+            out["backbone/%s/folded_bias" % name] = b.to(torch.float32).contiguous()
+        return out
+
+    def load_folded(self, tensors) -> None:
+        """Inverse of ``export_folded`` (bf16 entries may arrive as uint16 bit patterns): identity batch norm around the
+        stored folded filter, so ``packed()`` reproduces the exporting model's operands bit for bit."""
+        layers = {}
+        for name, p in self.params.items():
+            w = tensors["backbone/%s/folded_weights" % name]
+            w = torch.as_tensor(np.asarray(w))
+            if w.dtype in (torch.uint16, torch.int16):
+                w = w.view(torch.bfloat16)
+            b = torch.as_tensor(np.asarray(tensors["backbone/%s/folded_bias" % name]), dtype=torch.float32)
+            c = b.shape[0]
+            layers[name] = {"weights": w.float().numpy(), "beta": b.numpy(), "gamma": np.ones(c, np.float32),
+                            "moving_mean": np.zeros(c, np.float32),
+                            "moving_variance": np.full(c, 1.0 - BN_EPS, np.float32)}  # gamma / sqrt(var + eps) == 1
+        self.load_tf_weights(layers)
+
     def folded(self, name: str) -> Tuple[torch.Tensor, torch.Tensor]:
         """(HWIO fp32 weights with BN folded, fp32 bias)."""
         p = self.params[name]

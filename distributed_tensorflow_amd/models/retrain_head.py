@@ -56,6 +56,14 @@ class RetrainHead:
         self._step_t = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._ticket = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._dz = None
+        self._ring = None  # optional [R,4] device ring of per-step metric sums (train ce, train correct, val ce, val correct)
+
+    def use_metrics_ring(self, ring: Optional[torch.Tensor]) -> None:
+        """Per-step summaries without a host sync per step: ``train_step(..., ring_slot=s)`` adds the batch's loss sum and
+        correct count to ``ring[s, 0:2]``, ``accumulate_metrics(..., ring_slot=s, column=2)`` a validation batch's to
+        ``ring[s, 2:4]``; the driver reads and zeroes the ring at logging points."""
+        assert ring is None or (ring.dim() == 2 and ring.shape[1] == 4 and ring.dtype == torch.float32 and ring.is_contiguous())
+        self._ring = ring
 
     # flat views: TF names final_training_ops/weights/final_weights, .../biases/final_biases (SURVEY §5.4)
     @property
@@ -77,7 +85,7 @@ class RetrainHead:
         self.global_step = int(np.asarray(t.get("Variable", 0)).reshape(-1)[0])
 
     # ------------------------------------------------------------------ forward / eval
-    def _fwd_native(self, cache, labels_all, rows, training: bool, want_probs: bool):
+    def _fwd_native(self, cache, labels_all, rows, training: bool, want_probs: bool, metrics_ptr: int = 0):
         B = int(rows.shape[0]) if rows is not None else int(cache.shape[0])
         p = RetrainHeadParams()
         p.cache, p.labels_all, p.rows = cache.data_ptr(), labels_all.data_ptr(), native.ptr(rows)
@@ -89,8 +97,11 @@ class RetrainHead:
         if training and (self._dz is None or self._dz.shape[0] != B):
             self._dz = torch.empty(B, self.C, dtype=torch.float32, device=self.device)
         p.probs, p.pred, p.dz = native.ptr(probs), native.ptr(pred), native.ptr(self._dz if training else None)
-        self._metrics.zero_()
-        p.metrics = self._metrics.data_ptr()
+        if metrics_ptr:
+            p.metrics = metrics_ptr  # (a slot of the per-step ring: accumulates, zeroed by the driver)
+        else:
+            self._metrics.zero_()
+            p.metrics = self._metrics.data_ptr()
         native.check(native.hip().dtf_retrain_head_fwd(C.byref(p), torch.cuda.current_stream().cuda_stream), "head fwd")
         return B, probs, pred
 
@@ -123,12 +134,29 @@ class RetrainHead:
             return torch.softmax(bottlenecks.to(self.device, torch.float32) @ self.weights + self.biases, 1)
 
     # ------------------------------------------------------------------ training
+    def accumulate_metrics(self, cache: torch.Tensor, labels_all: torch.Tensor, rows: Optional[torch.Tensor],
+                           ring_slot: int, column: int = 2) -> None:
+        """Forward only; loss sum and correct count of ``cache[rows]`` are added to ``ring[ring_slot, column:column+2]``."""
+        assert self._ring is not None and column in (0, 2)
+        if self.native:
+            self._fwd_native(cache, labels_all, rows, False, False,
+                             metrics_ptr=self._ring.data_ptr() + (ring_slot * 4 + column) * 4)
+        else:
+            x = cache if rows is None else cache.index_select(0, rows.long())
+            y = labels_all if rows is None else labels_all.index_select(0, rows.long())
+            with torch.no_grad():
+                loss, probs = self._fwd_eager(x, y)
+            self._ring[ring_slot, column] += loss * x.shape[0]
+            self._ring[ring_slot, column + 1] += (probs.argmax(1) == y.long()).sum()
+
     def train_step(self, cache: torch.Tensor, labels_all: torch.Tensor, rows: Optional[torch.Tensor] = None,
-                   group=None) -> Tuple[float, float]:
+                   group=None, ring_slot: Optional[int] = None) -> Tuple[float, float]:
         """One SGD step on ``cache[rows]``; returns (cross-entropy, accuracy) of the batch *before* the update
         as device-synchronising floats only when asked through ``last_metrics``."""
+        use_ring = ring_slot is not None and self._ring is not None
         if self.native:
-            B, _, _ = self._fwd_native(cache, labels_all, rows, True, False)
+            B, _, _ = self._fwd_native(cache, labels_all, rows, True, False,
+                                       metrics_ptr=self._ring.data_ptr() + ring_slot * 16 if use_ring else 0)
             st = torch.cuda.current_stream().cuda_stream
             lib = native.hip()
             if self.world == 1:
@@ -161,6 +189,9 @@ class RetrainHead:
             self.P.sub_(g, alpha=self.lr)
             self._metrics[0] = loss.detach() * x.shape[0]
             self._metrics[1] = (p.argmax(1) == y.long()).sum()
+            if use_ring:
+                self._ring[ring_slot, 0] += self._metrics[0]
+                self._ring[ring_slot, 1] += self._metrics[1]
             B = x.shape[0]
         self.global_step += 1
         self._last_B = B

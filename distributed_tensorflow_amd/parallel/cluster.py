@@ -92,14 +92,23 @@ class StoreClient:
         self._h = self._lib.dtf_store_connect(host.encode(), port, int(timeout_s * 1000))
         if not self._h:
             raise ConnectionError("cannot reach rendezvous store at %s:%d" % (host, port))
+        # one connection, one request at a time: the heartbeat, monitor and training threads share this client
+        self._lock = threading.Lock()
+
+    def _handle(self):
+        if not self._h:
+            raise ConnectionError("store client is closed")
+        return self._h
 
     def set(self, key: str, value: bytes) -> None:
-        if self._lib.dtf_store_set(self._h, key.encode(), value, len(value)) < 0:
-            raise ConnectionError("store set failed")
+        with self._lock:
+            if self._lib.dtf_store_set(self._handle(), key.encode(), value, len(value)) < 0:
+                raise ConnectionError("store set failed")
 
     def get(self, key: str, timeout_s: float = -1.0, cap: int = 1 << 16) -> Optional[bytes]:
         buf = C.create_string_buffer(cap)
-        n = self._lib.dtf_store_get(self._h, key.encode(), buf, cap, int(timeout_s * 1000) if timeout_s >= 0 else -1)
+        with self._lock:
+            n = self._lib.dtf_store_get(self._handle(), key.encode(), buf, cap, int(timeout_s * 1000) if timeout_s >= 0 else -1)
         if n == -1:
             return None
         if n < 0:
@@ -107,16 +116,19 @@ class StoreClient:
         return buf.raw[:min(n, cap)]
 
     def add(self, key: str, delta: int = 1) -> int:
-        v = self._lib.dtf_store_add(self._h, key.encode(), delta)
+        with self._lock:
+            v = self._lib.dtf_store_add(self._handle(), key.encode(), delta)
         if v == -100:
             raise ConnectionError("store add failed")
         return v
 
     def check(self, key: str) -> bool:
-        return self._lib.dtf_store_check(self._h, key.encode()) == 1
+        with self._lock:
+            return self._lib.dtf_store_check(self._handle(), key.encode()) == 1
 
     def delete(self, key: str) -> None:
-        self._lib.dtf_store_delete(self._h, key.encode())
+        with self._lock:
+            self._lib.dtf_store_delete(self._handle(), key.encode())
 
     def counter(self, key: str) -> int:
         return self.add(key, 0)
@@ -134,9 +146,10 @@ class StoreClient:
         return self.wait_counter("barrier/" + name, world, timeout_s)
 
     def close(self) -> None:
-        if self._h:
-            self._lib.dtf_store_close(self._h)
-            self._h = None
+        with self._lock:
+            if self._h:
+                self._lib.dtf_store_close(self._h)
+                self._h = None
 
     def __del__(self):
         try:
@@ -181,6 +194,24 @@ class Heartbeat:
 
     def stop(self) -> None:
         self._stop.set()
+
+
+def job_store(rank: int, world: int, timeout_s: float = 30.0):
+    """The job's rendezvous store for ranks started by ``torchrun`` / the local launcher (no ``--ps_hosts``): rank 0 hosts
+    one on an ephemeral port (or ``DTF_STORE_PORT``) and announces the port through the already initialised process group;
+    everyone connects.  Returns ``(client, server or None)``; ``(None, None)`` for a single process."""
+    if world <= 1:
+        return None, None
+    import torch.distributed as dist
+    server = None
+    port = int(os.environ.get("DTF_STORE_PORT", "0"))
+    if rank == 0:
+        server = StoreServer(port)
+        port = server.port
+    box = [port]
+    dist.broadcast_object_list(box, src=0)
+    host = "127.0.0.1" if rank == 0 else os.environ.get("MASTER_ADDR", "127.0.0.1")
+    return StoreClient(host, int(box[0]), timeout_s=timeout_s), server
 
 
 class Server:

@@ -17,8 +17,16 @@ Equivalent behaviour here:
 * ``managed_session`` is a context manager that turns any exception into a coordinated stop
   (``request_stop``) and always runs a final save on the chief (the reference's demo2 never saves
   explicitly, quirk Q8);
-* ``should_stop()`` is cheap on the hot path: the local flag is all-reduced (max) across ranks
-  only every ``stop_check_interval`` steps, so one failing rank stops the whole job;
+* the stop flag and liveness travel OUT OF BAND, through the job's rendezvous store
+  (``csrc/host/tcp_store.cc``): ``request_stop`` sets a store key, every rank's monitor thread polls
+  it and bumps its heartbeat counter (``cluster.Heartbeat``), and a rank whose counter stops moving
+  for ``2 x period`` turns into a stop request on every survivor.  ``should_stop()`` then only reads
+  a local flag — no collective, so a rank that died cannot wedge it.  A survivor that is itself
+  blocked inside a collective on the dead rank (RCCL has no per-call timeout) cannot poll anything:
+  if the training thread has not acknowledged a failure stop within ``fatal_grace_s`` the monitor
+  ends the process with exit status 70, and the relaunched job resumes from the last checkpoint;
+* without a store (single process, or a launcher that has none) the local flag is all-reduced (max)
+  every ``stop_check_interval`` STEPS;
 * ``--fault_inject_step`` support lives in the training drivers and is exercised by the tests.
 """
 from __future__ import annotations
@@ -35,7 +43,8 @@ from ..utils import checkpoint as ckpt
 class Supervisor:
     def __init__(self, trainer, *, is_chief: bool, logdir: Optional[str], saver: Optional[ckpt.Saver] = None,
                  save_model_secs: float = 600.0, checkpoint_basename: str = "model.ckpt",
-                 stop_check_interval: int = 50, summary_writer=None, log_fn: Callable[[str], None] = print):
+                 stop_check_interval: int = 50, summary_writer=None, log_fn: Callable[[str], None] = print,
+                 store=None, heartbeat_period_s: float = 1.0, fatal_grace_s: float = 20.0):
         self.trainer = trainer
         self.engine = trainer.engine
         self.is_chief = is_chief
@@ -55,6 +64,17 @@ class Supervisor:
         self.restored_from: Optional[str] = None
         self.num_autosaves = 0
         self.last_exception: Optional[BaseException] = None
+        # out-of-band control plane (None: collective stop flag only)
+        self.store = store
+        self.heartbeat_period_s = heartbeat_period_s
+        self.fatal_grace_s = fatal_grace_s
+        self.heartbeat = None
+        self.dead_ranks: list = []
+        self.stop_reason: Optional[str] = None
+        self._monitor_thread: Optional[threading.Thread] = None
+        self._failure_seen_at: Optional[float] = None
+        self._acknowledged = False
+        self._stop_key = "sv/stop"
 
     # ------------------------------------------------------------------ init / restore
     def prepare_or_wait_for_session(self) -> int:
@@ -100,18 +120,80 @@ class Supervisor:
         if self.is_chief and self.save_path and self.save_model_secs and self.save_model_secs > 0:
             self._saver_thread = threading.Thread(target=self._saver_loop, name="dtf-saver", daemon=True)
             self._saver_thread.start()
+        if self.store is not None and self.trainer.world > 1 and self._monitor_thread is None:
+            from .cluster import Heartbeat
+            rank = getattr(self.trainer, "rank", 0)
+            self.heartbeat = Heartbeat(self.store, rank, period_s=self.heartbeat_period_s).start()
+            self._monitor_thread = threading.Thread(target=self._monitor_loop, name="dtf-monitor", daemon=True)
+            self._monitor_thread.start()
+
+    # ------------------------------------------------------------------ failure detection (out of band)
+    def _monitor_loop(self) -> None:
+        """Poll the store: the job-wide stop key and every rank's heartbeat.  Runs on every rank."""
+        world = self.trainer.world
+        period = self.heartbeat_period_s
+        t_start = time.time()
+        while not self._saver_wake.is_set():
+            try:
+                stop = self.store.counter(self._stop_key) > 0
+                # (a rank is only declared dead after it has been seen alive: start-up skew is not a failure)
+                dead = self.heartbeat.dead_ranks(world, 2.0 * period) if time.time() - t_start > 2.0 * period else []
+                dead = [r for r in dead if self.store.counter("hb/%d" % r) > 0 and self.store.counter("sv/done/%d" % r) == 0]
+            except ConnectionError:
+                stop, dead = True, []
+                self.stop_reason = self.stop_reason or "rendezvous store unreachable"
+            if dead and not self.dead_ranks:
+                self.dead_ranks = dead
+                self.stop_reason = "rank(s) %s stopped sending heartbeats" % dead
+                self.log("Supervisor: " + self.stop_reason)
+                try:
+                    self.store.add(self._stop_key, 1)
+                except ConnectionError:
+                    pass
+                stop = True
+            if stop and not self._stop_local.is_set():
+                self.stop_reason = self.stop_reason or "stop requested by a peer"
+                self._stop_local.set()
+            if stop and self._failure_seen_at is None:
+                self._failure_seen_at = time.time()
+            if (self._failure_seen_at is not None and not self._acknowledged and self.fatal_grace_s > 0
+                    and time.time() - self._failure_seen_at > self.fatal_grace_s):
+                # the training thread never came back to look at the flag: it is blocked in a collective on a dead peer
+                self.log("Supervisor: %s; training thread unresponsive for %.0f s -> exiting (status 70), "
+                         "relaunch resumes from the last checkpoint" % (self.stop_reason, self.fatal_grace_s))
+                import sys
+                for f in (sys.stdout, sys.stderr):  # (os._exit skips the interpreter's own flush)
+                    try:
+                        f.flush()
+                    except Exception:
+                        pass
+                os._exit(70)
+            time.sleep(period / 2.0)
 
     # ------------------------------------------------------------------ stop protocol
     def request_stop(self, ex: Optional[BaseException] = None) -> None:
         if ex is not None:
             self.last_exception = ex
+            self.stop_reason = self.stop_reason or "exception on this rank: %r" % (ex,)
         self._stop_local.set()
+        if self.store is not None:
+            try:
+                self.store.add(self._stop_key, 1)  # out of band: the peers learn of it without a collective
+            except ConnectionError:
+                pass
 
-    def should_stop(self, force_check: bool = False) -> bool:
-        """Collective: every rank must call it the same number of times."""
+    def should_stop(self, force_check: bool = False, steps: int = 1) -> bool:
+        """With a rendezvous store: reads the local flag the monitor thread maintains (no communication).  Without:
+        collective — every rank calls it at the same points — and the flag is all-reduced every
+        ``stop_check_interval`` STEPS (``steps`` = steps run since the previous call)."""
         if self._stop_global:
+            self._acknowledged = True
             return True
-        self._steps_since_check += 1
+        if self.store is not None and self.trainer.world > 1:
+            if self._stop_local.is_set():
+                self._stop_global = self._acknowledged = True
+            return self._stop_global
+        self._steps_since_check += max(1, steps)
         if force_check or self._steps_since_check >= self.stop_check_interval or self.trainer.world == 1:
             self._steps_since_check = 0
             self._stop_global = self.trainer.any_rank(self._stop_local.is_set())
@@ -119,11 +201,25 @@ class Supervisor:
 
     def stop(self, final_save: bool = True) -> None:
         """``sv.stop()``: stop services, final save on the chief, barrier."""
+        self._acknowledged = True
         self._stop_local.set()
         self._saver_wake.set()
         if self._saver_thread is not None:
             self._saver_thread.join(timeout=30)
             self._saver_thread = None
+        if self._monitor_thread is not None:
+            self._monitor_thread.join(timeout=5)
+            self._monitor_thread = None
+        if self.store is not None and self.trainer.world > 1:
+            # this rank is done (its heartbeat may now stop without being a failure); the chief, which usually hosts the
+            # store, stays until everyone has said so
+            try:
+                self.store.add("sv/done/%d" % getattr(self.trainer, "rank", 0), 1)
+                self.store.add("sv/done", 1)
+                if self.is_chief and not self.dead_ranks:
+                    self.store.wait_counter("sv/done", self.trainer.world, timeout_s=30.0)
+            except ConnectionError:
+                pass
         if final_save:
             try:
                 self._save("final")

@@ -139,7 +139,7 @@ def mnist_state_from_tf(engine, tensors: Dict[str, np.ndarray]) -> int:
         if tf_name + "/Adam" in tensors:
             M[k].copy_(torch.from_numpy(np.asarray(tensors[tf_name + "/Adam"], np.float32).reshape(shape)))
             V[k].copy_(torch.from_numpy(np.asarray(tensors[tf_name + "/Adam_1"], np.float32).reshape(shape)))
-    step = int(tensors.get("Variable", tensors.get("_dtf/step", 0)))
+    step = int(np.asarray(tensors.get("Variable", tensors.get("_dtf/step", 0))).reshape(-1)[0])
     sd["step"] = torch.tensor([step], dtype=torch.int32)
     engine.load_state_dict(sd)
     return step
@@ -156,8 +156,13 @@ class Saver:
         self._kept = []
 
     def save(self, save_path: str, global_step: Optional[int] = None) -> str:
+        tensors = mnist_state_to_tf(self.engine, with_global_step=self.with_global_step)
+        if global_step is not None:
+            # name the file after the step INSIDE the snapshot: the host's mirror of the step counter can be up to one
+            # multi-step graph launch ahead of what the stream-ordered snapshot saw
+            global_step = int(np.asarray(tensors.get("Variable", tensors.get("_dtf/step", global_step))).reshape(-1)[0])
         path = save_path if global_step is None else "%s-%d" % (save_path, global_step)
-        save_tensors(path, mnist_state_to_tf(self.engine, with_global_step=self.with_global_step))
+        save_tensors(path, tensors)
         update_checkpoint_state(os.path.dirname(os.path.abspath(path)) or ".", path)
         self._kept.append(path)
         while self.max_to_keep and len(self._kept) > self.max_to_keep:

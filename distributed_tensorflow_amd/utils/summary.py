@@ -22,6 +22,7 @@ import json
 import os
 import socket
 import struct
+import threading
 import time
 from typing import Dict, Iterable, List, Optional, Tuple
 
@@ -181,24 +182,32 @@ class FileWriter:
         if not self._h:
             raise OSError("cannot open event file " + self.path)
         self._jsonl = open(os.path.join(logdir, "scalars%s.jsonl" % filename_suffix), "a")
+        # One Summary is assembled in the native writer's per-handle state between begin and end: the training thread and
+        # the Supervisor's autosave thread (global_step/sec) both write through this object, so a whole add_summary is one
+        # critical section (ctypes releases the GIL during the native calls).
+        self._lock = threading.Lock()
         if graph is not None:
             blob = json.dumps(graph).encode()
             self._lib.dtf_events_graph(self._h, blob, len(blob))
 
     def add_summary(self, summary: Summary, global_step: int, wall_time: Optional[float] = None) -> None:
-        lib, h = self._lib, self._h
-        lib.dtf_events_begin(h, int(global_step), float(wall_time or 0.0))
-        for tag, v in summary.scalars:
-            lib.dtf_events_scalar(h, tag.encode(), float(v))
-        for tag, hs in summary.histograms:
-            n = len(hs["bucket_limit"])
-            lim = (C.c_double * n)(*hs["bucket_limit"])
-            cnt = (C.c_double * n)(*hs["bucket"])
-            lib.dtf_events_histogram(h, tag.encode(), hs["min"], hs["max"], hs["num"], hs["sum"], hs["sum_squares"],
-                                     n, lim, cnt)
-        lib.dtf_events_end(h)
-        if summary.scalars:
-            self._jsonl.write(json.dumps({"step": int(global_step), **{t: v for t, v in summary.scalars}}) + "\n")
+        lib = self._lib
+        with self._lock:
+            h = self._h
+            if not h:
+                return  # closed (a late write from a service thread during shutdown)
+            lib.dtf_events_begin(h, int(global_step), float(wall_time or 0.0))
+            for tag, v in summary.scalars:
+                lib.dtf_events_scalar(h, tag.encode(), float(v))
+            for tag, hs in summary.histograms:
+                n = len(hs["bucket_limit"])
+                lim = (C.c_double * n)(*hs["bucket_limit"])
+                cnt = (C.c_double * n)(*hs["bucket"])
+                lib.dtf_events_histogram(h, tag.encode(), hs["min"], hs["max"], hs["num"], hs["sum"], hs["sum_squares"],
+                                         n, lim, cnt)
+            lib.dtf_events_end(h)
+            if summary.scalars:
+                self._jsonl.write(json.dumps({"step": int(global_step), **{t: v for t, v in summary.scalars}}) + "\n")
 
     def add_scalars(self, values: Dict[str, float], global_step: int) -> None:
         s = Summary()
@@ -207,14 +216,17 @@ class FileWriter:
         self.add_summary(s, global_step)
 
     def flush(self) -> None:
-        self._lib.dtf_events_flush(self._h)
-        self._jsonl.flush()
+        with self._lock:
+            if self._h:
+                self._lib.dtf_events_flush(self._h)
+                self._jsonl.flush()
 
     def close(self) -> None:
-        if self._h:
-            self._lib.dtf_events_close(self._h)
-            self._h = None
-            self._jsonl.close()
+        with self._lock:
+            if self._h:
+                self._lib.dtf_events_close(self._h)
+                self._h = None
+                self._jsonl.close()
 
     def __enter__(self):
         return self

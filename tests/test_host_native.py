@@ -184,3 +184,34 @@ def test_trace_ranges_and_step_timer():
     s = t.summary()
     assert "images/sec" in s and "a " in s and "x3" in s
     assert trace.format_table([("k", 2, 1.0, 500.0)]).count("\n") == 1
+
+
+# ----------------------------------------------------------------------------- events writer under two threads
+def test_file_writer_add_summary_is_thread_safe(tmp_path):
+    """The Supervisor's autosave thread and the training thread write through one FileWriter: every record must stay a
+    well-formed event (CRCs verify) carrying exactly the scalars of ONE add_summary call under its own step."""
+    import threading
+    from distributed_tensorflow_amd.utils.summary import FileWriter, Summary, read_events
+    w = FileWriter(str(tmp_path))
+    n = 400
+
+    def writer(kind):
+        for i in range(n):
+            s = Summary()
+            if kind == 0:
+                s.scalar("a/x", float(i)).scalar("a/y", float(2 * i)).scalar("a/z", float(3 * i))
+                w.add_summary(s, i)
+            else:
+                w.add_scalars({"global_step/sec": float(i)}, 100000 + i)
+    th = [threading.Thread(target=writer, args=(k,)) for k in (0, 1)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    w.close()
+    ev = [e for e in read_events(w.path, verify_crc=True) if e["scalars"]]
+    assert len(ev) == 2 * n
+    for e in ev:
+        if e["step"] >= 100000:
+            assert e["scalars"] == {"global_step/sec": float(e["step"] - 100000)}
+        else:
+            i = e["step"]
+            assert e["scalars"] == {"a/x": float(i), "a/y": float(2 * i), "a/z": float(3 * i)}

@@ -1,0 +1,98 @@
+"""Retrain drivers end to end on CPU (tiny stand-in backbone): the self-contained inference bundle and ``test.py``
+(reference ``retrain1/retrain.py:470-475``, ``retrain1/test.py:10-58``), the per-step train / validation summaries with
+histograms (``retrain1/retrain.py:277-283,440-446``) and the retrain2 Supervisor: stop -> relaunch -> resume
+(``retrain2/retrain2.py:423-431,445,508``)."""
+import glob
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cli(args, cwd, timeout=600, env_extra=None):
+    env = dict(os.environ, PYTHONPATH=REPO, OMP_NUM_THREADS="2", **(env_extra or {}))
+    return subprocess.run([sys.executable] + args, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                          text=True, timeout=timeout)
+
+
+def test_retrain1_bundle_is_self_contained_and_test_py_classifies_held_out_images(tmp_path):
+    from distributed_tensorflow_amd.data import image_lists as il
+    from distributed_tensorflow_amd.utils import checkpoint as ckpt
+    from distributed_tensorflow_amd.utils.summary import read_events
+    cwd = str(tmp_path)
+    steps = 45
+    r = _cli([os.path.join(REPO, "retrain1", "retrain.py"), "--device", "cpu", "--synthetic", "--synthetic_classes", "3",
+              "--synthetic_images_per_class", "30", "--training_steps", str(steps), "--train_batch_size", "32",
+              "--validation_batch_size", "16", "--eval_step_interval", "10", "--learning_rate", "0.5", "--seed", "3",
+              "--double_softmax", "false"], cwd)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "Final test accuracy" in r.stdout
+    t = ckpt.load_tensors(os.path.join(cwd, "retrained_graph.pb"))
+    assert "backbone/tiny/proj" in t and t["backbone/tiny/proj"].shape == (192, 2048)   # the backbone travels in the bundle
+    assert t["final_training_ops/weights/final_weights"].shape == (2048, 3)
+
+    # ---- summaries: both writers got EVERY step's cross_entropy / accuracy under its true step index, and the
+    # variable summaries + pre_activations / activations histograms at the logging points
+    for split in ("train", "validation"):
+        ev = []
+        for f in glob.glob(os.path.join(cwd, "retrain_logs", split, "events.out.tfevents.*")):
+            ev += read_events(f)
+        ce_steps = sorted(e["step"] for e in ev if "cross_entropy" in e["scalars"])
+        assert ce_steps == list(range(steps)), (split, ce_steps[:5], len(ce_steps))
+        assert all("accuracy" in e["scalars"] for e in ev if "cross_entropy" in e["scalars"])
+        hist = [e for e in ev if e["histograms"]]
+        assert sorted(e["step"] for e in hist) == [0, 10, 20, 30, 40, 44]
+        tags = set(hist[0]["histograms"])
+        assert {"final_training_ops/Wx_plus_b/pre_activations", "final_training_ops/activations"} <= tags, tags
+        assert any(k.startswith("final_training_ops/weights") for k in tags)
+        assert hist[0]["histograms"]["final_training_ops/activations"]["num"] == (32 if split == "train" else 16) * 3
+    tr = []
+    for f in glob.glob(os.path.join(cwd, "retrain_logs", "train", "events.out.tfevents.*")):
+        tr += read_events(f)
+    ce = [e["scalars"]["cross_entropy"] for e in sorted(tr, key=lambda e: e.get("step", 0)) if "cross_entropy" in e["scalars"]]
+    assert np.mean(ce[-5:]) < np.mean(ce[:5])
+
+    # ---- inference script on images the training never saw (another seed of the same generator)
+    held = il.make_synthetic_image_dir(os.path.join(cwd, "held_out"), num_classes=3, images_per_class=8, seed=999)
+    r2 = _cli([os.path.join(REPO, "retrain1", "test.py"), "--imgs", held, "--device", "cpu"], cwd)
+    assert r2.returncode == 0, r2.stdout[-3000:]
+    files = [l for l in r2.stdout.splitlines() if l.endswith(".jpg")]
+    top1 = [l[3:] for l in r2.stdout.splitlines() if l.startswith("=> ")]
+    assert len(files) == len(top1) == 24
+    truth = [os.path.basename(os.path.dirname(f)).replace("_", " ") for f in files]
+    acc = np.mean([a == b for a, b in zip(top1, truth)])
+    assert acc >= 0.9, (acc, list(zip(top1, truth))[:6])
+    assert re.search(r"class 0\d \(score = 0\.\d{5}\)", r2.stdout)
+
+
+def test_retrain2_stop_relaunch_resume_two_ranks(tmp_path):
+    """A fault on the last rank at step 12: every rank stops (out-of-band stop flag through the job's store), the chief
+    saves ./logs/model.ckpt-<step>, the job exits non-zero; the relaunch restores it on the chief, broadcasts, continues
+    from that global step and exports."""
+    cwd = str(tmp_path)
+    common = ["--num_gpus", "2", "--backend", "gloo", "--device", "cpu", "--synthetic", "--synthetic_classes", "3",
+              "--synthetic_images_per_class", "20", "--train_batch_size", "16", "--validation_batch_size", "8",
+              "--eval_step_interval", "5", "--learning_rate", "0.5", "--seed", "5", "--save_model_secs", "0",
+              "--double_softmax", "false"]
+    env = {"DTF_HEARTBEAT_PERIOD_S": "0.2", "MASTER_PORT": "29712"}
+    r = _cli([os.path.join(REPO, "retrain2", "retrain2.py"), "--training_steps", "30", "--fault_inject_step", "12"] + common,
+             cwd, env_extra=env)
+    assert r.returncode != 0, r.stdout[-2000:]
+    assert "injected fault at step 12" in r.stdout and "Supervisor: final checkpoint" in r.stdout, r.stdout[-3000:]
+    saved = glob.glob(os.path.join(cwd, "logs", "model.ckpt-*"))
+    assert saved, r.stdout[-2000:]
+    step = max(int(p.rsplit("-", 1)[1]) for p in saved)
+    assert 12 <= step < 30
+    assert not os.path.exists(os.path.join(cwd, "retrained_graph.pb"))
+    env["MASTER_PORT"] = "29713"
+    r2 = _cli([os.path.join(REPO, "retrain2", "retrain2.py"), "--training_steps", "30"] + common, cwd, env_extra=env)
+    assert r2.returncode == 0, r2.stdout[-3000:]
+    assert "restored" in r2.stdout and ("global_step=%d" % step) in r2.stdout
+    first = min(int(m) for m in re.findall(r"Step (\d+):", r2.stdout))
+    assert first >= step, (first, step)
+    assert "Final test accuracy" in r2.stdout and os.path.exists(os.path.join(cwd, "retrained_graph.pb"))
+    assert os.path.exists(os.path.join(cwd, "logs", "model.ckpt-30"))
