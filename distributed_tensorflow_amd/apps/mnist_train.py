@@ -135,6 +135,10 @@ def run(FLAGS, distributed: bool) -> int:
     try:
         while step < FLAGS.training_steps and not (sv is not None and sv.should_stop(steps=burst)):
             if FLAGS.fault_inject_step >= 0 and step == FLAGS.fault_inject_step and rank == world - 1:
+                if os.environ.get("DTF_FAULT_KIND", "raise") == "die":
+                    # the process vanishes (a killed worker, a lost node): nothing is said to anybody
+                    print("rank %d: injected death at step %d" % (rank, step), flush=True)
+                    os._exit(9)
                 raise RuntimeError("injected fault at step %d" % step)
             # run up to the next point where the host has something to do (evaluation, summary flush, fault
             # injection, end of training; the stop flag is polled at least every 64 steps): the engine replays
@@ -190,9 +194,10 @@ def run(FLAGS, distributed: bool) -> int:
             _log(rank, "Throughput: %.1f images/sec (%d steps x global batch %d)" % (
                 done * FLAGS.batch_size * world / max(1e-9, elapsed), done, FLAGS.batch_size * world))
         if sv is not None:
-            # (a rank that failed does not write; on a coordinated stop the chief, whose loop ended through
-            # should_stop(), saves the last consistent state)
-            sv.stop(final_save=(rc == 0 or world == 1))
+            # the chief saves whenever it is still alive — its loop ended through should_stop(), or its collective was
+            # torn down under it by a peer that failed: parameters only change after a completed gradient exchange, so
+            # its state is that of the last completed step (tf.train.Supervisor's chief saves on stop the same way)
+            sv.stop(final_save=True)
         elif rank == 0:
             path = ckpt.Saver(engine, with_global_step=False).save(FLAGS.checkpoint_path)
             _log(rank, "Saved checkpoint " + path)
@@ -204,11 +209,10 @@ def run(FLAGS, distributed: bool) -> int:
             store_server.stop()
         if server is not None:
             server.report_done()
-    stopped_early = sv is not None and rc == 0 and engine.global_step < FLAGS.training_steps
-    if stopped_early:
+    if sv is not None and engine.global_step < FLAGS.training_steps:
         _log(rank, "stopped at global step %d of %d (%s)" % (engine.global_step, FLAGS.training_steps,
                                                              sv.stop_reason or "stop requested"))
-        return 3  # (no barrier: the rank that failed is not coming)
+        return rc or 3  # (no barrier: the rank that failed is not coming)
     if world > 1:
         import torch.distributed as dist
         if dist.is_initialized() and rc == 0:

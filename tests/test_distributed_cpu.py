@@ -141,3 +141,24 @@ def test_fault_injection_stops_all_ranks(tmp_path):
               "--save_model_secs", "0", "--seed", "2"], cwd, timeout=300)
     assert r.returncode != 0
     assert "injected fault at step 3" in r.stdout
+    # the survivor (the chief) leaves its loop through the out-of-band stop flag and saves the last consistent state
+    assert "stopped at global step" in r.stdout and "Supervisor: final checkpoint" in r.stdout, r.stdout[-3000:]
+    saved = [f for f in os.listdir(os.path.join(cwd, "logs")) if f.startswith("model.ckpt-")]
+    assert saved and all(3 <= int(f.rsplit("-", 1)[1].split(".")[0]) < 40 for f in saved), saved
+
+
+def test_rank_that_dies_silently_ends_the_job_in_bounded_time(tmp_path):
+    """The last rank disappears (os._exit) without telling anyone: the survivor is either thrown out of its collective
+    by the transport or stopped by the heartbeat monitor; either way the job ends non-zero well within a minute."""
+    import time
+    cwd = str(tmp_path)
+    env = dict(os.environ, PYTHONPATH=REPO, OMP_NUM_THREADS="2", DTF_FAULT_KIND="die", DTF_HEARTBEAT_PERIOD_S="0.25",
+               DTF_FATAL_GRACE_S="5")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(REPO, "demo2", "train.py"), "--num_gpus", "2", "--training_steps",
+                        "100000", "--device", "cpu", "--synthetic", "true", "--eval_step_interval", "100000",
+                        "--batch_size", "10", "--fault_inject_step", "5", "--save_model_secs", "0", "--seed", "2"],
+                       cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    dt = time.time() - t0
+    assert r.returncode != 0 and "injected death at step 5" in r.stdout, r.stdout[-3000:]
+    assert dt < 90, dt

@@ -180,6 +180,37 @@ def test_retrain_end_to_end_inception_small(tmp_path):
         os.chdir(cwd)
 
 
+def test_retrain1_then_test_py_on_held_out_jpegs(tmp_path):
+    """The retrained bundle is self-contained (folded Inception backbone + head): ``retrain1/test.py`` loads nothing but
+    ``retrained_graph.pb`` / ``retrained_labels.txt`` and classifies JPEGs the training never saw
+    (reference ``retrain1/test.py:10-58``)."""
+    import subprocess
+    import sys
+    import numpy as np
+    from distributed_tensorflow_amd.data import image_lists as il
+    from distributed_tensorflow_amd.utils import checkpoint as ckpt
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    w = str(tmp_path)
+    env = dict(os.environ, PYTHONPATH=repo)
+    r = subprocess.run([sys.executable, "-u", os.path.join(repo, "retrain1", "retrain.py"), "--synthetic",
+                        "--synthetic_classes", "3", "--synthetic_images_per_class", "40", "--training_steps", "200",
+                        "--eval_step_interval", "50", "--seed", "3"], cwd=w, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-3000:]
+    t = ckpt.load_tensors(os.path.join(w, "retrained_graph.pb"))
+    assert any(k.startswith("backbone/") for k in t) and "backbone/tiny/proj" not in t   # the real Inception travels
+    held = il.make_synthetic_image_dir(os.path.join(w, "held_out"), num_classes=3, images_per_class=10, seed=4242)
+    r2 = subprocess.run([sys.executable, "-u", os.path.join(repo, "retrain1", "test.py"), "--imgs", held], cwd=w, env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=200)
+    assert r2.returncode == 0, r2.stdout[-3000:]
+    files = [l for l in r2.stdout.splitlines() if l.endswith(".jpg")]
+    top1 = [l[3:] for l in r2.stdout.splitlines() if l.startswith("=> ")]
+    assert len(files) == len(top1) == 30
+    truth = [os.path.basename(os.path.dirname(f)).replace("_", " ") for f in files]
+    acc = np.mean([a == b for a, b in zip(top1, truth)])
+    assert acc >= 0.9, (acc, r.stdout[-1500:])
+
+
 def test_retrain2_two_ranks_one_gpu(tmp_path):
     """retrain2 (the distributed retrain): 2 ranks sharing the test GPU shard the bottleneck extraction, all-gather the
     cache, all-reduce the head gradients every step (host-staged on the gloo group) and rank 0 exports graph + labels."""
