@@ -63,7 +63,9 @@ struct EventsWriter {
   void loop() {
     std::unique_lock<std::mutex> l(mu);
     while (!stop) {
-      cv.wait_for(l, std::chrono::milliseconds(2000));
+      // (wait_until on the system clock = pthread_cond_timedwait, which the ThreadSanitizer runtime of this toolchain
+      // models; wait_for's pthread_cond_clockwait is invisible to it and yields false "double lock" reports)
+      cv.wait_until(l, std::chrono::system_clock::now() + std::chrono::milliseconds(2000));
       l.unlock();
       drain(true);
       l.lock();

@@ -170,6 +170,12 @@ def run(FLAGS, distributed: bool) -> int:
                 _log(rank, "Iter " + str(last) + ", test_acc: " + str(test_acc) + ", train_acc = " + str(train_acc))
                 if FLAGS.check_replicas and not trainer.replicas_in_sync():
                     raise RuntimeError("replica parameter checksums diverged at step %d" % last)
+                if FLAGS.check_replicas and world > 1 and step < FLAGS.training_steps - 2:
+                    # one checked step: what the optimizer consumed vs. the host-ordered sum of the local gradients
+                    dev = trainer.check_exchange()
+                    step = engine.global_step
+                    _log(rank, "checked step %d: exchanged gradient deviates %.2g from the sum of the local gradients"
+                         % (step - 1, dev))
                 if writer is not None:
                     s = Summary().scalar("eval/test_accuracy", test_acc).scalar("eval/train_accuracy", train_acc)
                     if FLAGS.variable_summaries:

@@ -77,9 +77,14 @@ class MnistEngineStruct(C.Structure):  # csrc/hip/engine.hip: struct MnistEngine
 
 def _ensure_built(name: str) -> str:
     path = os.path.join(_LIBDIR, name)
-    if not os.path.exists(path):
-        from . import build
-        (build.build_hip if "hip" in name else build.build_host)()
+    from . import build
+    which = "hip" if "hip" in name else "host"
+    stale = os.path.exists(path) and os.path.isdir(build.CSRC) and not build.is_current(which)
+    if stale and os.environ.get("DTF_ALLOW_STALE_LIB", "0") == "1":
+        stale = False
+    if not os.path.exists(path) or stale:
+        # (a library that was not built from the sources next to it is rebuilt, never used silently)
+        (build.build_hip if which == "hip" else build.build_host)()
     if not os.path.exists(path):
         raise NativeError("native library %s is missing and could not be built" % path)
     return path
@@ -100,6 +105,7 @@ def hip() -> C.CDLL:
         lib = C.CDLL(_ensure_built("libdtf_hip.so"))
         P, I, L, F = c_void_p, c_int, c_long, c_float
         _sig(lib, "dtf_version", I, [])
+        _sig(lib, "dtf_hip_source_digest", c_char_p, [])
         _sig(lib, "dtf_fc_fwd", I, [P, I, P, P, I, I, I, I, P, I, P])
         _sig(lib, "dtf_fc_bwd_data", I, [P, P, P, I, I, I, I, P])
         _sig(lib, "dtf_fc_dw", I, [P, I, P, P, I, I, I, I, P])
@@ -192,6 +198,7 @@ def host() -> C.CDLL:
             return _host
         lib = C.CDLL(_ensure_built("libdtf_host.so"))
         P, I = c_void_p, c_int
+        _sig(lib, "dtf_host_source_digest", c_char_p, [])
         _sig(lib, "dtf_crc32c", C.c_uint32, [P, c_uint64])
         _sig(lib, "dtf_masked_crc32c", C.c_uint32, [P, c_uint64])
         _sig(lib, "dtf_events_open", P, [c_char_p])

@@ -659,6 +659,68 @@ class DataParallelTrainer:
             dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
         return bool(torch.equal(lo.cpu(), hi.cpu()))
 
+    def check_exchange(self, tol: float = 2e-3) -> float:
+        """Debug assertion on the gradient exchange itself (``--check_replicas``).  ONE checked step:
+
+        1. this rank's local gradient of the coming step is computed with no exchange at all and summed over the ranks by
+           the process group, host-ordered on its own stream (the reference);
+        2. the step then runs through the production schedule (IPC kernels / RCCL inside the step graph / bucketed
+           process-group calls), and the gradient the optimizer actually consumed is recovered from Adam's first moment,
+           ``m' = b1 m + (1 - b1) g``.
+
+        Both passes draw the same batch and the same dropout mask (keyed by the step counter).  A stream-ordering bug —
+        the optimizer running before the exchange has landed, a bucket reduced before its producer finished — shows as a
+        deviation here long before the loss curve notices.  Returns the relative deviation (max over ranks); raises
+        beyond ``tol``.  Collective; advances training by exactly one (production) step."""
+        if not (self._multi and self.sync):
+            return 0.0
+        e = self.engine
+        if getattr(e, "dataset", None) is not None and e.spe - (e.global_step % e.spe) < 2:
+            self.train_steps(1)  # (not across the reshuffle at an epoch boundary)
+        b1 = float(e.cfg.beta1) if hasattr(e, "cfg") else float(getattr(e, "b1", 0.9))
+        if self._native:
+            cfg, keep = e.cfg, (e.cfg.G_fc1_dst, e.cfg.G_src, e.cfg.gather_n)
+            with self._ctx():
+                ring = e.metrics_ring.clone()
+            cfg.G_fc1_dst, cfg.G_src, cfg.gather_n = None, None, 0   # plain local gradients into G (graphs are untouched:
+            try:                                                      # their arguments were bound at capture)
+                with torch.cuda.stream(e.stream):
+                    e.G.zero_()
+                    e.fwd_bwd(3)
+            finally:
+                cfg.G_fc1_dst, cfg.G_src, cfg.gather_n = keep
+            with self._ctx():
+                ref = e.G.clone()
+                e.G.zero_()
+                e.metrics_ring.copy_(ring)  # (the local pass added this step's loss / accuracy once already)
+                self._reduce(ref)
+                m0 = e.M.clone()
+            scale = 1.0
+        else:
+            gen = e._gen.get_state()
+            ring = e._ring.copy()
+            e.fwd_bwd(3)
+            e._gen.set_state(gen)
+            e._ring[:] = ring
+            ref = e.G.clone()
+            e.G.zero_()
+            dist.all_reduce(ref, group=self.group)
+            m0 = e.M.clone()
+            scale = 1.0 / self.world
+        self.train_steps(1)
+        with self._ctx():
+            # compared in first-moment space (recovering g itself cancels catastrophically once |g| << |m|); the floor
+            # keeps the rounding of m' (~6e-8 |m'|) below the tolerance when the gradient has all but vanished
+            want = b1 * m0 + (1.0 - b1) * scale * ref
+            dev = (e.M - want).norm() / ((1.0 - b1) * scale * ref.norm() + 1e-4 * e.M.norm() + 1e-30)
+            t = dev.double().reshape(1).to("cpu" if self._stage_host else e.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        dev = float(t.item())
+        if not dev < tol:
+            raise AssertionError("gradient exchange (%s): the optimizer consumed a gradient that deviates %.3g from the sum "
+                                 "of the ranks' local gradients" % (self.schedule or self.comm, dev))
+        return dev
+
     def all_reduce_scalars(self, values) -> list:
         """Sum a few python floats across ranks (logging points only)."""
         if self.world == 1:

@@ -43,11 +43,30 @@ def _worker(rank, world, initfile, outdir, mode):
         res["P0"], res["P1"] = p0, eng.P.clone()
         res["in_sync_after_step"] = tr.replicas_in_sync()
     elif mode == "train":
-        for _ in range(6):
+        res["exchange_dev"] = tr.check_exchange()     # one checked step (debug assertion on the exchange itself)
+        res["in_sync_after_check"] = tr.replicas_in_sync()
+        # a broken exchange (rank 1's gradient never arrives in the production pass) must trip the assertion
+        real = dist.all_reduce
+
+        def lossy(t, *a, **k):
+            if t.data_ptr() == eng.G.data_ptr() and rank == 1:
+                t.zero_()
+            return real(t, *a, **k)
+        dist.all_reduce = lossy
+        try:
+            tr.check_exchange()
+            res["caught"] = False
+        except AssertionError:
+            res["caught"] = True
+        finally:
+            dist.all_reduce = real
+        tr.broadcast_state(0)
+        for _ in range(4):
             tr.train_step()
         res["P"] = eng.P.clone()
         res["in_sync"] = tr.replicas_in_sync()
         res["scalars"] = tr.all_reduce_scalars([1.0, rank])
+        res["steps"] = eng.global_step
     elif mode == "async":
         for _ in range(4):
             tr.train_step()
@@ -95,6 +114,8 @@ def test_dp2_training_keeps_replicas_identical():
     res, _ = _run("train")
     assert res[0]["in_sync"] and torch.equal(res[0]["P"], res[1]["P"])
     assert res[0]["scalars"] == [2.0, 1.0]
+    assert res[0]["exchange_dev"] < 1e-5 and res[0]["in_sync_after_check"] and res[0]["steps"] == 6
+    assert res[0]["caught"] and res[1]["caught"]
 
 
 def test_async_emulation_averages_parameters():

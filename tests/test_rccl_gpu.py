@@ -143,3 +143,54 @@ def test_expired_ipc_wait_skips_the_optimizer_on_every_rank(tmp_path):
         assert o["healthy"] is False and o["transport_after"] == "rccl" and o["in_sync"] is True, o
         assert o["host_step"] == o["device_step"] == o["step_before"] + 5, o
     assert max(o["errors"] for o in res) >= 1 and min(o["errors"] for o in res) == 0, res
+
+
+_CHECKED = r"""
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from distributed_tensorflow_amd.data import mnist
+from distributed_tensorflow_amd.engine.mnist_engine import NativeMnistEngine
+from distributed_tensorflow_amd.parallel.ddp import DataParallelTrainer, init_process_group
+rank, world = init_process_group("gloo")
+torch.cuda.set_device(0)
+imgs, labels = mnist.synthetic_mnist(4000, seed=1)
+d = mnist.DataSet(mnist._scale_flatten(imgs), mnist.dense_to_one_hot(labels), seed=1)
+dd = mnist.DeviceDataset(d, "cuda:0", rank=rank, world=world, seed=1)
+eng = NativeMnistEngine(dd, batch_size=100, seed=5, lr=1e-4, device="cuda:0", dtype=sys.argv[2])
+tr = DataParallelTrainer(eng, comm="ipc")
+out = {"rank": rank, "schedule": tr.schedule, "dev": []}
+tr.train_steps(3)
+for _ in range(2):
+    out["dev"].append(tr.check_exchange())
+    tr.train_steps(17)
+out["in_sync"] = tr.replicas_in_sync()
+out["host_step"], out["device_step"] = eng.global_step, int(eng.step_t.item())
+lm, am = eng.read_metrics(0, eng.global_step)
+out["loss_first"], out["loss_last"] = float(lm[:5].mean()), float(lm[-5:].mean())
+print("RESULT " + json.dumps(out), flush=True)
+dist.barrier()
+tr.close()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("schedule,dtype", [("ipc-inline", "fp32"), ("ipc-zerocopy", "fp32"), ("ipc-gather", "bf16"),
+                                            ("ipc-inline", "bf16")])
+def test_checked_step_validates_the_production_exchange(tmp_path, schedule, dtype):
+    """``check_exchange`` (the ``--check_replicas`` assertion): the gradient the optimizer consumed under the production
+    schedule equals the host-ordered sum of the ranks' local gradients; the checked step leaves counters, metrics and
+    replicas consistent."""
+    script = tmp_path / "checked.py"
+    script.write_text(_CHECKED)
+    env = dict(os.environ, MASTER_PORT="29644", HSA_ENABLE_IPC_MODE_LEGACY="0", DTF_DP_SCHEDULE=schedule)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29644", str(script), REPO, dtype]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    res = [json.loads(l.split("RESULT ", 1)[1]) for l in r.stdout.splitlines() if "RESULT " in l]
+    assert len(res) == 2, r.stdout[-3000:]
+    for o in res:
+        assert o["schedule"] == schedule and max(o["dev"]) < 2e-3, o
+        assert o["in_sync"] and o["host_step"] == o["device_step"] == 3 + 2 * 18, o
+        assert 1.5 < o["loss_last"] < o["loss_first"] + 0.05 < 2.6, o   # (the checked steps did not double-count metrics)
