@@ -184,7 +184,7 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
     const int ipw = e->dw2_splits > 0 && e->dw2_splits <= 16 ? e->dw2_splits : 4;
     if (e->f32)
       DTF_TRY(dtf_conv2_bwd_data_f32(e->dpool2, (const float*)e->pool2, e->amax2, e->P + e->off_Wc2, (const float*)e->pool1,
-                                     e->dpool1, e->G + e->off_bc2, B, st));
+                                     e->dpool1, B, st));
     else
       DTF_TRY(dtf_conv2_bwd_data_lds_packed(e->dpool2, e->pool2, e->amax2, e->wc2b, e->pool1, e->dpool1, e->G + e->off_bc2, B,
                                             st));
@@ -199,7 +199,8 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
       fc1.skip = e->skip;
     }
     if (e->f32)
-      DTF_TRY(dtf_conv_dw_duo_f32(e->dpool2, (const float*)e->pool2, e->amax2, (const float*)e->pool1, e->G + e->off_Wc2, B,
+      DTF_TRY(dtf_conv_dw_duo_f32(e->dpool2, (const float*)e->pool2, e->amax2, (const float*)e->pool1, e->G + e->off_Wc2,
+                                  e->G + e->off_bc2, B,
                                   e->images, e->perm, e->step, e->spe, e->dpool1, e->amax1, e->G + e->off_Wc1,
                                   e->G + e->off_bc1, early_adam ? &fc1 : nullptr, st));
     else

@@ -24,14 +24,16 @@
 #ifdef DTF_CONV_STAMPS
 __device__ unsigned long long* g_conv_stamps;
 DTF_API int dtf_dbg_set_conv_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps), &p, sizeof(p)); }
-#define CSTAMP(i) do { if (threadIdx.x == 0 && g_conv_stamps) { g_conv_stamps[blockIdx.x * 32 + 2 * (i)] = __builtin_amdgcn_s_memtime(); \
-  g_conv_stamps[blockIdx.x * 32 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define CSTAMP_AT(bid, i) do { if (threadIdx.x == 0 && g_conv_stamps) { g_conv_stamps[(bid) * 32 + 2 * (i)] = __builtin_amdgcn_s_memtime(); \
+  g_conv_stamps[(bid) * 32 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define CSTAMP(i) CSTAMP_AT(blockIdx.x, i)
 // per-wave: loop-end clock and HW_ID (SIMD / CU placement) at g_conv_stamps[workgroup][32 .. 47] / [48 .. 63]
 #define CSTAMP_WAVE() do { if ((threadIdx.x & 63) == 0 && g_conv_stamps) { \
   g_conv_stamps[gridDim.x * 32 + blockIdx.x * 32 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime(); \
   g_conv_stamps[gridDim.x * 32 + blockIdx.x * 32 + 16 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); } } while (0)
 #else
 #define CSTAMP(i) do { } while (0)
+#define CSTAMP_AT(bid, i) do { } while (0)
 #define CSTAMP_WAVE() do { } while (0)
 #endif
 
@@ -41,8 +43,6 @@ constexpr int XP = 36;                  // floats per input halo pixel (32 ch + 
 constexpr int XIMG = 18 * 18 * XP;      // 11 664 floats
 constexpr int DP = 68;                  // floats per dY halo pixel (64 ch + 4 pad)
 constexpr int DIMG = 18 * 18 * DP;      // 22 032 floats
-constexpr int BWD_RED = 4 * 13 * 256;
-constexpr int BWD_LDS = ((DIMG > BWD_RED ? DIMG : BWD_RED) + 64) * 4;
 }  // namespace
 
 // ------------------------------------------------------------------ forward + bias + ReLU + 2x2 max-pool
@@ -129,6 +129,11 @@ __global__ __launch_bounds__(512) void conv2_fwd_f32_kernel(const float* __restr
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // A fragments are read one tap ahead as well, so a wave's own instruction stream never waits for LDS between two taps
+  // (with "oldest wave first" issue the younger wave of a SIMD only fills the older one's gaps, and runs alone at the end)
+  float2 af[FWD_MT], afn[FWD_MT];
+#pragma unroll
+  for (int mt = 0; mt < FWD_MT; ++mt) af[mt] = *reinterpret_cast<const float2*>(img + abase[mt]);
 #pragma unroll 1
   for (int dy = 0; dy < 5; ++dy) {
     const int dyn = dy < 4 ? dy + 1 : 4;  // (the last prefetch re-reads row 4)
@@ -139,10 +144,11 @@ __global__ __launch_bounds__(512) void conv2_fwd_f32_kernel(const float* __restr
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int dx = 0; dx < 5; ++dx) {
-      const int toff = (dy * 18 + dx) * XP;
-      float2 af[FWD_MT];
+      // next tap in (dy, dx) order; after the last one the read is a harmless repeat of tap (4, 4)
+      const int toffn = dx < 4 ? (dy * 18 + dx + 1) * XP : ((dy < 4 ? dy + 1 : 4) * 18 + (dy < 4 ? 0 : 4)) * XP;
 #pragma unroll
-      for (int mt = 0; mt < FWD_MT; ++mt) af[mt] = *reinterpret_cast<const float2*>(img + abase[mt] + toff);
+      for (int mt = 0; mt < FWD_MT; ++mt) afn[mt] = *reinterpret_cast<const float2*>(img + abase[mt] + toffn);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mt = 0; mt < FWD_MT; ++mt) {
         acc[mt][0] = mfma16f32(af[mt].x, bcur[dx][0], acc[mt][0]);
@@ -153,8 +159,10 @@ __global__ __launch_bounds__(512) void conv2_fwd_f32_kernel(const float* __restr
         acc[mt][0] = mfma16f32(af[mt].y, bcur[dx][2], acc[mt][0]);
         acc[mt][1] = mfma16f32(af[mt].y, bcur[dx][3], acc[mt][1]);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < FWD_MT; ++mt) af[mt] = afn[mt];
     }
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int dx = 0; dx < 5; ++dx)
 #pragma unroll
@@ -229,144 +237,236 @@ struct UnpoolTask32 {
 };
 }  // namespace
 
-// ------------------------------------------------------------------ data gradient + un-pool + ReLU mask + bias gradient
-// grid (B, 2): input channels [16 y, 16 y + 16).  dpool2 fp32 [B,49,64]; pool2 fp32 [B,49,64]; amax2 u8 [B,49,64];
-// W fp32 HWIO [25][32][64]; pool1 fp32 [B,196,32] (ReLU mask of the layer below); dpool1 fp32 [B,196,32]; db2[64] (atomics)
-__global__ __launch_bounds__(256) void conv2_bwd_data_f32_kernel(const float* __restrict__ dpool2, const float* __restrict__ pool2,
+// ------------------------------------------------------------------ data gradient + un-pool + ReLU mask
+// Same shape as the forward: one workgroup = 80 consecutive input positions (5 MFMA row tiles) of the batch's 196*B x all 32
+// input channels; 245 workgroups at batch 100.  All 8 waves split K: wave w takes output channels [8w, 8w + 8) of every tap
+// (two k-steps per tap, 500 MFMAs on 10 accumulator tiles, like the forward); the eight partial sums are combined through
+// LDS.  80 positions touch at most 7 image rows of at most two images: only the halo rows those need (<= 15 rows of
+// 18 x 68 floats) are un-pooled into LDS.  The bias gradient is produced by the filter-gradient launch, which stages dY
+// per image anyway.
+// grid ceil(196 B / 80); 512 threads.  dpool2 fp32 [B,49,64]; pool2 fp32 [B,49,64]; amax2 u8 [B,49,64]; W fp32 HWIO
+// [25][32][64]; pool1 fp32 [B,196,32] (ReLU mask of the layer below); dpool1 fp32 [B,196,32]
+namespace {
+constexpr int BD_POS = 80, BD_MT = BD_POS / 16;
+constexpr int BD_ROWS = 15;
+constexpr int BD_IMG = BD_ROWS * 18 * DP;        // 18 360 floats
+constexpr int BD_RED = 8 * BD_MT * 2 * 256;      // [wave][tile][lane][4]: 20 480 floats
+constexpr int BD_LDS = (BD_IMG > BD_RED ? BD_IMG : BD_RED) * 4;
+}  // namespace
+
+__global__ __launch_bounds__(512) void conv2_bwd_data_f32_kernel(const float* __restrict__ dpool2, const float* __restrict__ pool2,
                                                                  const uint8_t* __restrict__ amax2, const float* __restrict__ W,
                                                                  const float* __restrict__ pool1, float* __restrict__ dpool1,
-                                                                 float* __restrict__ db2) {
+                                                                 const int B) {
   extern __shared__ __attribute__((aligned(16))) float smem32[];
   float* dimg = smem32;
-  float* dbs = smem32 + (DIMG > BWD_RED ? DIMG : BWD_RED);
-  const int b = blockIdx.x, n0 = blockIdx.y * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int k0 = 16 * wave;  // this wave's output channels [k0, k0 + 16) of every tap
+  const int k0 = 8 * wave;  // this wave's output channels [k0, k0 + 8) of every tap
+  const int npos = 196 * B;
+  const int P0 = blockIdx.x * BD_POS;
+  const int b0 = P0 / 196;
+  const int plast = min(P0 + BD_POS, npos) - 1;
+  const bool two = plast / 196 != b0;  // (workgroup-uniform, like everything up to the task decode)
+  CSTAMP(0);
+  // slot 0 = image b0, output rows [ylo0, yhi0]; slot 1 = image b0 + 1, output rows [0, yhi1].  Output row y reads halo
+  // rows y .. y + 4 (halo row = image row + 2): slot 0 stages halo rows [ylo0, yhi0 + 4] at LDS rows 0.., slot 1 halo rows
+  // [0, yhi1 + 4] behind them.
+  const int ylo0 = (P0 - b0 * 196) / 14;
+  const int yhi0 = two ? 13 : (plast - b0 * 196) / 14;
+  const int yhi1 = two ? (plast - (b0 + 1) * 196) / 14 : -5;
+  const int nrow0 = yhi0 - ylo0 + 5, nrow1 = yhi1 + 5;
+  // window rows whose image rows fall into the staged halo rows
+  const int py0lo = max(ylo0 - 2, 0) >> 1, py0hi = min(yhi0 + 2, 13) >> 1;
+  const int nwr0 = py0hi - py0lo + 1;
+  const int nwr1 = two ? (min(yhi1 + 2, 13) >> 1) + 1 : 0;
+  const int ntask = (nwr0 + nwr1) * 112;  // (window row, px 0..6, 4-channel group 0..15); <= 6 window rows in all
 
-  // B fragment of (flipped) tap t': elements j = W[24 - t'][n0 + r][k0 + 4q + j]
-  const float* wbase = W + (long)(n0 + r) * 64 + k0 + 4 * q;
+  // B fragments of (flipped) tap t': elements j = W[24 - t'][16 nt + r][k0 + 2q + j]
+  const float* wbase = W + (long)r * 64 + k0 + 2 * q;
   // (a whole filter row one row ahead, pinned: see conv2_fwd_f32_kernel)
-  f32x4 bcur[5], bnxt[5];
+  float2 bcur[5][2], bnxt[5][2];
 #pragma unroll
-  for (int dx = 0; dx < 5; ++dx) bcur[dx] = *reinterpret_cast<const f32x4*>(wbase + (long)(24 - dx) * 2048);
+  for (int dx = 0; dx < 5; ++dx)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) bcur[dx][nt] = *reinterpret_cast<const float2*>(wbase + (long)(24 - dx) * 2048 + nt * 1024);
 
-  UnpoolTask32 ut[4];
+  UnpoolTask32 ut[2];
+  int trow[2], tcol[2], tslot[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int task = tid + 256 * i;  // 784 tasks: window = task >> 4, channel group = task & 15 (= tid & 15 for every i)
-    ut[i].load(dpool2, pool2, amax2, (long)b * 3136 + (task < 784 ? task * 4 : 0));
+  for (int i = 0; i < 2; ++i) {
+    const int task = tid + 512 * i;
+    const int t = task < ntask ? task : 0;
+    const int wr = t / 112, rem = t - wr * 112;
+    const int slot = wr >= nwr0 ? 1 : 0;
+    const int py = slot ? wr - nwr0 : py0lo + wr;
+    const int px = rem >> 4;
+    tslot[i] = slot; trow[i] = py; tcol[i] = px;
+    ut[i].load(dpool2, pool2, amax2, ((long)(b0 + slot) * 49 + py * 7 + px) * 64 + (rem & 15) * 4);
   }
-  if (tid < 64) dbs[tid] = 0.f;
-  for (int c = tid; c < DIMG / 4; c += 256) *reinterpret_cast<f32x4*>(dimg + c * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  CSTAMP(5);
+  {
+    const int n4 = (nrow0 + nrow1) * (18 * DP / 4);
+    for (int c = tid; c < n4; c += 512) *reinterpret_cast<f32x4*>(dimg + c * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   __syncthreads();
-  f32x4 gsum = {0.f, 0.f, 0.f, 0.f};
+  CSTAMP(6);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int task = tid + 256 * i;
-    if (task < 784) {
+  for (int i = 0; i < 2; ++i) {
+    const int task = tid + 512 * i;
+    if (task < ntask) {
       ut[i].mask();
-      const int win = task >> 4, py = win / 7, px = win - py * 7;
-      ut[i].store(dimg + (task & 15) * 4, py, px, 18, DP, 2, 2);
-      gsum[0] += ut[i].g[0]; gsum[1] += ut[i].g[1]; gsum[2] += ut[i].g[2]; gsum[3] += ut[i].g[3];
-    }
-  }
-  // bias gradient (one of the image's two workgroups): lanes l, l^16, l^32 share a channel group
-  if (db2 && blockIdx.y == 0) {
+      const int slot = tslot[i];
+      const int hlo = slot ? 0 : ylo0, hhi = slot ? yhi1 + 4 : yhi0 + 4, rbase = slot ? nrow0 : -ylo0;
+      float* dst = dimg + ((task - (task / 112) * 112) & 15) * 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v = gsum[j];
-      v += __shfl_xor(v, 16);
-      v += __shfl_xor(v, 32);
-      if (lane < 16) atomicAdd(&dbs[lane * 4 + j], v);
+      for (int sp = 0; sp < 4; ++sp) {
+        const int hy = 2 * trow[i] + (sp >> 1) + 2;
+        if (hy >= hlo && hy <= hhi) {
+          f32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = ((ut[i].av >> (8 * j)) & 0xffu) == (uint32_t)sp ? ut[i].g[j] : 0.f;
+          *reinterpret_cast<f32x4*>(dst + ((rbase + hy) * 18 + 2 * tcol[i] + (sp & 1) + 2) * DP) = o;
+        }
+      }
     }
   }
+
+  CSTAMP(7);
+  int abase[BD_MT];
+#pragma unroll
+  for (int mt = 0; mt < BD_MT; ++mt) {
+    const int p = min(P0 + mt * 16 + r, plast);  // (padding rows of the last workgroup repeat its last position)
+    const int slot = p >= (b0 + 1) * 196 ? 1 : 0;
+    const int pos = p - (b0 + slot) * 196;
+    const int y = pos / 14, xx = pos - y * 14;
+    abase[mt] = (((slot ? nrow0 : -ylo0) + y) * 18 + xx) * DP + k0 + 2 * q;
+  }
+  // ReLU mask of the layer below for the (at most two) tiles this wave finalises, fetched ahead of the k loop
+  float pm[2][4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int t = wave + 8 * u;
+    const int mt = t >> 1, nt = t & 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = P0 + mt * 16 + 4 * q + i;
+      pm[u][i] = (t < 2 * BD_MT && p < npos) ? pool1[(long)p * 32 + nt * 16 + r] : 0.f;
+    }
+  }
+  f32x4 acc[BD_MT][2];
+#pragma unroll
+  for (int mt = 0; mt < BD_MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
-  if (db2 && blockIdx.y == 0 && tid < 64) atomicAdd(&db2[tid], dbs[tid]);
+  CSTAMP(1);
 
-  int abase[13];
+  // (A fragments one tap ahead: see conv2_fwd_f32_kernel)
+  float2 af[BD_MT], afn[BD_MT];
 #pragma unroll
-  for (int mt = 0; mt < 13; ++mt) {
-    int m = mt * 16 + r;
-    m = m < 196 ? m : 195;
-    const int y = m / 14, xx = m - y * 14;
-    abase[mt] = (y * 18 + xx) * DP + k0 + 4 * q;
-  }
-  f32x4 acc[13];
-#pragma unroll
-  for (int mt = 0; mt < 13; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+  for (int mt = 0; mt < BD_MT; ++mt) af[mt] = *reinterpret_cast<const float2*>(dimg + abase[mt]);
 #pragma unroll 1
   for (int dy = 0; dy < 5; ++dy) {
     const int dyn = dy < 4 ? dy + 1 : 4;
 #pragma unroll
-    for (int dx = 0; dx < 5; ++dx) bnxt[dx] = *reinterpret_cast<const f32x4*>(wbase + (long)(24 - (dyn * 5 + dx)) * 2048);
+    for (int dx = 0; dx < 5; ++dx)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        bnxt[dx][nt] = *reinterpret_cast<const float2*>(wbase + (long)(24 - (dyn * 5 + dx)) * 2048 + nt * 1024);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int dx = 0; dx < 5; ++dx) {
-      const int toff = (dy * 18 + dx) * DP;
-      f32x4 af[13];
+      const int toffn = dx < 4 ? (dy * 18 + dx + 1) * DP : ((dy < 4 ? dy + 1 : 4) * 18 + (dy < 4 ? 0 : 4)) * DP;
 #pragma unroll
-      for (int mt = 0; mt < 13; ++mt) af[mt] = *reinterpret_cast<const f32x4*>(dimg + abase[mt] + toff);
+      for (int mt = 0; mt < BD_MT; ++mt) afn[mt] = *reinterpret_cast<const float2*>(dimg + abase[mt] + toffn);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int mt = 0; mt < BD_MT; ++mt) {
+        acc[mt][0] = mfma16f32(af[mt].x, bcur[dx][0].x, acc[mt][0]);
+        acc[mt][1] = mfma16f32(af[mt].x, bcur[dx][1].x, acc[mt][1]);
+      }
 #pragma unroll
-        for (int mt = 0; mt < 13; ++mt) acc[mt] = mfma16f32(af[mt][j], bcur[dx][j], acc[mt]);
+      for (int mt = 0; mt < BD_MT; ++mt) {
+        acc[mt][0] = mfma16f32(af[mt].y, bcur[dx][0].y, acc[mt][0]);
+        acc[mt][1] = mfma16f32(af[mt].y, bcur[dx][1].y, acc[mt][1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < BD_MT; ++mt) af[mt] = afn[mt];
     }
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int dx = 0; dx < 5; ++dx) bcur[dx] = bnxt[dx];
+    for (int dx = 0; dx < 5; ++dx)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) bcur[dx][nt] = bnxt[dx][nt];
   }
 
+  // ---- combine the eight K slices through LDS (the staged rows are dead); tile id = mt * 2 + nt, finalised by wave id % 8
+  CSTAMP(2);
+  CSTAMP_WAVE();
   __syncthreads();
+  CSTAMP(3);
   float* red = smem32;
+  constexpr int TPW = BD_MT * 2;
 #pragma unroll
-  for (int mt = 0; mt < 13; ++mt) *reinterpret_cast<f32x4*>(red + ((wave * 13 + mt) * 64 + lane) * 4) = acc[mt];
+  for (int mt = 0; mt < BD_MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+      *reinterpret_cast<f32x4*>(red + ((wave * TPW + mt * 2 + nt) * 64 + lane) * 4) = acc[mt][nt];
   __syncthreads();
-  for (int mt = wave; mt < 13; mt += 4) {
-    f32x4 s = *reinterpret_cast<const f32x4*>(red + (mt * 64 + lane) * 4);
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(red + ((w * 13 + mt) * 64 + lane) * 4);
-      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
-    }
+  for (int u = 0; u < 2; ++u) {
+    const int t = wave + 8 * u;
+    if (t < TPW) {
+      f32x4 s = *reinterpret_cast<const f32x4*>(red + (t * 64 + lane) * 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = mt * 16 + 4 * q + i;
-      if (row < 196) {
-        const long o = ((long)b * 196 + row) * 32 + n0 + r;
-        dpool1[o] = pool1[o] > 0.f ? s[i] : 0.f;
+      for (int w = 1; w < 8; ++w) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(red + ((w * TPW + t) * 64 + lane) * 4);
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+      }
+      const int mt = t >> 1, nt = t & 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = P0 + mt * 16 + 4 * q + i;
+        if (p < npos) dpool1[(long)p * 32 + nt * 16 + r] = pm[u][i] > 0.f ? s[i] : 0.f;
       }
     }
   }
+  CSTAMP(4);
 }
 
 // ------------------------------------------------------------------ filter gradient
-// block -> (image quad g, output-channel half c, filter row dy); 256 threads.
+// block -> (image quad g, output-channel half c, filter row dy); 512 threads.
 // pool1 fp32 [B,196,32] (the conv input); dW fp32 [25][32][64] accumulated with atomics.
 namespace {
 constexpr int DW_XROWS = 14 * 18 * XP;   // the 14 halo rows a filter row touches: 9072 floats
 constexpr int DW_DY = 196 * XP;          // dY of one channel half, position-major, 36-float pitch: 7056 floats
-constexpr int DW_RED = 4 * 20 * 256;     // 20 480 floats
+constexpr int DW_RED = 8 * 10 * 256;     // [wave][tile][lane][4]: 20 480 floats
 constexpr int DW_LDS = (DW_XROWS + DW_DY > DW_RED ? DW_XROWS + DW_DY : DW_RED) * 4;
 
 __device__ __forceinline__ void conv2_dw_f32_body(float* __restrict__ smem, const int id, const float* __restrict__ pool1,
                                                   const float* __restrict__ dpool2, const float* __restrict__ pool2,
-                                                  const uint8_t* __restrict__ amax2, float* __restrict__ dW, int B) {
+                                                  const uint8_t* __restrict__ amax2, float* __restrict__ dW,
+                                                  float* __restrict__ db2, int B) {
+  // 512 threads: wave = (k group kq = wave & 3, input-channel tile mt = wave >> 2); two waves per SIMD, so one wave's LDS
+  // reads and address arithmetic run in the shadow of the other's MFMAs (with four waves the loop ran at 51 cycles per MFMA)
   float* ximg = smem;
   float* dyi = smem + DW_XROWS;
   const int dy = id % 5, c = (id / 5) & 1, g = id / 10;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
+  const int kq = wave & 3, mt = wave >> 2;
   const int b0 = 4 * g;
   const int nimg = min(4, B - b0);
 
-  f32x4 xv[8];
-  UnpoolTask32 ut[2];
+  f32x4 xv[4];
+  UnpoolTask32 ut;
+  f32x4 gsum = {0.f, 0.f, 0.f, 0.f};  // bias gradient of this thread's channel group (filter row 0's workgroups only)
+  const bool bias_role = db2 && dy == 0;
   auto load = [&](const int b) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int ch = tid + 256 * i;  // 2016 chunks: (staged row 0..13, halo col 0..17, part 0..7)
+    for (int i = 0; i < 4; ++i) {
+      const int ch = tid + 512 * i;  // 2016 chunks: (staged row 0..13, halo col 0..17, part 0..7)
       const int pix = ch >> 3, part = ch & 7;
       const int sy = pix / 18, hx = pix - sy * 18;
       const int y = sy + dy - 2, xx = hx - 2;
@@ -374,97 +474,109 @@ __device__ __forceinline__ void conv2_dw_f32_body(float* __restrict__ smem, cons
       xv[i] = *reinterpret_cast<const f32x4*>(pool1 + (ok ? (((long)b * 14 + y) * 14 + xx) * 32 + part * 4 : 0L));
       if (!ok) xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int task = tid + 256 * i;  // 392 tasks: window = task >> 3, channel group (of this half) = task & 7
-      const int t = task < 392 ? task : 0;
-      ut[i].load(dpool2, pool2, amax2, (long)b * 3136 + (t >> 3) * 64 + c * 32 + (t & 7) * 4);
-    }
+    const int t = tid < 392 ? tid : 0;  // 392 tasks: window = task >> 3, channel group (of this half) = task & 7
+    ut.load(dpool2, pool2, amax2, (long)b * 3136 + (t >> 3) * 64 + c * 32 + (t & 7) * 4);
   };
   auto store = [&]() {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int ch = tid + 256 * i;
+    for (int i = 0; i < 4; ++i) {
+      const int ch = tid + 512 * i;
       if (ch < 2016) *reinterpret_cast<f32x4*>(ximg + (ch >> 3) * XP + (ch & 7) * 4) = xv[i];
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int task = tid + 256 * i;
-      if (task < 392) {
-        ut[i].mask();
-        const int win = task >> 3, py = win / 7, px = win - py * 7;
-        ut[i].store(dyi + (task & 7) * 4, py, px, 14, XP, 0, 0);
-      }
+    if (tid < 392) {
+      ut.mask();
+      const int win = tid >> 3, py = win / 7, px = win - py * 7;
+      ut.store(dyi + (tid & 7) * 4, py, px, 14, XP, 0, 0);
+      if (bias_role) { gsum[0] += ut.g[0]; gsum[1] += ut.g[1]; gsum[2] += ut.g[2]; gsum[3] += ut.g[3]; }
     }
   };
 
-  f32x4 acc[5][2][2];  // [dx][cin tile][cout tile]
+  f32x4 acc[5][2];  // [dx][cout tile] of input-channel tile mt
 #pragma unroll
   for (int dx = 0; dx < 5; ++dx)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) acc[dx][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < 2; ++nt) acc[dx][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  CSTAMP(0);
   if (nimg > 0) load(b0);
   for (int im = 0; im < nimg; ++im) {
     __syncthreads();  // the previous image has been consumed
     store();
     __syncthreads();
+    if (im == 0) CSTAMP(1);
+    if (im == 1) CSTAMP(2);
     if (im + 1 < nimg) load(b0 + im + 1);
-    // k-step s covers positions 4s .. 4s+3 (lane quarter q <-> position 4s + q); wave (s + im) & 3 takes step s
-    for (int s = (wave - im) & 3; s < 49; s += 4) {
+    // k-step s covers positions 4s .. 4s+3 (lane quarter q <-> position 4s + q); k group (s + im) & 3 takes step s, so
+    // over the four images every wave issues the same number of MFMAs
+    for (int s = (kq - im) & 3; s < 49; s += 4) {
       const int pos = 4 * s + q;
       const int y = pos / 14, xx = pos - y * 14;
-      const float* xa = ximg + (y * 18 + xx) * XP + r;  // tap (dy, dx): staged row y, halo column xx + dx
+      const float* xa = ximg + (y * 18 + xx) * XP + mt * 16 + r;  // tap (dy, dx): staged row y, halo column xx + dx
       const float* da = dyi + pos * XP + r;
       const float b0f = da[0], b1f = da[16];
-      float a[5][2];
+      float a[5];
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) a[dx] = xa[dx * XP];
 #pragma unroll
       for (int dx = 0; dx < 5; ++dx) {
-        a[dx][0] = xa[dx * XP];
-        a[dx][1] = xa[dx * XP + 16];
-      }
-#pragma unroll
-      for (int dx = 0; dx < 5; ++dx) {
-        acc[dx][0][0] = mfma16f32(a[dx][0], b0f, acc[dx][0][0]);
-        acc[dx][0][1] = mfma16f32(a[dx][0], b1f, acc[dx][0][1]);
-        acc[dx][1][0] = mfma16f32(a[dx][1], b0f, acc[dx][1][0]);
-        acc[dx][1][1] = mfma16f32(a[dx][1], b1f, acc[dx][1][1]);
+        acc[dx][0] = mfma16f32(a[dx], b0f, acc[dx][0]);
+        acc[dx][1] = mfma16f32(a[dx], b1f, acc[dx][1]);
       }
     }
   }
-  // combine the four waves' partial sums, then one atomic per element and workgroup
+  // bias gradient (workgroup-uniform branch): threads with equal (tid & 7) hold the same 4 channels of this half; the
+  // waves' sums meet in LDS so the workgroup issues ONE 32-lane atomic (per-wave atomics on these two cache lines from
+  // every workgroup queue up at the L2 and hold back the filter-gradient atomics behind them)
+  if (bias_role) {
+    __syncthreads();  // the staged image is dead
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = gsum[j];
+      v += __shfl_xor(v, 8);
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lane < 8) smem[wave * 32 + lane * 4 + j] = v;
+    }
+    __syncthreads();
+    if (tid < 32) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += smem[w * 32 + tid];
+      atomicAdd(&db2[c * 32 + tid], v);
+    }
+  }
+  // combine the four k groups' partial sums, then one atomic per element and workgroup
+  CSTAMP(3);
   __syncthreads();
+  CSTAMP(4);
   float* red = smem;
 #pragma unroll
   for (int dx = 0; dx < 5; ++dx)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-        *reinterpret_cast<f32x4*>(red + ((wave * 20 + (dx * 2 + mt) * 2 + nt) * 64 + lane) * 4) = acc[dx][mt][nt];
+    for (int nt = 0; nt < 2; ++nt)
+      *reinterpret_cast<f32x4*>(red + ((wave * 10 + dx * 2 + nt) * 64 + lane) * 4) = acc[dx][nt];
   __syncthreads();
-  for (int t = wave; t < 20; t += 4) {
-    f32x4 s = *reinterpret_cast<const f32x4*>(red + (t * 64 + lane) * 4);
+  for (int t = wave; t < 20; t += 8) {  // output tile t = (dx, cin tile, cout tile)
+    const int dx = t >> 2, mtt = (t >> 1) & 1, nt = t & 1;
+    f32x4 s = *reinterpret_cast<const f32x4*>(red + (((mtt * 4) * 10 + dx * 2 + nt) * 64 + lane) * 4);
 #pragma unroll
     for (int w = 1; w < 4; ++w) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(red + ((w * 20 + t) * 64 + lane) * 4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(red + (((mtt * 4 + w) * 10 + dx * 2 + nt) * 64 + lane) * 4);
       s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
     }
-    const int dx = t >> 2, mt = (t >> 1) & 1, nt = t & 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int cin = mt * 16 + 4 * q + i, cout = c * 32 + nt * 16 + r;
+      const int cin = mtt * 16 + 4 * q + i, cout = c * 32 + nt * 16 + r;
       atomicAdd(&dW[((long)(dy * 5 + dx) * 32 + cin) * 64 + cout], s[i]);
     }
   }
+  CSTAMP(5);
 }
 
 // conv2 dW (workgroups [0, n2)), conv1 dW/db (the next n1) and optionally trailing optimizer workgroups (see ConvDwDuo in
 // conv2_lds.hip) in one launch.
 struct ConvDwDuo32 {
-  const float* pool1; const float* dpool2; const float* pool2; const uint8_t* amax2; float* dW2;
+  const float* pool1; const float* dpool2; const float* pool2; const uint8_t* amax2; float* dW2; float* db2;
   int B, n2;
   const float* images; const int* perm; const int* step_ptr; int spe;
   const float* dpool1; const uint8_t* amax1; float* dW1; float* db1;
@@ -475,13 +587,13 @@ struct ConvDwDuo32 {
 constexpr int DUO32_LDS = DW_LDS > CONV1_DW_LDS_FLOATS * 4 ? DW_LDS : CONV1_DW_LDS_FLOATS * 4;
 }  // namespace
 
-__global__ __launch_bounds__(256) void conv_dw_duo_f32_kernel(const ConvDwDuo32 a) {
+__global__ __launch_bounds__(512) void conv_dw_duo_f32_kernel(const ConvDwDuo32 a) {
   extern __shared__ __attribute__((aligned(16))) float smem32[];
   const int id = blockIdx.x;
   if (id < a.n2)
-    conv2_dw_f32_body(smem32, id, a.pool1, a.dpool2, a.pool2, a.amax2, a.dW2, a.B);
+    conv2_dw_f32_body(smem32, id, a.pool1, a.dpool2, a.pool2, a.amax2, a.dW2, a.db2, a.B);
   else if (id >= a.n2 + a.n1)
-    adam_tf_body(a.adam, id - a.n2 - a.n1, a.nadam, 256);
+    adam_tf_body(a.adam, id - a.n2 - a.n1, a.nadam, 512);
   else
     conv1_dw_body(smem32, id - a.n2, a.n1, a.images, a.perm, a.step_ptr, a.spe, a.B, a.dpool1, a.amax1, a.dW1, a.db1);
 }
@@ -493,7 +605,7 @@ DTF_API int dtf_conv2_f32_init() {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS2);
   if (e != hipSuccess) return (int)e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_bwd_data_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          BWD_LDS);
+                          BD_LDS);
   if (e != hipSuccess) return (int)e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dw_duo_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           DUO32_LDS);
@@ -515,22 +627,23 @@ DTF_API int dtf_conv2_fwd_f32(const float* x, const float* W, const float* bias,
 }
 
 DTF_API int dtf_conv2_bwd_data_f32(const float* dpool2, const float* pool2, const void* amax2, const float* W,
-                                   const float* pool1, float* dpool1, float* db2, int B, hipStream_t st) {
+                                   const float* pool1, float* dpool1, int B, hipStream_t st) {
   if (B <= 0) return ERR_SHAPE;
   if (!g_f32_attr_set) {
     const int rc = dtf_conv2_f32_init();
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(conv2_bwd_data_f32_kernel, dim3(B, 2), dim3(256), BWD_LDS, st, dpool2, pool2, (const uint8_t*)amax2, W,
-                     pool1, dpool1, db2);
+  hipLaunchKernelGGL(conv2_bwd_data_f32_kernel, dim3(dtf_cdiv(196L * B, BD_POS)), dim3(512), BD_LDS, st, dpool2, pool2,
+                     (const uint8_t*)amax2, W, pool1, dpool1, B);
   DTF_CHECK_LAUNCH();
   return 0;
 }
 
 // Both filter gradients of the conv stack in one launch: conv2's from (pool1, dpool2, pool2, amax2), conv1's from
-// (images[perm], dpool1, amax1) when dW1 != null.  dW2 / dW1 / db1 are accumulated with atomics (pre-zeroed).
+// (images[perm], dpool1, amax1) when dW1 != null; conv2's bias gradient when db2 != null.  dW2 / db2 / dW1 / db1 are
+// accumulated with atomics (pre-zeroed).
 DTF_API int dtf_conv_dw_duo_f32(const float* dpool2, const float* pool2, const void* amax2, const float* pool1, float* dW2,
-                                int B, const float* images, const int* perm, const int* step_ptr, int spe,
+                                float* db2, int B, const float* images, const int* perm, const int* step_ptr, int spe,
                                 const float* dpool1, const void* amax1, float* dW1, float* db1, const OptimParams* adam,
                                 hipStream_t st) {
   if (B <= 0 || (perm && spe <= 0)) return ERR_SHAPE;
@@ -540,7 +653,7 @@ DTF_API int dtf_conv_dw_duo_f32(const float* dpool2, const float* pool2, const v
     if (rc) return rc;
   }
   ConvDwDuo32 a;
-  a.pool1 = pool1; a.dpool2 = dpool2; a.pool2 = pool2; a.amax2 = (const uint8_t*)amax2; a.dW2 = dW2;
+  a.pool1 = pool1; a.dpool2 = dpool2; a.pool2 = pool2; a.amax2 = (const uint8_t*)amax2; a.dW2 = dW2; a.db2 = db2;
   a.B = B; a.n2 = dtf_cdiv(B, 4) * 10;
   a.images = images; a.perm = perm; a.step_ptr = step_ptr; a.spe = spe;
   a.dpool1 = dpool1; a.amax1 = (const uint8_t*)amax1; a.dW1 = dW1; a.db1 = db1;
@@ -554,7 +667,7 @@ DTF_API int dtf_conv_dw_duo_f32(const float* dpool2, const float* pool2, const v
     // slots the two filter-gradient roles leave in one resident wave of 512 (more would queue behind them as a tail)
     a.nadam = 512 - (a.n2 + a.n1) > 64 ? 512 - (a.n2 + a.n1) : 64;
   }
-  hipLaunchKernelGGL(conv_dw_duo_f32_kernel, dim3(a.n2 + a.n1 + a.nadam), dim3(256), DUO32_LDS, st, a);
+  hipLaunchKernelGGL(conv_dw_duo_f32_kernel, dim3(a.n2 + a.n1 + a.nadam), dim3(512), DUO32_LDS, st, a);
   DTF_CHECK_LAUNCH();
   return 0;
 }

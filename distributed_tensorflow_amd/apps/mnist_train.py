@@ -123,9 +123,15 @@ def run(FLAGS, distributed: bool) -> int:
         sv.prepare_or_wait_for_session()
         sv.start_standard_services()
 
+    import contextlib
+    timer = None
     if FLAGS.profile:
         from ..utils import trace
         _log(rank, "profiling: roctx ranges %s" % ("on" if trace.enable(True) else "unavailable (libroctx64 not found)"))
+        timer = trace.StepTimer()  # host-side split of the loop: launching steps / evaluation / summaries
+
+    def phase(name):
+        return timer.phase(name) if timer is not None else contextlib.nullcontext()
     start_step = engine.global_step
     flushed = start_step
     start_time = time.time()
@@ -149,7 +155,10 @@ def run(FLAGS, distributed: bool) -> int:
             if FLAGS.fault_inject_step > step:
                 burst = min(burst, FLAGS.fault_inject_step - step)
             burst = max(1, burst)
-            trainer.train_steps(burst)
+            with phase("train steps (launch)"):
+                trainer.train_steps(burst)
+            if timer is not None:
+                timer.add_images(burst * FLAGS.batch_size * world)
             if trainer.ipc is not None and trainer.comm == "ipc" and not trainer.ensure_healthy():
                 # an in-kernel wait of the direct exchange expired on some rank: that step was skipped on every rank that
                 # could know, the job has agreed on it, fallen back to the collective path and re-synchronised the replicas
@@ -157,16 +166,19 @@ def run(FLAGS, distributed: bool) -> int:
             step = engine.global_step
             last = step - 1
             if step - flushed >= 512:
-                _flush_step_summaries(writer, engine, flushed, step)
+                with phase("step summaries (sync + read ring)"):
+                    _flush_step_summaries(writer, engine, flushed, step)
                 flushed = step
             if last % FLAGS.eval_step_interval == 0:
-                _flush_step_summaries(writer, engine, flushed, step)
+                with phase("step summaries (sync + read ring)"):
+                    _flush_step_summaries(writer, engine, flushed, step)
                 flushed = step
-                _tl, test_acc = _sharded_eval(trainer, test_dd.images, test_dd.labels)
-                if FLAGS.eval_train_set:
-                    _trl, train_acc = _sharded_eval(trainer, train_dd.images, train_dd.labels)
-                else:
-                    train_acc = float("nan")
+                with phase("evaluation"):
+                    _tl, test_acc = _sharded_eval(trainer, test_dd.images, test_dd.labels)
+                    if FLAGS.eval_train_set:
+                        _trl, train_acc = _sharded_eval(trainer, train_dd.images, train_dd.labels)
+                    else:
+                        train_acc = float("nan")
                 _log(rank, "Iter " + str(last) + ", test_acc: " + str(test_acc) + ", train_acc = " + str(train_acc))
                 if FLAGS.check_replicas and not trainer.replicas_in_sync():
                     raise RuntimeError("replica parameter checksums diverged at step %d" % last)
@@ -196,6 +208,8 @@ def run(FLAGS, distributed: bool) -> int:
         done = max(0, engine.global_step - start_step)
         _flush_step_summaries(writer, engine, flushed, engine.global_step)
         _log(rank, "Training time: %3.2fs" % elapsed)
+        if timer is not None:
+            _log(rank, "host phases: " + timer.summary())
         if done:
             _log(rank, "Throughput: %.1f images/sec (%d steps x global batch %d)" % (
                 done * FLAGS.batch_size * world / max(1e-9, elapsed), done, FLAGS.batch_size * world))

@@ -695,7 +695,6 @@ class DataParallelTrainer:
                 e.metrics_ring.copy_(ring)  # (the local pass added this step's loss / accuracy once already)
                 self._reduce(ref)
                 m0 = e.M.clone()
-            scale = 1.0
         else:
             gen = e._gen.get_state()
             ring = e._ring.copy()
@@ -706,7 +705,7 @@ class DataParallelTrainer:
             e.G.zero_()
             dist.all_reduce(ref, group=self.group)
             m0 = e.M.clone()
-            scale = 1.0 / self.world
+        scale = 1.0 / self.world  # (local gradients are means over the local batch; the optimizer divides the sum by world)
         self.train_steps(1)
         with self._ctx():
             # compared in first-moment space (recovering g itself cancels catastrophically once |g| << |m|); the floor

@@ -168,7 +168,7 @@ out["in_sync"] = tr.replicas_in_sync()
 out["host_step"], out["device_step"] = eng.global_step, int(eng.step_t.item())
 lm, am = eng.read_metrics(0, eng.global_step)
 out["loss_first"], out["loss_last"] = float(lm[:5].mean()), float(lm[-5:].mean())
-print("RESULT " + json.dumps(out), flush=True)
+json.dump(out, open(os.path.join(sys.argv[3], "r%d.json" % rank), "w"))
 dist.barrier()
 tr.close()
 dist.destroy_process_group()
@@ -185,11 +185,10 @@ def test_checked_step_validates_the_production_exchange(tmp_path, schedule, dtyp
     script.write_text(_CHECKED)
     env = dict(os.environ, MASTER_PORT="29644", HSA_ENABLE_IPC_MODE_LEGACY="0", DTF_DP_SCHEDULE=schedule)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29644", str(script), REPO, dtype]
+           "--master-port", "29644", str(script), REPO, dtype, str(tmp_path)]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
-    res = [json.loads(l.split("RESULT ", 1)[1]) for l in r.stdout.splitlines() if "RESULT " in l]
-    assert len(res) == 2, r.stdout[-3000:]
+    res = [json.load(open(str(tmp_path / ("r%d.json" % k)))) for k in range(2)]
     for o in res:
         assert o["schedule"] == schedule and max(o["dev"]) < 2e-3, o
         assert o["in_sync"] and o["host_step"] == o["device_step"] == 3 + 2 * 18, o
