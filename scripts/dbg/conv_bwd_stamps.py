@@ -54,3 +54,33 @@ report("conv2 bwd-data", (196 * B + 79) // 80, 5, "entry -> dY staged -> k loop 
 report("conv2 dW (conv2 role only)", ((B + 3) // 4) * 10, 6, "entry -> image 0 staged -> image 1 staged -> all k loops done -> barrier -> end",
        lambda: lib.dtf_conv_dw_duo_f32(dpool2.data_ptr(), pool2.data_ptr(), amax2.data_ptr(), pool1.data_ptr(), dW2.data_ptr(), db2.data_ptr(), B,
                                        None, None, None, 0, None, None, None, None, None, 0))
+
+
+# ---- the whole launch as the engine issues it: conv2 dW + conv1 dW + W_fc1's Adam update
+from distributed_tensorflow_amd import native
+images = torch.rand(4000, 784, device=dev); perm = torch.randperm(4000, device=dev, dtype=torch.int32)
+step = torch.zeros(1, dtype=torch.int32, device=dev)
+amax1 = torch.randint(0, 4, (B, 196, 32), dtype=torch.uint8, device=dev)
+dW1 = torch.zeros(25, 32, device=dev); db1 = torch.zeros(32, device=dev)
+n = 3136 * 1024
+Pm, Gm, Mm, Vm = (torch.zeros(n, device=dev) for _ in range(4))
+op = native.OptimParams()
+op.P, op.G, op.M, op.V = Pm.data_ptr(), Gm.data_ptr(), Mm.data_ptr(), Vm.data_ptr()
+op.n, op.zero_from, op.lr, op.beta1, op.beta2, op.eps, op.grad_scale = n, n, 1e-4, 0.9, 0.999, 1e-8, 1.0
+op.step = step.data_ptr()
+n2, n1 = ((B + 3) // 4) * 10, min(B, 128)
+nwg = 512
+st = torch.zeros(2 * nwg + 8, 32, dtype=torch.int64, device=dev)
+assert lib.dtf_dbg_set_conv_stamps(st.data_ptr()) == 0
+for _ in range(20):
+    rc = lib.dtf_conv_dw_duo_f32(dpool2.data_ptr(), pool2.data_ptr(), amax2.data_ptr(), pool1.data_ptr(), dW2.data_ptr(), db2.data_ptr(), B,
+                                 images.data_ptr(), perm.data_ptr(), step.data_ptr(), 40, dpool1.data_ptr(), amax1.data_ptr(),
+                                 dW1.data_ptr(), db1.data_ptr(), C.byref(op), 0)
+    assert rc == 0, rc
+torch.cuda.synchronize()
+t = st.cpu().numpy().astype(np.int64)[:nwg].reshape(nwg, 16, 2)
+rt0 = t[:, 0, 1][t[:, 0, 1] > 0].min()
+for name, lo, hi in (("conv2 dW", 0, n2), ("conv1 dW", n2, n2 + n1), ("Adam W_fc1", n2 + n1, nwg)):
+    e, x = (t[lo:hi, 0, 1] - rt0) / 100.0, (t[lo:hi, 5, 1] - rt0) / 100.0
+    print("%-10s %3d workgroups: entry %.2f .. %.2f us (median %.2f), exit %.2f .. %.2f us (median %.2f), lifetime median %.2f us" % (
+        name, hi - lo, e.min(), e.max(), np.median(e), x.min(), x.max(), np.median(x), np.median(x - e)))
