@@ -203,6 +203,12 @@ def run(FLAGS, distributed: bool) -> int:
         return rc
     index = il.build_image_index(image_lists, image_dir)
 
+    # the decode processes of the extraction pipeline start now, so they are warm by the time the backbone is on the GPU
+    pipeline = None
+    if os.environ.get("DTF_EXTRACT_PIPELINE", "1") != "0" and (device.type == "cuda" or os.environ.get("DTF_EXTRACT_PIPELINE") == "1"):
+        from ..data.pipeline import DecodePipeline
+        pipeline = DecodePipeline(device, batch_size=FLAGS.extract_batch_size)
+
     # ---- backbone
     backbone_kind = getattr(FLAGS, "backbone", "auto")
     if backbone_kind == "auto":
@@ -251,14 +257,20 @@ def run(FLAGS, distributed: bool) -> int:
     distortion = Distortion(FLAGS.flip_left_right, FLAGS.random_crop, FLAGS.random_scale, FLAGS.random_brightness)
     cache = BottleneckCache(index, device)
     t_extract = time.time()
-    created = cache.extract(backbone, preproc, batch_size=FLAGS.extract_batch_size, rank=rank, world=world,
-                            txt_dir=FLAGS.bottleneck_dir if FLAGS.bottleneck_txt_cache else None,
-                            progress=(print if rank == 0 else None))
+    try:
+        created = cache.extract(backbone, preproc, batch_size=FLAGS.extract_batch_size, rank=rank, world=world,
+                                txt_dir=FLAGS.bottleneck_dir if FLAGS.bottleneck_txt_cache else None,
+                                progress=(print if rank == 0 else None), pipeline=pipeline)
+    finally:
+        if pipeline is not None:
+            pipeline.close()
     if device.type == "cuda":
         torch.cuda.synchronize()
     dt = time.time() - t_extract
     _log(rank, "bottleneck extraction: %d images on this rank in %.2fs (%.1f images/sec/rank, HBM cache %.1f MB)" % (
         created, dt, created / max(dt, 1e-9), cache.values.numel() * 4 / 1e6))
+    if pipeline is not None and cache.extract_stats:
+        _log(rank, "extraction pipeline: " + DecodePipeline.describe(cache.extract_stats))
 
     train_writer = validation_writer = None
     if rank == 0:

@@ -166,9 +166,11 @@ class BottleneckCache:
 
     # -------------------------------------------------------------- extraction
     def extract(self, backbone, preproc: ImagePreprocessor, batch_size: int = 64, rank: int = 0, world: int = 1,
-                txt_dir: Optional[str] = None, progress=print) -> int:
+                txt_dir: Optional[str] = None, progress=print, pipeline=None) -> int:
         """Fill the cache: this rank computes a contiguous 1/world block of the missing rows (batched
-        forward), then the blocks are all-gathered.  Returns the number of bottlenecks this rank created."""
+        forward), then the blocks are all-gathered.  Returns the number of bottlenecks this rank created.
+        ``pipeline``: a ``data.pipeline.DecodePipeline`` (decode processes -> pinned ring -> side-stream H2D, overlapped
+        with the forward); without one the batches are decoded, copied and run one after the other."""
         n = self.index.num_images
         if txt_dir:
             self.import_txt(txt_dir)
@@ -176,6 +178,28 @@ class BottleneckCache:
         lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
         todo = [i for i in range(lo, hi) if not self.filled[i]]
         created = 0
+        self.extract_stats = {}
+        if pipeline is not None and todo:
+            rows_t = torch.as_tensor(todo, dtype=torch.long, device=self.device)
+            done = [0]
+
+            def consume(first: int, count: int, x: torch.Tensor) -> None:
+                feats = backbone(x)
+                self.values.index_copy_(0, rows_t[first:first + count], feats[:count].to(torch.float32))
+                if (first + count) // 100 != first // 100 and progress:
+                    progress(str((first + count) // 100 * 100) + " bottleneck files created.")  # retrain1/retrain.py:179-180
+                done[0] = first + count
+
+            def cpu_batch(imgs, descs):
+                return torch.stack([preprocess_reference(a, descs[i]) for i, a in enumerate(imgs)]).to(torch.bfloat16)
+
+            def warm() -> None:  # kernel selection + graph capture at this batch size, under the first decodes
+                if self.device.type == "cuda":
+                    backbone(torch.zeros(pipeline.batch_size, INPUT_SIZE, INPUT_SIZE, 8, dtype=torch.bfloat16, device=self.device))
+
+            self.extract_stats = pipeline.run([self.index.paths[i] for i in todo], consume, preprocess_cpu=cpu_batch, warm=warm)
+            created = done[0]
+            todo = []
         for s in range(0, len(todo), batch_size):
             rows = todo[s:s + batch_size]
             x = preproc.load([self.index.paths[i] for i in rows])

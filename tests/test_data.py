@@ -153,3 +153,43 @@ def test_imagenet_node_lookup(tmp_path):
     syn.write_text("n01440764\ttench\n")
     with pytest.raises(ValueError):
         NodeLookup(str(pb), str(syn))
+
+
+def test_decode_pipeline_matches_serial_extraction(tmp_path):
+    """The extraction pipeline (decode processes -> shared ring -> preprocess) fills the cache with exactly the bottlenecks
+    the serial path computes, including a short last batch and images of mixed sizes, one of them large enough for the
+    reduced-scale (draft) decode."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from distributed_tensorflow_amd.models.retrain_head import TinyBackbone
+    from distributed_tensorflow_amd.data import image_lists as il
+    from distributed_tensorflow_amd.data.bottleneck import BottleneckCache, ImagePreprocessor
+    from distributed_tensorflow_amd.data.pipeline import DecodePipeline
+    d = il.make_synthetic_image_dir(str(tmp_path / "imgs"), num_classes=2, images_per_class=11, seed=4)
+    yy, xx = np.mgrid[0:1300, 0:1500].astype(np.float32)   # a smooth photograph-like image (noise would alias)
+    big = np.stack([127 + 120 * np.sin(yy / 90.0), 127 + 120 * np.cos(xx / 70.0), (yy + xx) / 2800.0 * 255], -1).astype(np.uint8)
+    sub = sorted(os.listdir(d))[0]
+    Image.fromarray(big).save(os.path.join(d, sub, "zz_big.jpg"), quality=90)
+    lists = il.create_image_lists(d, 10, 10)
+    index = il.build_image_index(lists, d)
+    backbone = TinyBackbone("cpu", seed=1)
+    a = BottleneckCache(index, "cpu")
+    a.extract(backbone, ImagePreprocessor("cpu"), batch_size=8, progress=None)
+    pipe = DecodePipeline("cpu", batch_size=8, workers=2, slots=3, chunk=3)
+    try:
+        b = BottleneckCache(index, "cpu")
+        n = b.extract(backbone, ImagePreprocessor("cpu"), batch_size=8, progress=None, pipeline=pipe)
+        st = b.extract_stats
+    finally:
+        pipe.close()
+    assert n == index.num_images == 23 and st["batches"] == 3 and st["images"] == 23
+    # the large image was decoded at 1/2 scale (650 x 750): fewer bytes than the full decode
+    assert st["h2d_bytes"] < 22 * 240 * 320 * 3 + 1300 * 1500 * 3 // 2
+    small = [i for i, p in enumerate(index.paths) if not p.endswith("zz_big.jpg")]
+    assert torch.equal(a.values[small], b.values[small])
+    bigrow = [i for i, p in enumerate(index.paths) if p.endswith("zz_big.jpg")]
+    # draft decode = DCT-domain 2x reduction before the bilinear resample: close to, not identical with, the full decode
+    rel = float((a.values[bigrow] - b.values[bigrow]).norm() / a.values[bigrow].norm())
+    assert rel < 0.05, rel
+    assert "images/s" in DecodePipeline.describe(st)
