@@ -147,6 +147,25 @@ DTF_API int dtf_retrain_head_bwd(const float* cache, const int* rows, const floa
   return 0;
 }
 
+// dx[b][k] = sum_c dz[b][c] * W[k][c]: the gradient w.r.t. the bottleneck, needed only when the backbone is fine-tuned
+// (SURVEY §2.6 config 5).  thread -> (b, k); consecutive lanes write consecutive k.
+__global__ __launch_bounds__(256) void retrain_head_dx_kernel(const float* __restrict__ dz, const float* __restrict__ W,
+                                                              float* __restrict__ dx, int B, int C) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)B * BN) return;
+  const int b = (int)(t / BN), k = (int)(t % BN);
+  float g = 0.f;
+  for (int c = 0; c < C; ++c) g = fmaf(dz[(long)b * C + c], W[(long)k * C + c], g);
+  dx[t] = g;
+}
+
+DTF_API int dtf_retrain_head_dx(const float* dz, const float* W, float* dx, int B, int C, hipStream_t st) {
+  if (B <= 0 || C <= 0) return ERR_SHAPE;
+  hipLaunchKernelGGL(retrain_head_dx_kernel, dim3(dtf_cdiv((long)B * BN, 256)), dim3(256), 0, st, dz, W, dx, B, C);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
 // Class-balanced sampler with replacement (C33): rows[i] = offsets[c] + (r % counts[c]),
 // c uniform over classes, r uniform in [0, 2^27).  Counter-based RNG keyed by (seed, draw counter).
 __global__ __launch_bounds__(256) void sample_rows_kernel(const long* __restrict__ offsets, const long* __restrict__ counts,

@@ -423,15 +423,34 @@ class InceptionTrainer:
         return self.feat
 
     def head_forward_backward(self, labels: torch.Tensor) -> None:
+        """The new softmax layer on the pooled features, through the retrain-head kernels (``csrc/hip/retrain_head.hip``):
+        logits + (double-)softmax cross-entropy + accuracy + dlogits in one launch, the filter / bias gradient in a
+        second, the gradient w.r.t. the features in a third — no library GEMM or softmax kernel in the step."""
+        from .retrain_head import RetrainHeadParams
+        import ctypes as C
+        native, lib, st = self.native, self.lib, torch.cuda.current_stream().cuda_stream
         W = self.param("final_training_ops/weights/final_weights")
         b = self.param("final_training_ops/biases/final_biases")
-        logits = torch.addmm(b, self.feat, W)
-        loss, dlogits, p = softmax_xent_grad(logits, labels, self.double_softmax)
-        self.last_loss.copy_(loss)
-        self.last_correct.copy_((p.argmax(1) == labels.long()).float().sum())
-        torch.mm(self.feat.t(), dlogits, out=self.grad("final_training_ops/weights/final_weights"))
-        self.grad("final_training_ops/biases/final_biases").copy_(dlogits.sum(0))
-        torch.mm(dlogits, W.t(), out=self.dfeat)
+        B = self.B
+        if not hasattr(self, "_head_dz"):
+            self._head_dz = torch.empty(B, self.C, dtype=torch.float32, device=self.device)
+            self._head_metrics = torch.zeros(2, dtype=torch.float32, device=self.device)
+            self._head_labels = torch.empty(B, dtype=torch.int32, device=self.device)
+        self._head_labels.copy_(labels)
+        self._head_metrics.zero_()
+        p = RetrainHeadParams()
+        p.cache, p.labels_all, p.rows = self.feat.data_ptr(), self._head_labels.data_ptr(), None
+        p.W, p.b, p.B, p.C, p.grad_scale = W.data_ptr(), b.data_ptr(), B, self.C, 1.0 / B
+        p.double_softmax, p.training = int(self.double_softmax), 1
+        p.probs, p.pred, p.dz, p.metrics = None, None, self._head_dz.data_ptr(), self._head_metrics.data_ptr()
+        native.check(lib.dtf_retrain_head_fwd(C.byref(p), st), "head fwd")
+        native.check(lib.dtf_retrain_head_bwd(self.feat.data_ptr(), None, self._head_dz.data_ptr(), B, self.C, None, None,
+                                              self.grad("final_training_ops/weights/final_weights").data_ptr(),
+                                              self.grad("final_training_ops/biases/final_biases").data_ptr(), 0.0, st), "head bwd")
+        native.check(lib.dtf_retrain_head_dx(self._head_dz.data_ptr(), W.data_ptr(), self.dfeat.data_ptr(), B, self.C, st), "head dx")
+        # (loss sum, correct count) stay on the device; metrics() reads them
+        self.last_loss = self._head_metrics[0] / B
+        self.last_correct = self._head_metrics[1]
 
     def _dw_splits(self, K: int, Cout: int, npos: int) -> int:
         blocks = ((K + 127) // 128) * ((Cout + 63) // 64)
