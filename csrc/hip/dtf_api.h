@@ -73,7 +73,7 @@ DTF_API int dtf_conv1_fwd_f32(const float* images, const int* perm, const int* s
                               const float* bias, float* out, void* amax, hipStream_t st);
 DTF_API int dtf_conv2_fwd_f32(const float* x, const float* W, const float* bias, float* out, void* amax, int B, hipStream_t st);
 DTF_API int dtf_conv2_bwd_data_f32(const float* dpool2, const float* pool2, const void* amax2, const float* W,
-                                   const float* pool1, float* dpool1, int B, hipStream_t st);
+                                   const float* pool1, float* dpool1, int B, const struct OptimParams* adam, hipStream_t st);
 DTF_API int dtf_conv_dw_duo_f32(const float* dpool2, const float* pool2, const void* amax2, const float* pool1, float* dW2,
                                 float* db2, int B, const float* images, const int* perm, const int* step_ptr, int spe,
                                 const float* dpool1, const void* amax1, float* dW1, float* db1, const struct OptimParams* adam,

@@ -182,12 +182,6 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
     }
     // un-pool + conv2 bwd-data (+db2) as one LDS-resident kernel, then both conv filter gradients as one launch
     const int ipw = e->dw2_splits > 0 && e->dw2_splits <= 16 ? e->dw2_splits : 4;
-    if (e->f32)
-      DTF_TRY(dtf_conv2_bwd_data_f32(e->dpool2, (const float*)e->pool2, e->amax2, e->P + e->off_Wc2, (const float*)e->pool1,
-                                     e->dpool1, B, st));
-    else
-      DTF_TRY(dtf_conv2_bwd_data_lds_packed(e->dpool2, e->pool2, e->amax2, e->wc2b, e->pool1, e->dpool1, e->G + e->off_bc2, B,
-                                            st));
     OptimParams fc1{};
     if (early_adam) {
       fc1.P = e->P; fc1.G = e->G; fc1.M = e->M; fc1.V = e->V;
@@ -198,6 +192,15 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
       fc1.step = e->step;
       fc1.skip = e->skip;
     }
+    // W_fc1's Adam update rides in the filter-gradient launch.  (Measured alternative for fp32: in the data-gradient
+    // launch, whose 245 workgroups leave 267 resident slots — that launch grows from 24.8 to 33.6 us while the
+    // filter-gradient launch only shrinks from 34.8 to 29.4 us: the ~20 us of streaming needs the longer host.)
+    if (e->f32)
+      DTF_TRY(dtf_conv2_bwd_data_f32(e->dpool2, (const float*)e->pool2, e->amax2, e->P + e->off_Wc2, (const float*)e->pool1,
+                                     e->dpool1, B, nullptr, st));
+    else
+      DTF_TRY(dtf_conv2_bwd_data_lds_packed(e->dpool2, e->pool2, e->amax2, e->wc2b, e->pool1, e->dpool1, e->G + e->off_bc2, B,
+                                            st));
     if (e->f32)
       DTF_TRY(dtf_conv_dw_duo_f32(e->dpool2, (const float*)e->pool2, e->amax2, (const float*)e->pool1, e->G + e->off_Wc2,
                                   e->G + e->off_bc2, B,

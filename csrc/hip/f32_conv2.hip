@@ -254,17 +254,17 @@ constexpr int BD_RED = 8 * BD_MT * 2 * 256;      // [wave][tile][lane][4]: 20 48
 constexpr int BD_LDS = (BD_IMG > BD_RED ? BD_IMG : BD_RED) * 4;
 }  // namespace
 
-__global__ __launch_bounds__(512) void conv2_bwd_data_f32_kernel(const float* __restrict__ dpool2, const float* __restrict__ pool2,
-                                                                 const uint8_t* __restrict__ amax2, const float* __restrict__ W,
-                                                                 const float* __restrict__ pool1, float* __restrict__ dpool1,
-                                                                 const int B) {
-  extern __shared__ __attribute__((aligned(16))) float smem32[];
+__device__ __forceinline__ void conv2_bwd_data_f32_body(float* __restrict__ smem32, const int bid,
+                                                        const float* __restrict__ dpool2, const float* __restrict__ pool2,
+                                                        const uint8_t* __restrict__ amax2, const float* __restrict__ W,
+                                                        const float* __restrict__ pool1, float* __restrict__ dpool1,
+                                                        const int B) {
   float* dimg = smem32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int k0 = 8 * wave;  // this wave's output channels [k0, k0 + 8) of every tap
   const int npos = 196 * B;
-  const int P0 = blockIdx.x * BD_POS;
+  const int P0 = bid * BD_POS;
   const int b0 = P0 / 196;
   const int plast = min(P0 + BD_POS, npos) - 1;
   const bool two = plast / 196 != b0;  // (workgroup-uniform, like everything up to the task decode)
@@ -433,6 +433,25 @@ __global__ __launch_bounds__(512) void conv2_bwd_data_f32_kernel(const float* __
     }
   }
   CSTAMP(4);
+}
+
+// The data-gradient workgroups plus, optionally, trailing optimizer workgroups (W_fc1's Adam update: its gradient is final
+// since the fc backward launch).  80 KB of LDS per workgroup = two per CU, so the 245 MFMA-bound workgroups leave 267 resident
+// slots; the bandwidth-bound update runs in them instead of next to the (longer) filter-gradient launch.
+struct ConvBwdData32 {
+  const float* dpool2; const float* pool2; const uint8_t* amax2; const float* W; const float* pool1; float* dpool1;
+  int B, nbd;
+  OptimParams adam;  // adam.n == 0: no optimizer workgroups
+  int nadam;
+};
+
+__global__ __launch_bounds__(512) void conv2_bwd_data_f32_kernel(const ConvBwdData32 a) {
+  extern __shared__ __attribute__((aligned(16))) float smem32[];
+  const int id = blockIdx.x;
+  if (id < a.nbd)
+    conv2_bwd_data_f32_body(smem32, id, a.dpool2, a.pool2, a.amax2, a.W, a.pool1, a.dpool1, a.B);
+  else
+    adam_tf_body(a.adam, id - a.nbd, a.nadam, 512);
 }
 
 // ------------------------------------------------------------------ filter gradient
@@ -632,14 +651,24 @@ DTF_API int dtf_conv2_fwd_f32(const float* x, const float* W, const float* bias,
 }
 
 DTF_API int dtf_conv2_bwd_data_f32(const float* dpool2, const float* pool2, const void* amax2, const float* W,
-                                   const float* pool1, float* dpool1, int B, hipStream_t st) {
+                                   const float* pool1, float* dpool1, int B, const OptimParams* adam, hipStream_t st) {
   if (B <= 0) return ERR_SHAPE;
+  if (adam && (adam->n <= 0 || adam->n % 4 || adam->zero_from % 4 || !adam->step)) return ERR_SHAPE;
   if (!g_f32_attr_set) {
     const int rc = dtf_conv2_f32_init();
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(conv2_bwd_data_f32_kernel, dim3(dtf_cdiv(196L * B, BD_POS)), dim3(512), BD_LDS, st, dpool2, pool2,
-                     (const uint8_t*)amax2, W, pool1, dpool1, B);
+  ConvBwdData32 a;
+  a.dpool2 = dpool2; a.pool2 = pool2; a.amax2 = (const uint8_t*)amax2; a.W = W; a.pool1 = pool1; a.dpool1 = dpool1;
+  a.B = B; a.nbd = dtf_cdiv(196L * B, BD_POS);
+  a.adam = OptimParams{};
+  a.nadam = 0;
+  if (adam) {
+    a.adam = *adam;
+    a.adam.ticket = nullptr;  // (the step is advanced by the optimizer launch that covers the rest of the arena)
+    a.nadam = 512 - a.nbd > 64 ? 512 - a.nbd : 64;
+  }
+  hipLaunchKernelGGL(conv2_bwd_data_f32_kernel, dim3(a.nbd + a.nadam), dim3(512), BD_LDS, st, a);
   DTF_CHECK_LAUNCH();
   return 0;
 }

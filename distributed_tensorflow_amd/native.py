@@ -157,7 +157,7 @@ def hip() -> C.CDLL:
         _sig(lib, "dtf_conv2_f32_init", I, [])
         _sig(lib, "dtf_conv1_fwd_f32", I, [P, P, P, I, I, P, P, P, P, P])
         _sig(lib, "dtf_conv2_fwd_f32", I, [P, P, P, P, P, I, P])
-        _sig(lib, "dtf_conv2_bwd_data_f32", I, [P, P, P, P, P, P, I, P])
+        _sig(lib, "dtf_conv2_bwd_data_f32", I, [P, P, P, P, P, P, I, C.POINTER(OptimParams), P])
         _sig(lib, "dtf_conv_dw_duo_f32", I, [P, P, P, P, P, P, I, P, P, P, I, P, P, P, P, C.POINTER(OptimParams), P])
         _sig(lib, "dtf_graph_begin", I, [P])
         _sig(lib, "dtf_graph_end", I, [P, C.POINTER(c_void_p)])

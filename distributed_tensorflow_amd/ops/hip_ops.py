@@ -317,7 +317,7 @@ def conv2_backward_f32(dpool2: torch.Tensor, pool2: torch.Tensor, amax2: torch.T
     db = torch.zeros(64, dtype=torch.float32, device=dpool2.device)
     lib = native.hip()
     native.check(lib.dtf_conv2_bwd_data_f32(dpool2.data_ptr(), pool2.data_ptr(), amax2.data_ptr(), w.data_ptr(),
-                                            pool1.data_ptr(), dpool1.data_ptr(), B, _st()), "conv2_bwd_data_f32")
+                                            pool1.data_ptr(), dpool1.data_ptr(), B, None, _st()), "conv2_bwd_data_f32")
     native.check(lib.dtf_conv_dw_duo_f32(dpool2.data_ptr(), pool2.data_ptr(), amax2.data_ptr(), pool1.data_ptr(), dW.data_ptr(),
                                          db.data_ptr(), B, 0, 0, 0, 1, 0, 0, 0, 0, None, _st()), "conv2_dw_f32")
     return dpool1, dW, db

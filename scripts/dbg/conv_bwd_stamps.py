@@ -5,7 +5,7 @@ import numpy as np, torch
 here = os.path.dirname(os.path.abspath(__file__))
 lib = C.CDLL(os.path.join(here, "libf32conv_stamps.so"))
 P, I = C.c_void_p, C.c_int
-lib.dtf_conv2_bwd_data_f32.argtypes = [P, P, P, P, P, P, I, P]
+lib.dtf_conv2_bwd_data_f32.argtypes = [P, P, P, P, P, P, I, P, P]
 lib.dtf_conv_dw_duo_f32.argtypes = [P, P, P, P, P, P, I, P, P, P, I, P, P, P, P, P, P]
 lib.dtf_dbg_set_conv_stamps.argtypes = [P]
 B = 100
@@ -49,7 +49,7 @@ def report(name, nwg, n, labels, run, extra=()):
 
 report("conv2 bwd-data", (196 * B + 79) // 80, 5, "entry -> dY staged -> k loop done -> barrier -> end",
        lambda: lib.dtf_conv2_bwd_data_f32(dpool2.data_ptr(), pool2.data_ptr(), amax2.data_ptr(), W.data_ptr(), pool1.data_ptr(),
-                                          dpool1.data_ptr(), B, 0),
+                                          dpool1.data_ptr(), B, None, 0),
        extra=((5, "loads issued"), (6, "zero fill + barrier"), (7, "un-pool stores issued")))
 report("conv2 dW (conv2 role only)", ((B + 3) // 4) * 10, 6, "entry -> image 0 staged -> image 1 staged -> all k loops done -> barrier -> end",
        lambda: lib.dtf_conv_dw_duo_f32(dpool2.data_ptr(), pool2.data_ptr(), amax2.data_ptr(), pool1.data_ptr(), dW2.data_ptr(), db2.data_ptr(), B,
