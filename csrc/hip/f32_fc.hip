@@ -105,6 +105,11 @@ __global__ __launch_bounds__(256) void fc_bwd_trio_f32_kernel(const GemmTrio32 g
 }
 }  // namespace
 
+#ifdef DTF_GEMM32_STAMPS
+static void* g_trio_stamps = nullptr;  // (host global: every role's workgroups stamp into [workgroup][64])
+DTF_API void dtf_dbg_set_trio_stamps(void* p) { g_trio_stamps = p; }
+#endif
+
 // dW0[M0][N0] = X0^T dY0 (pitches M0 / N0), dW1[M1][N1] = X1^T dY1 (N1 <= 16, dY1 pitch ldy1) and
 // dX[Mq][Nq] += dYq[Mq][Kq] * Wq[Nq][Kq]^T (split over K, dX pre-zeroed) in one launch.  K = batch.
 DTF_API int dtf_fc_bwd_trio_f32(const float* X0, const float* dY0, float* dW0, int M0, int N0, const float* X1,
@@ -127,6 +132,9 @@ DTF_API int dtf_fc_bwd_trio_f32(const float* X0, const float* dY0, float* dW0, i
   g.q_mt = dtf_cdiv(Mq, 112);
   g.q_nt = dtf_cdiv(Nq, 64);
   g.nblk_q = g.q_mt * g.q_nt * s;
+#ifdef DTF_GEMM32_STAMPS
+  g.q.aux_out = g.d0.aux_out = g.d1.aux_out = g_trio_stamps;
+#endif
   hipLaunchKernelGGL(fc_bwd_trio_f32_kernel, dim3(g.nblk_q + g.nblk0 + nblk1), dim3(256), 0, st, g);
   DTF_CHECK_LAUNCH();
   return 0;

@@ -239,6 +239,9 @@ def run(FLAGS, distributed: bool) -> int:
         backbone = net.forward
     else:
         backbone = TinyBackbone(device, seed=seed)
+        _log(rank, "backbone: TinyBackbone (a fixed random projection of the down-sampled image, %s) — this exercises the "
+                   "retrain PLUMBING only; accuracies say nothing about Inception-v3.  Use --backbone inception on a GPU."
+             % ("requested" if getattr(FLAGS, "backbone", "auto") == "tiny" else "chosen because no GPU is present"))
     preproc = ImagePreprocessor(device)
     if backbone_kind == "inception" and need_calibration and index.num_images > 0:
         # random-init only: BatchNorm statistics from one batch of this dataset (same images on every rank)

@@ -337,5 +337,3 @@ def read_list_of_floats_from_file(file_path: str) -> List[float]:
         raise ValueError("%s: %d bytes, expected %d" % (file_path, len(raw), 8 * BOTTLENECK_TENSOR_SIZE))
     return np.frombuffer(raw, dtype=np.float64).tolist()
 
-
-bottleneck_path_2_bottleneck_values: dict = {}  # retrain1/retrain.py:369 (module-level memo the reference never fills)

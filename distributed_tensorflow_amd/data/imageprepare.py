@@ -20,22 +20,17 @@ def imageprepare(path: str) -> List[float]:
     from PIL import Image, ImageFilter
 
     im = Image.open(path).convert("L")
-    width, height = float(im.size[0]), float(im.size[1])
+    size = (float(im.size[0]), float(im.size[1]))
+    long_axis = 0 if size[0] > size[1] else 1          # 0: landscape, 1: portrait or square
+    # the long side becomes 20 px, the short side keeps the aspect (at least 1 px) and is centred on the 28-px canvas
+    short = max(1, int(round(20.0 / size[long_axis] * size[1 - long_axis], 0)))
+    margin = int(round((28 - short) / 2, 0))
+    new_size, corner = [0, 0], [0, 0]
+    new_size[long_axis], new_size[1 - long_axis] = 20, short
+    corner[long_axis], corner[1 - long_axis] = 4, margin
+    digit = im.resize(tuple(new_size), Image.LANCZOS).filter(ImageFilter.SHARPEN)
     canvas = Image.new("L", (28, 28), 255)
-    if width > height:
-        nheight = int(round((20.0 / width * height), 0))
-        if nheight == 0:
-            nheight = 1
-        img = im.resize((20, nheight), Image.LANCZOS).filter(ImageFilter.SHARPEN)
-        wtop = int(round(((28 - nheight) / 2), 0))
-        canvas.paste(img, (4, wtop))
-    else:
-        nwidth = int(round((20.0 / height * width), 0))
-        if nwidth == 0:
-            nwidth = 1
-        img = im.resize((nwidth, 20), Image.LANCZOS).filter(ImageFilter.SHARPEN)
-        wleft = int(round(((28 - nwidth) / 2), 0))
-        canvas.paste(img, (wleft, 4))
+    canvas.paste(digit, tuple(corner))
     px = np.asarray(canvas, dtype=np.float32).reshape(-1)
     return ((255.0 - px) * (1.0 / 255.0)).tolist()
 

@@ -31,37 +31,52 @@ def _st() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _pad_to(t: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    if t.shape[0] == rows and t.shape[1] == cols:
+        return t.contiguous()
+    out = torch.zeros(rows, cols, dtype=t.dtype, device=t.device)
+    out[:t.shape[0], :t.shape[1]] = t
+    return out
+
+
+def _up(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
 class _Linear(torch.autograd.Function):
-    # The MFMA kernels need K % 8 == 0 and even N; layers that do not fit (the 10-way logits) are a plain library
-    # GEMM (hipBLASLt through torch.mm), which is what such tiny shapes deserve anyway.
+    # The MFMA kernels need K % 8 == 0 and N % 8 == 0 (N % 2 in the forward).  Shapes that do not fit (the 10-way logits)
+    # are zero-padded to the next multiple and run through the same kernels: no library GEMM anywhere on this path.
     @staticmethod
     def forward(ctx, x, w, b, relu: bool):
-        xb = x.contiguous()
         K, N = w.shape
-        if K % 8 == 0 and N % 2 == 0:
-            y = hip_ops.fc_forward(xb, w.contiguous(), b, relu=relu)[0]
-        else:
-            y = xb.float() @ w
-            if b is not None:
-                y = y + b
-            if relu:
-                y = torch.relu(y)
-        ctx.save_for_backward(xb, w, y if relu else None)
-        ctx.has_bias = b is not None
+        Kp, Np = _up(K, 8), _up(N, 8)
+        xb = _pad_to(x, x.shape[0], Kp)
+        wp = _pad_to(w, Kp, Np)
+        bp = None if b is None else (b if Np == N else torch.cat([b, b.new_zeros(Np - N)]))
+        y = hip_ops.fc_forward(xb, wp, bp, relu=relu)[0]
+        if Np != N:
+            y = y[:, :N].contiguous()
+        ctx.save_for_backward(xb, wp, y if relu else None)
+        ctx.has_bias, ctx.kn = b is not None, (K, N)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y = ctx.saved_tensors
+        x, w, y = ctx.saved_tensors  # (padded operands)
+        K, N = ctx.kn
+        Kp, Np = w.shape
         if y is not None:
             dy = dy * (y > 0)
-        dyb = dy.to(torch.bfloat16).contiguous()
-        K, N = w.shape
+        dyb = _pad_to(dy.to(torch.bfloat16), dy.shape[0], Np)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = hip_ops.fc_backward_data(dyb, w.contiguous()) if N % 8 == 0 else dyb.float() @ w.t()
+            dx = hip_ops.fc_backward_data(dyb, w)
+            if Kp != K:
+                dx = dx[:, :K].contiguous()
         if ctx.needs_input_grad[1]:
-            dw = hip_ops.fc_backward_weight(x, dyb) if (K % 2 == 0 and N % 2 == 0) else x.float().t() @ dyb.float()
+            dw = hip_ops.fc_backward_weight(x, dyb)
+            if Kp != K or Np != N:
+                dw = dw[:K, :N].contiguous()
         db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
         if dx is not None and x.dtype != torch.float32:
             dx = dx.to(x.dtype)
@@ -69,7 +84,7 @@ class _Linear(torch.autograd.Function):
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
-    """``relu?(x[M,K] @ w[K,N] + b)`` -> fp32; ``x`` bf16 or fp32, K % 8 == 0, N even."""
+    """``relu?(x[M,K] @ w[K,N] + b)`` -> fp32; ``x`` bf16 or fp32 (any K, N: odd sizes are zero-padded to multiples of 8)."""
     return _Linear.apply(x, w, b, relu)
 
 

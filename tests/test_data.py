@@ -138,23 +138,6 @@ def test_packed_double_bottleneck_files(tmp_path):
         bn.write_list_of_floats_to_file([1.0, 2.0], p)
 
 
-def test_imagenet_node_lookup(tmp_path):
-    from distributed_tensorflow_amd.utils.imagenet_labels import NodeLookup
-    pb = tmp_path / "imagenet_2012_challenge_label_map_proto.pbtxt"
-    pb.write_text('# comment\nentry {\n  target_class: 449\n  target_class_string: "n01440764"\n}\n'
-                  'entry {\n  target_class: 450\n  target_class_string: "n01443537"\n}\n')
-    syn = tmp_path / "imagenet_synset_to_human_label_map.txt"
-    syn.write_text("n00004475\torganism, being\nn01440764\ttench, Tinca tinca\nn01443537\tgoldfish, Carassius auratus\n")
-    lk = NodeLookup(str(pb), str(syn))
-    assert lk.id_to_string(449) == "tench, Tinca tinca" and lk.id_to_string(7) == ""
-    probs = [0.0] * 460
-    probs[450], probs[449] = 0.7, 0.2
-    assert lk.top_k(probs, 2) == [(450, "goldfish, Carassius auratus", 0.7), (449, "tench, Tinca tinca", 0.2)]
-    syn.write_text("n01440764\ttench\n")
-    with pytest.raises(ValueError):
-        NodeLookup(str(pb), str(syn))
-
-
 def test_decode_pipeline_matches_serial_extraction(tmp_path):
     """The extraction pipeline (decode processes -> shared ring -> preprocess) fills the cache with exactly the bottlenecks
     the serial path computes, including a short last batch and images of mixed sizes, one of them large enough for the
