@@ -302,25 +302,57 @@ struct PackDesc {
   int taps, cin, cout, pad;
 };
 
+// One tile = (tap, 32 input channels, 64 output channels): read coalesced along co (the master's contiguous axis), written
+// straight out for Wq (co contiguous) and through an LDS transpose for Wp (ci contiguous), so both stores are full
+// 64-128-byte segments (the element-wise version scattered 2-byte stores at stride K: 0.64 TB/s).
 __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const float* __restrict__ arena, const PackDesc* __restrict__ descs,
                                                                 uint16_t* __restrict__ Wp, uint16_t* __restrict__ Wq) {
+  __shared__ uint16_t t[32][66];
   const PackDesc d = descs[blockIdx.y];
-  const long n = (long)d.taps * d.cin * d.cout;
   const float* w = arena + d.w_off;
   const int K = d.taps * d.cin, Kq = d.taps * d.cout;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const int co = (int)(i % d.cout);
-    const long t = i / d.cout;
-    const int ci = (int)(t % d.cin), tap = (int)(t / d.cin);
-    const uint16_t v = f2bf(w[i]);
-    Wp[d.p_off + (long)co * K + tap * d.cin + ci] = v;
-    Wq[d.q_off + (long)ci * Kq + tap * d.cout + co] = v;
+  const int nci = (d.cin + 31) >> 5, nco = (d.cout + 63) >> 6;
+  const int ntile = d.taps * nci * nco;
+  const int tid = threadIdx.x;
+  const int col = tid & 63, row0 = tid >> 6;         // load / Wq mapping: 4 rows per pass
+  const int oc = tid >> 2, chunk = (tid & 3) * 8;    // Wp mapping: one co, 8 consecutive ci
+  for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int cot = tile % nco, r = tile / nco;
+    const int cit = r % nci, tap = r / nci;
+    const int ci0 = cit * 32, co0 = cot * 64;
+    __syncthreads();  // the previous tile has been read out
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = row0 + 4 * j;
+      const int ci = ci0 + row, co = co0 + col;
+      uint16_t v = 0;
+      if (ci < d.cin && co < d.cout) {
+        v = f2bf(w[((long)tap * d.cin + ci) * d.cout + co]);
+        Wq[d.q_off + (long)ci * Kq + tap * d.cout + co] = v;
+      }
+      t[row][col] = v;
+    }
+    __syncthreads();
+    const int co = co0 + oc;
+    if (co < d.cout) {
+      uint16_t* dst = Wp + d.p_off + (long)co * K + tap * d.cin + ci0 + chunk;
+      if (ci0 + chunk + 8 <= d.cin && ((d.p_off + (long)co * K + tap * d.cin + ci0 + chunk) & 7) == 0) {
+        uint32_t u[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = (uint32_t)t[chunk + 2 * e][oc] | ((uint32_t)t[chunk + 2 * e + 1][oc] << 16);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(u[0], u[1], u[2], u[3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (ci0 + chunk + e < d.cin) dst[e] = t[chunk + e][oc];
+      }
+    }
   }
 }
 
 DTF_API int dtf_pack_conv_weights(const float* arena, const void* descs, int nconv, void* Wp, void* Wq, hipStream_t st) {
   if (nconv <= 0) return ERR_SHAPE;
-  hipLaunchKernelGGL(pack_conv_weights_kernel, dim3(64, nconv), dim3(256), 0, st, arena, (const PackDesc*)descs,
+  hipLaunchKernelGGL(pack_conv_weights_kernel, dim3(96, nconv), dim3(256), 0, st, arena, (const PackDesc*)descs,
                      (uint16_t*)Wp, (uint16_t*)Wq);
   DTF_CHECK_LAUNCH();
   return 0;
