@@ -514,7 +514,11 @@ __global__ __launch_bounds__(256) void dw2_kernel(const DW2Params q) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int ci = ci0 + wm * WT + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+#ifdef DTF_DW2_PLAIN_STORES  // (timing experiment only: wrong sums, shows what the atomics cost)
+        if (ci < g.Cin && co < q.Cout) q.dW[((long)tap * g.Cin + ci) * q.Cout + co] = acc[a][b][i];
+#else
         if (ci < g.Cin && co < q.Cout) atomicAdd(&q.dW[((long)tap * g.Cin + ci) * q.Cout + co], acc[a][b][i]);
+#endif
       }
     }
 #endif

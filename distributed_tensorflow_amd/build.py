@@ -106,6 +106,7 @@ def _recipe(which: str):
     if which == "hip":
         d = os.path.join(CSRC, "hip")
         cc = [HIPCC, "--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-I", d]
+        cc += os.environ.get("DTF_EXTRA_HIPCC_FLAGS", "").split()  # (experiments; part of the digest)
         ld = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC"]
         return d, (".hip",), cc, ld, os.path.join(LIBDIR, "libdtf_hip.so")
     d = os.path.join(CSRC, "host")
