@@ -6,7 +6,7 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 mkdir -p gpurun_out/soak
 for n in ${@:-2 4}; do
   timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29660 + n)) \
-    bench.py --gpus $n --steps 100000 --warmup 200 --backend gloo > gpurun_out/soak/n$n.log 2>&1 || { tail -20 gpurun_out/soak/n$n.log; exit 1; }
+    bench.py --gpus $n --steps 100000 --warmup 200 --backend gloo --extra-dtype none --ref-steps 0 ${DTF_BENCH_ARGS} > gpurun_out/soak/n$n.log 2>&1 || { tail -20 gpurun_out/soak/n$n.log; exit 1; }
   grep "^{" gpurun_out/soak/n$n.log | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
