@@ -586,7 +586,11 @@ __device__ __forceinline__ void conv2_dw_f32_body(float* __restrict__ smem, cons
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int cin = mtt * 16 + 4 * q + i, cout = c * 32 + nt * 16 + r;
+#ifdef DTF_DW_PLAIN_STORES  // (timing experiment only: wrong sums, shows what the atomics cost)
+      dW[((long)(dy * 5 + dx) * 32 + cin) * 64 + cout] = s[i];
+#else
       atomicAdd(&dW[((long)(dy * 5 + dx) * 32 + cin) * 64 + cout], s[i]);
+#endif
     }
   }
   CSTAMP(5);
