@@ -225,7 +225,7 @@ def main():
             "data": "synthetic MNIST-shaped (28x28x1, 10 classes), random-init weights",
             "config": {"model": "demo2 MNIST CNN (conv5x5x32-pool-conv5x5x64-pool-fc1024-dropout-fc10), Adam 1e-4",
                        "global_batch": global_batch, "seq_len": None, "parallelism": "dp%d" % world,
-                       "per_gpu_batch": args.batch, "engine": args.engine, "hipgraph": not args.no_graph,
+                       "per_gpu_batch": args.batch, "engine": args.engine, "hipgraph": (not args.no_graph) and args.engine == "native",
                        "overlap_allreduce": (not args.no_overlap) if trainer._multi else None,
                        "gradient_transport": trainer.comm if trainer._multi else None,
                        "dp_schedule": getattr(trainer, "schedule", None)},
