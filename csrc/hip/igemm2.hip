@@ -364,7 +364,11 @@ DTF_API int dtf_pack_conv_weights(const float* arena, const void* descs, int nco
 // Both MFMA operands are K-major here (K = output positions) while memory is channel-major, so the tiles are staged in
 // their natural [position][channel] layout by the same asynchronous global->LDS ring and transposed on the way out of
 // LDS by ds_read_b64_tr_b16 (one transposing read delivers 4 consecutive k for this lane's m/n column).
-//   workgroup = (split z, tap, ci tile, co tile); 4 waves as 2x2; wave tile = (BT/2)^2; K-step = 64 positions.
+//   workgroup = (split z, m tile, co tile) where m = tap * Cin + ci runs over the FLATTENED filter rows (HWIO is exactly
+//   [m][co]): a layer with fewer input channels than the tile is wide packs several taps into one tile instead of
+//   leaving it half empty (32 -> 32 channels, 3x3: 5 tiles of 64 rows instead of 9 quarter-full ones; every lane's 8
+//   channels belong to one tap, so its tap shift is a per-lane constant and the K loop is unchanged);
+//   4 waves as 2x2; wave tile = (BT/2)^2; K-step = 64 positions.
 //   LDS row = BT channels (BT*2 bytes).  A transposing read is served per 32-lane half = 4 k-rows x 64 B; the 16-byte
 //   chunk c of row r is stored at c ^ 4*(r & 3) (256-B rows) or c ^ 4*((r >> 1) & 1) (128-B rows, where row parity
 //   already selects the half of the bank row), which puts those four 64-B pieces on four different quarters of the
@@ -378,7 +382,7 @@ struct DW2Params {
   const uint16_t* dz;
   float* dW;
   ConvGeom g;  // H, W, Cin, cstride (of x), Ho, Wo, KH, KW, stride, pad
-  int Cout, K, kchunk, nit, nct, taps;
+  int Cout, K, kchunk, nmt, nct, Mtot;  // Mtot = taps * Cin filter rows, nmt tiles of them
   int rw, rh, qh;  // 64 positions = (qh*Ho + rh) rows + rw columns
 };
 
@@ -394,11 +398,9 @@ __global__ __launch_bounds__(256) void dw2_kernel(const DW2Params q) {
   const ConvGeom g = q.g;
   int id = blockIdx.x;
   const int ct = id % q.nct; id /= q.nct;
-  const int it = id % q.nit; id /= q.nit;
-  const int tap = id % q.taps;
-  const int z = id / q.taps;
-  const int ci0 = it * BT, co0 = ct * BT;
-  const int dy = tap / g.KW - g.pad_h, dx = tap % g.KW - g.pad_w;
+  const int mt = id % q.nmt;
+  const int z = id / q.nmt;
+  const int m0 = mt * BT, co0 = ct * BT;
   const int kbeg = z * q.kchunk;
   const int kend = min(q.K, kbeg + q.kchunk);
   if (kbeg >= kend) return;
@@ -406,7 +408,11 @@ __global__ __launch_bounds__(256) void dw2_kernel(const DW2Params q) {
   const int lrow = lane / CH, pch = lane % CH;
   // logical channel offset fetched by this lane (swizzle on the global side), see the bank note above
   const int cofs = (pch ^ (BT == 128 ? 4 * (lrow & 3) : 4 * ((lrow >> 1) & 1))) * 8;
-  const bool xc_ok = ci0 + cofs < g.Cin, zc_ok = co0 + cofs < q.Cout;
+  // this lane's 8 filter rows m0 + cofs .. + 7 = (tap, ci .. ci + 7): Cin % 8 == 0, so they never straddle two taps
+  const int mrow = m0 + cofs;
+  const bool xc_ok = mrow < q.Mtot, zc_ok = co0 + cofs < q.Cout;
+  const int tap = xc_ok ? mrow / g.Cin : 0, ci_l = mrow - tap * g.Cin;
+  const int dy = tap / g.KW - g.pad_h, dx = tap % g.KW - g.pad_w;
   const int npos = g.Ho * g.Wo;
   // Issuing a K-step must stay well below the MFMA time of the step (one wave per SIMD): the (image, row, column) of
   // each of this lane's positions is decoded with real divisions ONCE and then advanced by 64 positions per step with
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(256) void dw2_kernel(const DW2Params q) {
     ph[i] = rem / g.Wo;
     pw[i] = rem - ph[i] * g.Wo;
   }
-  const unsigned xcol = (unsigned)(ci0 + cofs) * 2u, zcol = (unsigned)(co0 + cofs) * 2u;
+  const unsigned xcol = (unsigned)ci_l * 2u, zcol = (unsigned)(co0 + cofs) * 2u;
 
   // loads of the step the decoded positions currently stand at, then advance them by KP
   auto issue = [&](int sb) {
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(256) void dw2_kernel(const DW2Params q) {
     }
   }
   wait_vmcnt<0>();
-  // epilogue: fp32 atomics into dW[(tap, ci)][co]; lanes 0..31 cover 32 consecutive co (128 B)
+  // epilogue: fp32 atomics into dW[m = (tap, ci)][co]; lanes 0..31 cover 32 consecutive co (128 B)
   const int h = lane >> 5, r = lane & 31;
 #pragma unroll
   for (int a = 0; a < T; ++a)
@@ -513,11 +519,11 @@ __global__ __launch_bounds__(256) void dw2_kernel(const DW2Params q) {
       const int co = co0 + wn * WT + b * 32 + r;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int ci = ci0 + wm * WT + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int m = m0 + wm * WT + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
 #ifdef DTF_DW2_PLAIN_STORES  // (timing experiment only: wrong sums, shows what the atomics cost)
-        if (ci < g.Cin && co < q.Cout) q.dW[((long)tap * g.Cin + ci) * q.Cout + co] = acc[a][b][i];
+        if (m < q.Mtot && co < q.Cout) q.dW[(long)m * q.Cout + co] = acc[a][b][i];
 #else
-        if (ci < g.Cin && co < q.Cout) atomicAdd(&q.dW[((long)tap * g.Cin + ci) * q.Cout + co], acc[a][b][i]);
+        if (m < q.Mtot && co < q.Cout) atomicAdd(&q.dW[(long)m * q.Cout + co], acc[a][b][i]);
 #endif
       }
     }
@@ -544,7 +550,7 @@ DTF_API int dtf_conv_dw_v2(const void* x, int in_cstride, const void* dz, float*
   q.x = (const uint16_t*)x; q.dz = (const uint16_t*)dz; q.dW = dW;
   q.g.H = H; q.g.W = W; q.g.Cin = Cin; q.g.cstride = in_cstride; q.g.Ho = Ho; q.g.Wo = Wo;
   q.g.KH = KH; q.g.KW = KW; q.g.stride = stride; q.g.pad_h = pad_h; q.g.pad_w = pad_w;
-  q.Cout = Cout; q.K = B * Ho * Wo; q.taps = KH * KW;
+  q.Cout = Cout; q.K = B * Ho * Wo; q.Mtot = KH * KW * Cin;
   q.rw = 64 % Wo;
   q.rh = (64 / Wo) % Ho;
   q.qh = (64 / Wo) / Ho;
@@ -554,9 +560,9 @@ DTF_API int dtf_conv_dw_v2(const void* x, int in_cstride, const void* dz, float*
   const int nz = dtf_cdiv(q.K, q.kchunk);
   const bool big = Cin > 64 && Cout > 64 && !(variant & 1);  // variant 1: 64-wide tiles regardless
   const int BT = big ? 128 : 64;
-  q.nit = dtf_cdiv(Cin, BT);
+  q.nmt = dtf_cdiv(q.Mtot, BT);
   q.nct = dtf_cdiv(Cout, BT);
-  const long blocks = (long)nz * q.taps * q.nit * q.nct;
+  const long blocks = (long)nz * q.nmt * q.nct;
   if (blocks > 0x7fffffffL) return ERR_SHAPE;
   if (big)
     hipLaunchKernelGGL(dw2_kernel<128>, dim3((int)blocks), dim3(256), 3 * 2 * 64 * 128 * 2, st, q);

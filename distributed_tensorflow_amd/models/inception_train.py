@@ -464,7 +464,7 @@ class InceptionTrainer:
         fewest splits that still put one resident workgroup on every CU (96 KB of LDS: one 128-tile workgroup per CU,
         three 64-tile ones)."""
         bt = 128 if (s.cin > 64 and s.cout > 64 and not variant) else 64
-        tiles = s.kh * s.kw * ((s.cin + bt - 1) // bt) * ((s.cout + bt - 1) // bt)
+        tiles = ((s.kh * s.kw * s.cin + bt - 1) // bt) * ((s.cout + bt - 1) // bt)  # (filter rows are flattened over taps)
         target = int(os.environ.get("DTF_DW_BLOCKS", "0")) or (256 if bt == 128 else 768)
         # round DOWN: one workgroup more than fits at once costs a whole extra round (measured: 280 workgroups of a
         # 256-slot grid took 2 x 37 us)
