@@ -96,3 +96,12 @@ def test_retrain2_stop_relaunch_resume_two_ranks(tmp_path):
     assert first >= step, (first, step)
     assert "Final test accuracy" in r2.stdout and os.path.exists(os.path.join(cwd, "retrained_graph.pb"))
     assert os.path.exists(os.path.join(cwd, "logs", "model.ckpt-30"))
+    # the distributed run's bundle is self-contained too: retrain2/test.py classifies held-out images with it alone
+    from distributed_tensorflow_amd.data import image_lists as il
+    held = il.make_synthetic_image_dir(os.path.join(cwd, "held_out"), num_classes=3, images_per_class=4, seed=77)
+    r3 = _cli([os.path.join(REPO, "retrain2", "test.py"), "--imgs", held, "--device", "cpu"], cwd)
+    assert r3.returncode == 0, r3.stdout[-3000:]
+    top1 = [l[3:] for l in r3.stdout.splitlines() if l.startswith("=> ")]
+    files = [l for l in r3.stdout.splitlines() if l.endswith(".jpg")]
+    truth = [os.path.basename(os.path.dirname(f)).replace("_", " ") for f in files]
+    assert len(top1) == len(truth) == 12 and np.mean([a == b for a, b in zip(top1, truth)]) >= 0.75, list(zip(top1, truth))
