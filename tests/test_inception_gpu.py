@@ -230,3 +230,28 @@ def test_retrain2_two_ranks_one_gpu(tmp_path):
     acc = float(r.stdout.split("Final test accuracy = ")[1].split("%")[0])
     assert acc >= 80.0, r.stdout[-1500:]
     assert os.path.exists(w + "/rg.pb") and os.path.exists(w + "/labels.txt")
+
+
+def test_extraction_pipeline_matches_serial_path_on_gpu(tmp_path):
+    """decode processes -> pinned ring -> side-stream H2D + resize -> Inception forward fills the HBM cache with the same
+    bottlenecks as the serial decode / copy / forward loop (short last batch included), and reports its stage split."""
+    from distributed_tensorflow_amd.data import image_lists as il
+    from distributed_tensorflow_amd.data.bottleneck import BottleneckCache, ImagePreprocessor
+    from distributed_tensorflow_amd.data.pipeline import DecodePipeline
+    from distributed_tensorflow_amd.models.inception_v3 import InceptionV3
+    d = il.make_synthetic_image_dir(str(tmp_path / "imgs"), num_classes=2, images_per_class=21, seed=9)
+    index = il.build_image_index(il.create_image_lists(d, 10, 10), d)
+    net = InceptionV3(DEV, seed=2)
+    a = BottleneckCache(index, DEV)
+    a.extract(net.forward, ImagePreprocessor(DEV), batch_size=16, progress=None)
+    pipe = DecodePipeline(DEV, batch_size=16, workers=3, slots=3, chunk=4)
+    try:
+        b = BottleneckCache(index, DEV)
+        n = b.extract(net.forward, ImagePreprocessor(DEV), batch_size=16, progress=None, pipeline=pipe)
+        st = b.extract_stats
+    finally:
+        pipe.close()
+    torch.cuda.synchronize()
+    assert n == index.num_images == 42 and st["batches"] == 3
+    assert torch.allclose(a.values, b.values, rtol=1e-3, atol=1e-3), float((a.values - b.values).abs().max())
+    assert float(b.values.abs().sum()) > 0 and {"h2d_ms_per_batch", "gpu_ms_per_batch", "decode_wait_s"} <= set(st)
