@@ -204,6 +204,7 @@ class DecodePipeline:
                 d.off_y, d.off_x, d.flip, d.brightness = 0.0, 0.0, 0, 1.0
             return descs
 
+        import threading
         # ---- feeder thread: waits for the decoders, moves the finished batch into its pinned buffer (the copy is split
         # over a few threads; it releases the GIL), hands the shared slot back to the decoders, and passes the batch on
         import queue
@@ -211,6 +212,10 @@ class DecodePipeline:
         from concurrent.futures import ThreadPoolExecutor
         ready: "queue.Queue" = queue.Queue(maxsize=self.slots)
         tstat = {"wait": 0.0, "worker": 0.0, "copy": 0.0}
+        # a pinned buffer may be refilled only after the consumer thread has ENQUEUED the DMA out of it (and recorded the
+        # event the feeder then waits on): `issued` is the newest batch for which that has happened
+        issued = [-1]
+        issued_cv = threading.Condition()
         ncopy = 4
         copiers = ThreadPoolExecutor(max_workers=ncopy) if cuda else None
 
@@ -228,6 +233,9 @@ class DecodePipeline:
                     if cuda:
                         t0 = time.perf_counter()
                         if k >= self.slots:
+                            with issued_cv:
+                                while issued[0] < k - self.slots and not failed[0]:
+                                    issued_cv.wait(0.5)
                             copied[s].synchronize()  # the DMA out of this pinned buffer (batch k - slots) has finished
                         cut = [(nbytes * c // ncopy) & ~63 for c in range(ncopy)] + [nbytes]
                         list(copiers.map(lambda c: self._pin[s][cut[c]:cut[c + 1]].copy_(self._host[s][cut[c]:cut[c + 1]]),
@@ -247,44 +255,54 @@ class DecodePipeline:
             except BaseException as e:  # noqa: BLE001 - hand the failure to the consuming thread
                 ready.put(e)
 
+        failed = [False]
         th = threading.Thread(target=feeder, name="dtf-extract-feeder", daemon=True)
         th.start()
         idle_s = 0.0
-        for _ in range(nb):
-            t0 = time.perf_counter()
-            item = ready.get()
-            idle_s += time.perf_counter() - t0
-            if isinstance(item, BaseException):
-                raise item
-            k, descs, imgs = item
-            s, xb = k % self.slots, k % 2
-            lo, hi = k * B, min(n, (k + 1) * B)
-            nbytes = int(batch_bytes[k])
-            if not cuda:
-                consume(lo, hi - lo, preprocess_cpu(imgs, descs))
-                continue
-            te = t_ev[k] if k < len(t_ev) else None
-            with torch.cuda.stream(side):
-                side.wait_event(x_free[xb])  # the forward of batch k-2 has consumed this input buffer
-                if te:
-                    te[0].record(side)
-                pix[xb][:nbytes].copy_(self._pin[s][:nbytes], non_blocking=True)
-                desc_dev[xb].copy_(desc_host[s], non_blocking=True)
-                copied[s].record(side)
-                if te:
-                    te[1].record(side)
-                native.check(lib.dtf_preprocess_images(pix[xb].data_ptr(), desc_dev[xb].data_ptr(), xbuf[xb].data_ptr(), B,
-                                                       INPUT_SIZE, side.cuda_stream), "preprocess")
-                if te:
-                    te[2].record(side)
-                x_ready[xb].record(side)
-            main.wait_event(x_ready[xb])
-            if k < len(g_ev):
-                g_ev[k][0].record(main)
-            consume(lo, hi - lo, xbuf[xb])
-            if k < len(g_ev):
-                g_ev[k][1].record(main)
-            x_free[xb].record(main)
+        try:
+          for _ in range(nb):
+              t0 = time.perf_counter()
+              item = ready.get()
+              idle_s += time.perf_counter() - t0
+              if isinstance(item, BaseException):
+                  raise item
+              k, descs, imgs = item
+              s, xb = k % self.slots, k % 2
+              lo, hi = k * B, min(n, (k + 1) * B)
+              nbytes = int(batch_bytes[k])
+              if not cuda:
+                  consume(lo, hi - lo, preprocess_cpu(imgs, descs))
+                  continue
+              te = t_ev[k] if k < len(t_ev) else None
+              with torch.cuda.stream(side):
+                  side.wait_event(x_free[xb])  # the forward of batch k-2 has consumed this input buffer
+                  if te:
+                      te[0].record(side)
+                  pix[xb][:nbytes].copy_(self._pin[s][:nbytes], non_blocking=True)
+                  desc_dev[xb].copy_(desc_host[s], non_blocking=True)
+                  copied[s].record(side)
+                  if te:
+                      te[1].record(side)
+                  native.check(lib.dtf_preprocess_images(pix[xb].data_ptr(), desc_dev[xb].data_ptr(), xbuf[xb].data_ptr(), B,
+                                                         INPUT_SIZE, side.cuda_stream), "preprocess")
+                  if te:
+                      te[2].record(side)
+                  x_ready[xb].record(side)
+              with issued_cv:
+                  issued[0] = k
+                  issued_cv.notify_all()
+              main.wait_event(x_ready[xb])
+              if k < len(g_ev):
+                  g_ev[k][0].record(main)
+              consume(lo, hi - lo, xbuf[xb])
+              if k < len(g_ev):
+                  g_ev[k][1].record(main)
+              x_free[xb].record(main)
+        except BaseException:
+            failed[0] = True  # (lets a feeder that is waiting for this thread's progress leave its loop)
+            with issued_cv:
+                issued_cv.notify_all()
+            raise
         th.join()
         if copiers is not None:
             copiers.shutdown()
