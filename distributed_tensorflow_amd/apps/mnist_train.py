@@ -118,7 +118,7 @@ def run(FLAGS, distributed: bool) -> int:
                 store, store_server = cl.job_store(rank, world)
         sv = Supervisor(trainer, is_chief=(rank == 0), logdir=FLAGS.log_dir, save_model_secs=FLAGS.save_model_secs,
                         summary_writer=writer, log_fn=lambda m: _log(rank, m), store=store,
-                        heartbeat_period_s=float(os.environ.get("DTF_HEARTBEAT_PERIOD_S", "1.0")),
+                        heartbeat_period_s=float(os.environ.get("DTF_HEARTBEAT_PERIOD_S", "5.0")),
                         fatal_grace_s=float(os.environ.get("DTF_FATAL_GRACE_S", "20")))
         sv.prepare_or_wait_for_session()
         sv.start_standard_services()

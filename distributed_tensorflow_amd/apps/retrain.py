@@ -295,7 +295,7 @@ def run(FLAGS, distributed: bool) -> int:
         sv = Supervisor(_HeadTrainer(head, rank, world), is_chief=(rank == 0), logdir=FLAGS.log_dir,
                         saver=_HeadSaver(head), save_model_secs=FLAGS.save_model_secs, summary_writer=train_writer,
                         log_fn=lambda m: _log(rank, m), store=store,
-                        heartbeat_period_s=float(os.environ.get("DTF_HEARTBEAT_PERIOD_S", "1.0")),
+                        heartbeat_period_s=float(os.environ.get("DTF_HEARTBEAT_PERIOD_S", "5.0")),
                         fatal_grace_s=float(os.environ.get("DTF_FATAL_GRACE_S", "20")))
         sv.prepare_or_wait_for_session()
         sv.start_standard_services()
