@@ -102,6 +102,10 @@ def hip() -> C.CDLL:
     with _lock:
         if _hip is not None:
             return _hip
+        # torch first: it ships its own libamdhip64, and the process must only ever have ONE HIP runtime.  Loaded before
+        # torch, this library binds the system runtime, torch then brings a second one, and the first kernel-attribute
+        # call fails with hipErrorNoDevice (seen when build() and smoke() ran in one process).
+        import torch  # noqa: F401
         lib = C.CDLL(_ensure_built("libdtf_hip.so"))
         P, I, L, F = c_void_p, c_int, c_long, c_float
         _sig(lib, "dtf_version", I, [])
