@@ -30,6 +30,8 @@ CXX = os.environ.get("CXX") or shutil.which("g++") or "g++"
 
 def _digest(paths: List[str], extra: str = "") -> str:
     # location independent: the tree is copied to another path on the GPU box and must hash the same there
+    # (the compiler is named by its base name: the same toolchain can sit behind /opt/rocm or /opt/rocm-x.y.z on PATH)
+    extra = " ".join(os.path.basename(w) if w in (HIPCC, CXX) else w for w in extra.split(" "))
     h = hashlib.sha1(extra.replace(ROOT, "$ROOT").encode())
     for p in sorted(paths):
         with open(p, "rb") as f:
