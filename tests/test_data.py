@@ -176,3 +176,21 @@ def test_decode_pipeline_matches_serial_extraction(tmp_path):
     rel = float((a.values[bigrow] - b.values[bigrow]).norm() / a.values[bigrow].norm())
     assert rel < 0.05, rel
     assert "images/s" in DecodePipeline.describe(st)
+
+
+def test_decode_pipeline_reports_undecodable_files(tmp_path):
+    """A file that is not an image fails the header probe with a clear error before any batch is scheduled."""
+    import pytest
+    from distributed_tensorflow_amd.data import image_lists as il
+    from distributed_tensorflow_amd.data.pipeline import DecodePipeline
+    d = il.make_synthetic_image_dir(str(tmp_path / "imgs"), num_classes=1, images_per_class=3, seed=1)
+    sub = sorted(os.listdir(d))[0]
+    bad = os.path.join(d, sub, "broken.jpg")
+    open(bad, "wb").write(b"not a jpeg at all")
+    paths = sorted(os.path.join(d, sub, f) for f in os.listdir(os.path.join(d, sub)))
+    pipe = DecodePipeline("cpu", batch_size=2, workers=1, slots=2, chunk=2)
+    try:
+        with pytest.raises(ValueError, match="undecodable"):
+            pipe.run(paths, lambda first, count, x: None, preprocess_cpu=lambda imgs, descs: None)
+    finally:
+        pipe.close()

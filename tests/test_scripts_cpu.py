@@ -47,3 +47,16 @@ def test_pmc_summary():
     assert "MFMA pipe busy on 6.1%" in out
     assert "LDS bank-conflict cycles / LDS active = 45.0%" in out
     assert "waiting on any instruction / wave cycles = 10.0%" in out
+
+
+def test_demo1_profile_prints_the_host_phase_split(tmp_path):
+    """``--profile`` wires ``utils.trace.StepTimer`` into the loop: the log ends with the host-side split."""
+    import subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "demo1", "train.py"), "--device", "cpu", "--synthetic", "true",
+                        "--training_steps", "3", "--eval_step_interval", "2", "--batch_size", "8", "--eval_train_set", "false",
+                        "--profile"], cwd=str(tmp_path), env=dict(os.environ, PYTHONPATH=repo, OMP_NUM_THREADS="2"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("host phases:")]
+    assert line and "train steps (launch)" in line[0] and "evaluation" in line[0] and "images/sec" in line[0], r.stdout[-1500:]
