@@ -265,8 +265,8 @@ def run(FLAGS, distributed: bool) -> int:
                                 txt_dir=FLAGS.bottleneck_dir if FLAGS.bottleneck_txt_cache else None,
                                 progress=(print if rank == 0 else None), pipeline=pipeline)
     finally:
-        if pipeline is not None:
-            pipeline.close()
+        if pipeline is not None and not distortion.enabled:
+            pipeline.close()  # (a distorted run keeps the decode processes: its training batches stream through them)
     if device.type == "cuda":
         torch.cuda.synchronize()
     dt = time.time() - t_extract
@@ -334,13 +334,23 @@ def run(FLAGS, distributed: bool) -> int:
     i = head.global_step if sv is not None else 0
     start_step = i
     rc = 0
+    distorted = None
+    if distortion.enabled and pipeline is not None and steps > i:
+        # reference get_random_distorted_bottlenecks (retrain1/retrain.py:300-319) runs 2 x batch sess.run calls per step;
+        # here the whole schedule is drawn up front and streamed: decode + H2D of later steps run under the current one
+        from ..data.bottleneck import distorted_bottleneck_stream
+        distorted = distorted_bottleneck_stream(index, FLAGS.train_batch_size, "training", backbone, pipeline, distortion,
+                                                rng, steps - i)
     try:
         while i < steps and not (sv is not None and sv.should_stop()):
             if FLAGS.fault_inject_step >= 0 and i == FLAGS.fault_inject_step and rank == world - 1:
                 raise RuntimeError("injected fault at step %d" % i)
             if distortion.enabled:
-                feats, labels = get_random_distorted_bottlenecks(index, FLAGS.train_batch_size, "training", backbone,
-                                                                 preproc, distortion, rng)
+                if distorted is not None:
+                    feats, labels = next(distorted)
+                else:
+                    feats, labels = get_random_distorted_bottlenecks(index, FLAGS.train_batch_size, "training", backbone,
+                                                                     preproc, distortion, rng)
                 head.train_step(feats, labels, None, ring_slot=i % RING)
                 train_src = (feats, labels, None)
             else:
@@ -382,6 +392,12 @@ def run(FLAGS, distributed: bool) -> int:
         if sv is None or world == 1:
             raise
     finally:
+        if distorted is not None:
+            distorted.close()
+        if pipeline is not None and distortion.enabled:
+            if rank == 0 and pipeline.stats:
+                print("distorted training stream: " + type(pipeline).describe(pipeline.stats), flush=True)
+            pipeline.close()
         if sv is not None:
             sv.stop(final_save=True)
     if rc != 0 or (sv is not None and i < steps):

@@ -318,6 +318,50 @@ def get_random_distorted_bottlenecks(index: ImageIndex, how_many: int, category:
     return feats, torch.as_tensor(labels, dtype=torch.int32, device=feats.device)
 
 
+def distorted_bottleneck_stream(index: ImageIndex, how_many: int, category: str, backbone, pipeline, distortion: Distortion,
+                                rng: random.Random, steps: int):
+    """The same batches as ``steps`` consecutive calls of ``get_random_distorted_bottlenecks`` with this ``rng`` (same
+    draws in the same order: per step ``how_many`` x (class, image index), then ``how_many`` distortions), but streamed
+    through the decode pipeline (``data/pipeline.py``): the JPEGs of step k+1.. are decoded by the worker processes and
+    copied to the device while step k runs.  Yields ``(bottlenecks fp32 [how_many, 2048], labels int32 [how_many])``.
+    The plan is drawn up front as flat arrays (row index, label, 5 distortion parameters per image: 28 bytes each)."""
+    s = CATEGORIES.index(category)
+    C_ = index.num_classes
+    n = steps * how_many
+    rows = np.empty(n, np.int64)
+    labels = np.empty(n, np.int32)
+    dist = np.empty((n, 5), np.float64)
+    for st in range(steps):
+        base = st * how_many
+        for j in range(how_many):
+            c = rng.randrange(C_)
+            tries = 0
+            while index.counts[c, s] == 0 and tries < C_:
+                c = (c + 1) % C_
+                tries += 1
+            image_index = rng.randrange(MAX_NUM_IMAGES_PER_CLASS + 1)
+            rows[base + j] = int(index.offsets[c, s] + image_index % max(1, index.counts[c, s]))
+            labels[base + j] = c
+        for j in range(how_many):
+            precrop, oy, ox, flip, bright = distortion.sample(rng)
+            dist[base + j] = (precrop, oy, ox, float(flip), bright)
+    paths = [index.paths[r] for r in rows]
+    largest = int(np.ceil(dist[:, 0].max())) if n else INPUT_SIZE
+    dev = pipeline.device
+
+    def cpu_batch(imgs, descs):
+        return torch.stack([preprocess_reference(a, descs[i]) for i, a in enumerate(imgs)]).to(torch.bfloat16)
+
+    def desc(i: int):
+        d = dist[i]
+        return d[0], d[1], d[2], d[3] != 0.0, d[4]
+
+    for first, count, x in pipeline.batches(paths, batch_size=how_many, preprocess_cpu=cpu_batch, desc_fn=desc,
+                                            draft=max(2 * INPUT_SIZE, largest)):
+        feats = backbone(x).to(torch.float32)
+        yield feats[:count], torch.from_numpy(labels[first:first + count]).to(dev)
+
+
 # ----------------------------------------------------------------------------- packed-double files (C44)
 def write_list_of_floats_to_file(list_of_floats, file_path: str) -> None:
     """``retrain1/retrain.py:357-360``: ``BOTTLENECK_TENSOR_SIZE`` native doubles, ``struct.pack('d'*2048)``.

@@ -128,25 +128,43 @@ class DecodePipeline:
     def run(self, paths: Sequence[str], consume: Callable[[int, int, torch.Tensor], None],
             preprocess_cpu: Optional[Callable] = None, warm: Optional[Callable[[], None]] = None) -> Dict[str, float]:
         """Feed ``paths`` through decode -> H2D -> preprocess in batches of ``batch_size`` and call
-        ``consume(first, count, x)`` for each, in order, on the current stream; ``x`` is the bf16 NHWC ``[batch_size, 299,
-        299, 8]`` network input (rows >= count repeat the last image) and stays valid until the next-but-one call.
-        ``warm()`` (one-time work of the consumer: kernel selection, graph capture) runs while the decoders fill the
-        first slots."""
+        ``consume(first, count, x)`` for each, in order, on the current stream (see ``batches``).  Returns the stage
+        statistics (also kept in ``self.stats``)."""
+        for first, count, x in self.batches(paths, preprocess_cpu=preprocess_cpu, warm=warm):
+            consume(first, count, x)
+        return self.stats
+
+    def batches(self, paths: Sequence[str], *, batch_size: Optional[int] = None, preprocess_cpu: Optional[Callable] = None,
+                warm: Optional[Callable[[], None]] = None, desc_fn: Optional[Callable[[int], tuple]] = None,
+                draft: Optional[int] = None):
+        """Generator over ``(first, count, x)``: ``x`` is the bf16 NHWC ``[batch_size, 299, 299, 8]`` network input of
+        ``paths[first : first + count]`` (rows >= count repeat the last image), valid on the current stream until the
+        next-but-one batch is requested.  ``warm()`` (one-time work of the consumer: kernel selection, graph capture) runs
+        while the decoders fill the first slots.  ``desc_fn(i) -> (precrop, off_y, off_x, flip, brightness)`` gives image
+        ``i`` a distortion (``bottleneck.Distortion.sample``); ``draft`` overrides the reduced-scale decode request (a
+        distorted stream asks for its largest pre-crop size).  ``self.stats`` is filled when the stream is exhausted."""
+        import queue
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
         from .bottleneck import ImageDesc
-        n, B = len(paths), self.batch_size
+        n, B = len(paths), int(batch_size or self.batch_size)
+        draft = self.draft if draft is None else int(draft)
+        self.stats = {}
         if n == 0:
-            return {}
+            return
         t_all = time.perf_counter()
         for f in self._warm:
             f.result()
         self._warm = []
-        # ---- header probe: decoded sizes -> packed offsets of every batch (parallel, header reads only)
-        step = max(1, (n + 4 * self.workers - 1) // (4 * self.workers))
-        futs = [self.pool.submit(dw.probe, list(paths[i:i + step]), self.draft) for i in range(0, n, step)]
-        sizes = [s for f in futs for s in f.result()]
-        bad = [paths[i] for i, (h, w) in enumerate(sizes) if h <= 0 or w <= 0 or h * w * 3 > self.max_image_bytes]
+        # ---- header probe: decoded sizes -> packed offsets of every batch (parallel, header reads only, once per file)
+        uniq = list(dict.fromkeys(paths))
+        step = max(1, (len(uniq) + 4 * self.workers - 1) // (4 * self.workers))
+        futs = [self.pool.submit(dw.probe, uniq[i:i + step], draft) for i in range(0, len(uniq), step)]
+        size_of = dict(zip(uniq, (s for f in futs for s in f.result())))
+        bad = [p for p, (h, w) in size_of.items() if h <= 0 or w <= 0 or h * w * 3 > self.max_image_bytes]
         if bad:
             raise ValueError("undecodable or oversized image(s): %s" % bad[:3])
+        sizes = [size_of[p] for p in paths]
         t_probe = time.perf_counter() - t_all
         nb = (n + B - 1) // B
         offs = np.zeros(n, np.int64)
@@ -170,21 +188,20 @@ class DecodePipeline:
             desc_dev = [torch.empty(B * dsz, dtype=torch.uint8, device=self.device) for _ in range(2)]
             x_ready = [torch.cuda.Event() for _ in range(2)]
             x_free = [torch.cuda.Event() for _ in range(2)]
-            copied = [torch.cuda.Event(enable_timing=False) for _ in range(self.slots)]
-            t_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                    for _ in range(min(nb, 64))]
-            g_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(nb, 64))]
+            copied = [torch.cuda.Event() for _ in range(self.slots)]
+            nev = min(nb, 64)
+            t_ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(nev)]
+            g_ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) for _ in range(nev)]
             for e in x_free:
                 e.record(main)
 
         def submit(k: int):
             s = k % self.slots
             lo, hi = k * B, min(n, (k + 1) * B)
-            fs = []
-            for c0 in range(lo, hi, self.chunk):
-                items = [(paths[i], int(offs[i]), sizes[i][0], sizes[i][1]) for i in range(c0, min(hi, c0 + self.chunk))]
-                fs.append(self.pool.submit(dw.decode_chunk, self._shm[s].name, items, self.draft))
-            return fs
+            return [self.pool.submit(dw.decode_chunk, self._shm[s].name,
+                                     [(paths[i], int(offs[i]), sizes[i][0], sizes[i][1]) for i in range(c0, min(hi, c0 + self.chunk))],
+                                     draft)
+                    for c0 in range(lo, hi, self.chunk)]
 
         pending = {k: submit(k) for k in range(min(nb, self.slots))}
         t_warm = time.perf_counter()
@@ -199,25 +216,32 @@ class DecodePipeline:
                 i = min(lo + j, hi - 1)  # (a short last batch repeats its last image: one batch size, one graph)
                 d = descs[j]
                 H, W = sizes[i]
+                precrop, oy, ox, flip, bright = desc_fn(i) if desc_fn is not None else (float(INPUT_SIZE), 0.0, 0.0, False, 1.0)
                 d.offset, d.H, d.W = int(offs[i]), H, W
-                d.scale_y, d.scale_x = H / float(INPUT_SIZE), W / float(INPUT_SIZE)
-                d.off_y, d.off_x, d.flip, d.brightness = 0.0, 0.0, 0, 1.0
+                d.scale_y, d.scale_x = H / float(precrop), W / float(precrop)
+                d.off_y, d.off_x, d.flip, d.brightness = float(oy), float(ox), int(bool(flip)), float(bright)
             return descs
 
-        import threading
         # ---- feeder thread: waits for the decoders, moves the finished batch into its pinned buffer (the copy is split
         # over a few threads; it releases the GIL), hands the shared slot back to the decoders, and passes the batch on
-        import queue
-        import threading
-        from concurrent.futures import ThreadPoolExecutor
         ready: "queue.Queue" = queue.Queue(maxsize=self.slots)
         tstat = {"wait": 0.0, "worker": 0.0, "copy": 0.0}
         # a pinned buffer may be refilled only after the consumer thread has ENQUEUED the DMA out of it (and recorded the
         # event the feeder then waits on): `issued` is the newest batch for which that has happened
         issued = [-1]
         issued_cv = threading.Condition()
+        cancelled = [False]  # the consumer failed or abandoned the stream
         ncopy = 4
         copiers = ThreadPoolExecutor(max_workers=ncopy) if cuda else None
+
+        def hand_over(item) -> bool:
+            while not cancelled[0]:
+                try:
+                    ready.put(item, timeout=0.2)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def feeder() -> None:
             try:
@@ -234,8 +258,10 @@ class DecodePipeline:
                         t0 = time.perf_counter()
                         if k >= self.slots:
                             with issued_cv:
-                                while issued[0] < k - self.slots and not failed[0]:
+                                while issued[0] < k - self.slots and not cancelled[0]:
                                     issued_cv.wait(0.5)
+                            if cancelled[0]:
+                                return
                             copied[s].synchronize()  # the DMA out of this pinned buffer (batch k - slots) has finished
                         cut = [(nbytes * c // ncopy) & ~63 for c in range(ncopy)] + [nbytes]
                         list(copiers.map(lambda c: self._pin[s][cut[c]:cut[c + 1]].copy_(self._host[s][cut[c]:cut[c + 1]]),
@@ -251,75 +277,79 @@ class DecodePipeline:
                             imgs.append(np.frombuffer(self._shm[s].buf, np.uint8, H * W * 3, int(offs[i])).reshape(H, W, 3).copy())
                     if k + self.slots < nb:
                         pending[k + self.slots] = submit(k + self.slots)  # the shared slot is free again
-                    ready.put((k, descs, imgs))
+                    if not hand_over((k, descs, imgs)):
+                        return
             except BaseException as e:  # noqa: BLE001 - hand the failure to the consuming thread
-                ready.put(e)
+                hand_over(e)
 
-        failed = [False]
         th = threading.Thread(target=feeder, name="dtf-extract-feeder", daemon=True)
         th.start()
         idle_s = 0.0
+        completed = False
         try:
-          for _ in range(nb):
-              t0 = time.perf_counter()
-              item = ready.get()
-              idle_s += time.perf_counter() - t0
-              if isinstance(item, BaseException):
-                  raise item
-              k, descs, imgs = item
-              s, xb = k % self.slots, k % 2
-              lo, hi = k * B, min(n, (k + 1) * B)
-              nbytes = int(batch_bytes[k])
-              if not cuda:
-                  consume(lo, hi - lo, preprocess_cpu(imgs, descs))
-                  continue
-              te = t_ev[k] if k < len(t_ev) else None
-              with torch.cuda.stream(side):
-                  side.wait_event(x_free[xb])  # the forward of batch k-2 has consumed this input buffer
-                  if te:
-                      te[0].record(side)
-                  pix[xb][:nbytes].copy_(self._pin[s][:nbytes], non_blocking=True)
-                  desc_dev[xb].copy_(desc_host[s], non_blocking=True)
-                  copied[s].record(side)
-                  if te:
-                      te[1].record(side)
-                  native.check(lib.dtf_preprocess_images(pix[xb].data_ptr(), desc_dev[xb].data_ptr(), xbuf[xb].data_ptr(), B,
-                                                         INPUT_SIZE, side.cuda_stream), "preprocess")
-                  if te:
-                      te[2].record(side)
-                  x_ready[xb].record(side)
-              with issued_cv:
-                  issued[0] = k
-                  issued_cv.notify_all()
-              main.wait_event(x_ready[xb])
-              if k < len(g_ev):
-                  g_ev[k][0].record(main)
-              consume(lo, hi - lo, xbuf[xb])
-              if k < len(g_ev):
-                  g_ev[k][1].record(main)
-              x_free[xb].record(main)
-        except BaseException:
-            failed[0] = True  # (lets a feeder that is waiting for this thread's progress leave its loop)
-            with issued_cv:
-                issued_cv.notify_all()
-            raise
-        th.join()
-        if copiers is not None:
-            copiers.shutdown()
-        if cuda:
-            torch.cuda.synchronize(self.device)
-        wait_s, worker_s, copy_s = tstat["wait"], tstat["worker"], tstat["copy"]
-        total = time.perf_counter() - t_all
-        st = {"images": n, "seconds": total, "images_per_sec": n / max(total, 1e-9), "probe_s": t_probe,
-              "decode_wait_s": wait_s, "decode_cpu_s": worker_s, "host_copy_s": copy_s, "warm_s": t_warm, "consumer_idle_s": idle_s, "workers": self.workers, "batches": nb,
-              "h2d_bytes": int(batch_bytes.sum())}
-        if cuda and t_ev:
-            m = len(t_ev)
-            st["h2d_ms_per_batch"] = sum(a.elapsed_time(b) for a, b, _ in t_ev) / m
-            st["preprocess_ms_per_batch"] = sum(b.elapsed_time(c) for _, b, c in t_ev) / m
-            st["gpu_ms_per_batch"] = sum(a.elapsed_time(b) for a, b in g_ev) / m
-        self.stats = st
-        return st
+            for _ in range(nb):
+                t0 = time.perf_counter()
+                item = ready.get()
+                idle_s += time.perf_counter() - t0
+                if isinstance(item, BaseException):
+                    raise item
+                k, descs, imgs = item
+                s, xb = k % self.slots, k % 2
+                lo, hi = k * B, min(n, (k + 1) * B)
+                nbytes = int(batch_bytes[k])
+                if not cuda:
+                    yield lo, hi - lo, preprocess_cpu(imgs, descs)
+                    continue
+                te = t_ev[k] if k < nev else None
+                with torch.cuda.stream(side):
+                    side.wait_event(x_free[xb])  # the consumer of batch k-2 is done with this input buffer
+                    if te:
+                        te[0].record(side)
+                    pix[xb][:nbytes].copy_(self._pin[s][:nbytes], non_blocking=True)
+                    desc_dev[xb].copy_(desc_host[s], non_blocking=True)
+                    copied[s].record(side)
+                    if te:
+                        te[1].record(side)
+                    native.check(lib.dtf_preprocess_images(pix[xb].data_ptr(), desc_dev[xb].data_ptr(), xbuf[xb].data_ptr(), B,
+                                                           INPUT_SIZE, side.cuda_stream), "preprocess")
+                    if te:
+                        te[2].record(side)
+                    x_ready[xb].record(side)
+                with issued_cv:
+                    issued[0] = k
+                    issued_cv.notify_all()
+                main.wait_event(x_ready[xb])
+                if te:
+                    g_ev[k][0].record(main)
+                yield lo, hi - lo, xbuf[xb]
+                if te:
+                    g_ev[k][1].record(main)
+                x_free[xb].record(main)
+            completed = True
+        finally:
+            if not completed:  # the consumer failed or dropped the stream: let the feeder leave its waits
+                cancelled[0] = True
+                with issued_cv:
+                    issued_cv.notify_all()
+            th.join(timeout=30)
+            if copiers is not None:
+                copiers.shutdown()
+            if cuda:
+                torch.cuda.synchronize(self.device)
+            # statistics of what was delivered (a consumer that stops after the last batch never resumes the generator)
+            done_b = max(0, issued[0] + 1) if cuda else nb
+            done_n = min(n, done_b * B)
+            total = time.perf_counter() - t_all
+            st = {"images": done_n, "seconds": total, "images_per_sec": done_n / max(total, 1e-9), "probe_s": t_probe,
+                  "decode_wait_s": tstat["wait"], "decode_cpu_s": tstat["worker"], "host_copy_s": tstat["copy"],
+                  "warm_s": t_warm, "consumer_idle_s": idle_s, "workers": self.workers, "batches": done_b,
+                  "h2d_bytes": int(batch_bytes[:done_b].sum())}
+            m = min(nev, done_b - 1) if cuda else 0  # (the last batch's closing event may never have been recorded)
+            if m > 0:
+                st["h2d_ms_per_batch"] = sum(a.elapsed_time(b) for a, b, _ in t_ev[:m]) / m
+                st["preprocess_ms_per_batch"] = sum(b.elapsed_time(c) for _, b, c in t_ev[:m]) / m
+                st["gpu_ms_per_batch"] = sum(a.elapsed_time(b) for a, b in g_ev[:m]) / m
+            self.stats = st
 
     @staticmethod
     def describe(st: Dict[str, float]) -> str:

@@ -194,3 +194,33 @@ def test_decode_pipeline_reports_undecodable_files(tmp_path):
             pipe.run(paths, lambda first, count, x: None, preprocess_cpu=lambda imgs, descs: None)
     finally:
         pipe.close()
+
+
+def test_distorted_stream_equals_per_step_distorted_bottlenecks(tmp_path):
+    """``distorted_bottleneck_stream`` (decode pipeline) yields, step for step, what consecutive calls of
+    ``get_random_distorted_bottlenecks`` yield from the same random state (reference: retrain1/retrain.py:300-319)."""
+    import random
+    import torch
+    from distributed_tensorflow_amd.data import image_lists as il
+    from distributed_tensorflow_amd.data.bottleneck import (Distortion, ImagePreprocessor, distorted_bottleneck_stream,
+                                                            get_random_distorted_bottlenecks)
+    from distributed_tensorflow_amd.data.pipeline import DecodePipeline
+    from distributed_tensorflow_amd.models.retrain_head import TinyBackbone
+    d = il.make_synthetic_image_dir(str(tmp_path / "imgs"), num_classes=3, images_per_class=12, seed=2)
+    index = il.build_image_index(il.create_image_lists(d, 10, 10), d)
+    backbone = TinyBackbone("cpu", seed=1)
+    dist = Distortion(flip_left_right=True, random_crop=10, random_scale=20, random_brightness=15)
+    steps, B = 3, 6
+    rng_a = random.Random(42)
+    ref = [get_random_distorted_bottlenecks(index, B, "training", backbone, ImagePreprocessor("cpu"), dist, rng_a)
+           for _ in range(steps)]
+    pipe = DecodePipeline("cpu", batch_size=4, workers=2, slots=3, chunk=2)
+    try:
+        got = list(distorted_bottleneck_stream(index, B, "training", backbone, pipe, dist, random.Random(42), steps))
+    finally:
+        pipe.close()
+    assert len(got) == steps and pipe.stats["batches"] == steps
+    for (fa, la), (fb, lb) in zip(ref, got):
+        assert torch.equal(la.cpu(), lb.cpu()) and fa.shape == fb.shape == (B, 2048)
+        assert torch.equal(fa, fb)
+    assert len({tuple(l.tolist()) for _, l in got}) > 1   # (the steps really differ)
