@@ -30,6 +30,18 @@ def _load_split(index, preproc, category: str, rank: int, world: int, shard: boo
     rows = index.rows_of(category)
     if shard:
         rows = rows[rank::world]
+    if len(rows) and preproc.device.type == "cuda" and os.environ.get("DTF_EXTRACT_PIPELINE", "1") != "0":
+        # the HBM image cache is filled through the decode pipeline (decode processes -> pinned ring -> side-stream H2D +
+        # resize), written batch by batch into one preallocated tensor
+        from ..data.pipeline import DecodePipeline
+        out = torch.empty(len(rows), 299, 299, 8, dtype=torch.bfloat16, device=preproc.device)
+        pipe = DecodePipeline(preproc.device, batch_size=64)
+        try:
+            for first, count, x in pipe.batches([index.paths[r] for r in rows]):
+                out[first:first + count].copy_(x[:count])
+        finally:
+            pipe.close()
+        return out, torch.as_tensor(index.class_id[rows], dtype=torch.int32).to(preproc.device)
     xs, ys = [], []
     for i in range(0, len(rows), 32):
         chunk = rows[i:i + 32]
