@@ -244,6 +244,14 @@ class DataParallelTrainer:
         if self._multi and self._native and sync and self.comm != "ipc" and self.rccl is not None:
             self._ipc_hook, self._fc1_end = None, 0
             self._use_schedule("rccl")
+            if not self._all_ranks_ok(self._capture_ok()):
+                # RCCL calls could not be captured into the step graph on some rank: every rank falls back to the
+                # process group's collectives between three graph launches
+                self._note("the RCCL collectives could not be captured into the step graph: process-group schedule instead")
+                self.engine.set_grad_hook(None)
+                self._rccl_graph = False
+                self.rccl.close(abort=True)
+                self.rccl = None
         self.startup_seconds = round(time.perf_counter() - t_start, 3) if self._multi else 0.0
         if self._multi and self.rank == 0:
             print("data-parallel start-up: %.2f s; transport %s, schedule %s%s" % (
@@ -252,6 +260,22 @@ class DataParallelTrainer:
 
     def _note(self, msg: str) -> None:
         self.startup_log.append(msg)
+
+    def _capture_ok(self) -> bool:
+        """Capture this schedule's step graphs now; False (with a note) instead of an exception if that fails."""
+        try:
+            self.prepare()
+            return True
+        except Exception as e:  # noqa: BLE001
+            self._note("%s: graph capture failed on rank %d: %r" % (self.schedule, self.rank, e))
+            return False
+
+    def _all_ranks_ok(self, ok: bool) -> bool:
+        """Agreement (process group, collective stream): did every rank succeed?"""
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cpu" if self._stage_host else self.engine.device)
+        with self._ctx():
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return float(t.item()) > 0
 
     def _try_rccl(self) -> None:
         """Create the native RCCL communicator (collective).  Every rank reports whether its part worked; if any failed
@@ -447,8 +471,13 @@ class DataParallelTrainer:
                     continue
                 t_c = time.perf_counter()
                 use(c)
-                self.prepare()
-                dist.barrier(group=self.group)  # graph capture takes a different time on every rank; the waits are short here
+                # (also the barrier: graph capture takes a different time on every rank; the waits are short here)
+                if not self._all_ranks_ok(self._capture_ok()):
+                    self._note("%s: not eligible (graph capture failed on some rank)" % c)
+                    broken.add(c)
+                    times.append(float("inf"))
+                    grads.append(None)
+                    continue
                 # one step from the snapshot: Adam's first moment is linear in the gradient, m' = b1*m + (1-b1)*g, which
                 # gives the reduced gradient this schedule produced, wherever it keeps it
                 self.train_steps(1)
