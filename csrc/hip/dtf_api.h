@@ -67,7 +67,8 @@ DTF_API int dtf_fc_dw_f32(const float* X, int ldx, const float* dY, int ldy, flo
                           hipStream_t st);
 DTF_API int dtf_fc_bwd_trio_f32(const float* X0, const float* dY0, float* dW0, int M0, int N0, const float* X1,
                                 const float* dY1, int ldy1, float* dW1, int M1, int N1, int K, const float* dYq,
-                                const float* Wq, float* dXq, int Mq, int Nq, int Kq, int splits, hipStream_t st);
+                                const float* Wq, float* dXq, int Mq, int Nq, int Kq, int splits, const void* const* gA,
+                                const void* const* gB, int granks, hipStream_t st);
 DTF_API int dtf_conv2_f32_init();
 DTF_API int dtf_conv1_fwd_f32(const float* images, const int* perm, const int* step_ptr, int spe, int B, const float* Wt,
                               const float* bias, float* out, void* amax, hipStream_t st);

@@ -98,7 +98,7 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
   MnistEngine loc = *e_in;
   const MnistEngine* e = &loc;
   if (loc.gather_n > 0) {
-    if (loc.f32) return -22;  // (the operand-gather schedule exchanges bf16 operands)
+    if (loc.f32 && B % 20) return -22;  // (fp32: a K slab of the filter-gradient GEMM must not straddle two ranks' operands)
     if (!trio_ok(e_in) || loc.gather_rank < 0 || loc.gather_rank >= loc.gather_n || loc.gather_n > 8) return -22;
     loc.pool2 = const_cast<void*>(loc.gather_A[loc.gather_rank]);
     loc.dh = const_cast<void*>(loc.gather_B[loc.gather_rank]);
@@ -146,9 +146,9 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
     // fc2 dW[1024][10] = h_drop^T * dz, as one grouped launch when the batch fits a single K slab
     const bool gather = e->gather_n > 0;
     if (gather) {
-      // this rank's fc1 operands (bf16 pool2 [B,3136], dh [B,1024]) are complete: tell the peers, wait for theirs, and
-      // pull theirs into local memory (one pass over each xGMI link)
-      if (e->gather_bytes != (long)B * (3136 + 1024) * 2 || !e->gather_local) return -22;
+      // this rank's fc1 operands (pool2 [B,3136], dh [B,1024] in the compute dtype) are complete: tell the peers, wait for
+      // theirs, and pull theirs into local memory (one pass over each xGMI link)
+      if (e->gather_bytes != (long)B * (3136 + 1024) * (e->f32 ? 4 : 2) || !e->gather_local) return -22;
       DTF_TRY(dtf_ipc_sync_gather(e->gather_comm, e->gather_local, e->gather_bytes, 16, st));
     }
     if (e->f32) {
@@ -156,7 +156,7 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
       if (trio_ok(e)) {
         DTF_TRY(dtf_fc_bwd_trio_f32(x2, dh, dW_fc1, 3136, 1024, (const float*)e->h_drop, (const float*)e->dz, 16,
                                     e->G + e->off_Wfc2, 1024, 10, B, dh, e->P + e->off_Wfc1, e->dpool2, B, 3136, 1024,
-                                    e->bwd_splits, st));
+                                    e->bwd_splits, e->gather_A, e->gather_B, gather ? e->gather_n : 0, st));
       } else {
         DTF_TRY(dtf_fc_dw_f32((const float*)e->h_drop, 1024, (const float*)e->dz, 16, e->G + e->off_Wfc2, 1024, 10, B, 1, st));
         DTF_TRY(dtf_fc_dw_f32(x2, 3136, dh, 1024, dW_fc1, 3136, 1024, B, 1, st));

@@ -29,6 +29,28 @@ using BdB = F32RowK<64, 256, 32, false>;
 using DwA = F32ColK<128, 256, 20, true>;
 using DwB = F32ColK<64, 256, 20, false>;
 using DwBn = F32ColK<16, 256, 20, false>;  // N <= 16 (fc2: 10 classes, rows of the gradient padded to 16 floats)
+
+// K in segments: p.A / p.B are tables of operand blocks of p.kseg k-rows each (the "gather" data-parallel schedule: one block
+// per rank, see dtf_fc_bwd_trio_f32).  kseg is a multiple of BK, so a slab lies in one block and the choice of block is
+// uniform over the workgroup.
+template <int R, int NT, int BK, bool IS_A>
+struct F32ColKSeg : F32ColK<R, NT, BK, IS_A> {
+  using Base = F32ColK<R, NT, BK, IS_A>;
+  const float* const* tab;
+  int seg;
+  __device__ __forceinline__ void init(const GemmParams& p, int r0_, int tid) {
+    Base::init(p, r0_, tid);
+    tab = reinterpret_cast<const float* const*>(IS_A ? p.A : p.B);
+    seg = p.kseg;
+  }
+  __device__ __forceinline__ void load(int k0_, int, int tid) {
+    const int s = k0_ / seg;
+    this->src = tab[s];
+    Base::load(k0_ - s * seg, seg, tid);
+  }
+};
+using DwAg = F32ColKSeg<128, 256, 20, true>;
+using DwBg = F32ColKSeg<64, 256, 20, false>;
 }  // namespace
 
 // out[z][M][N] (fp32 slabs) = X[M][K] (fp32 row-major) * W[K][N] (fp32, TF [in,out] layout)
@@ -85,10 +107,16 @@ struct GemmTrio32 {
   GemmParams q, d0, d1;
   int nblk_q, q_mt, q_nt;  // data-gradient blocks come first: m-tile fastest, then n-tile, then K split
   int nblk0, mt0, mt1;     // then problem 0 (fc1 dW), then problem 1 (fc2 dW)
+  // "gather" data parallelism (ipc_allreduce.hip): problem 0 sums over the operand pairs of all ranks instead of being
+  // all-reduced afterwards; d0.K = granks * batch, d0.kseg = batch
+  const float* gA[8];
+  const float* gB[8];
 };
 constexpr int TRIO32_LDS = dtf_gemm32_lds<112, 64, BdA, BdB>() > dtf_gemm32_lds<128, 64, DwA, DwB>()
                                ? dtf_gemm32_lds<112, 64, BdA, BdB>() : dtf_gemm32_lds<128, 64, DwA, DwB>();
 
+// (GATHER is a template parameter for the reason given at fc_bwd_trio_kernel in gemm_api.hip)
+template <bool GATHER>
 __global__ __launch_bounds__(256) void fc_bwd_trio_f32_kernel(const GemmTrio32 g) {
   __shared__ __attribute__((aligned(16))) float smem[TRIO32_LDS];
   const int id = blockIdx.x;
@@ -97,7 +125,13 @@ __global__ __launch_bounds__(256) void fc_bwd_trio_f32_kernel(const GemmTrio32 g
     dtf_gemm32_body<112, 64, 32, 1, 4, BdA, BdB, Ep32Atomic>(g.q, mt * 112, (r % g.q_nt) * 64, r / g.q_nt, smem);
   } else if (id < g.nblk_q + g.nblk0) {
     const int k = id - g.nblk_q;
-    dtf_gemm32_body<128, 64, 20, 4, 1, DwA, DwB, Ep32Store>(g.d0, (k % g.mt0) * 128, (k / g.mt0) * 64, 0, smem);
+    if constexpr (GATHER) {
+      GemmParams d = g.d0;
+      d.A = g.gA;
+      d.B = g.gB;
+      dtf_gemm32_body<128, 64, 20, 4, 1, DwAg, DwBg, Ep32Store>(d, (k % g.mt0) * 128, (k / g.mt0) * 64, 0, smem);
+    } else
+      dtf_gemm32_body<128, 64, 20, 4, 1, DwA, DwB, Ep32Store>(g.d0, (k % g.mt0) * 128, (k / g.mt0) * 64, 0, smem);
   } else {
     const int k = id - g.nblk_q - g.nblk0;
     dtf_gemm32_body<128, 16, 20, 4, 1, DwA, DwBn, Ep32Store>(g.d1, (k % g.mt1) * 128, (k / g.mt1) * 16, 0, smem);
@@ -112,15 +146,25 @@ DTF_API void dtf_dbg_set_trio_stamps(void* p) { g_trio_stamps = p; }
 
 // dW0[M0][N0] = X0^T dY0 (pitches M0 / N0), dW1[M1][N1] = X1^T dY1 (N1 <= 16, dY1 pitch ldy1) and
 // dX[Mq][Nq] += dYq[Mq][Kq] * Wq[Nq][Kq]^T (split over K, dX pre-zeroed) in one launch.  K = batch.
+// With granks > 0, dW0 = sum over r < granks of gA[r]^T gB[r] instead (operand pairs of the shapes of X0 / dY0, e.g. the
+// ranks' exchanged activations; X0 / dY0 themselves are then unused); K must be a multiple of 20 then.
 DTF_API int dtf_fc_bwd_trio_f32(const float* X0, const float* dY0, float* dW0, int M0, int N0, const float* X1,
                                 const float* dY1, int ldy1, float* dW1, int M1, int N1, int K, const float* dYq,
-                                const float* Wq, float* dXq, int Mq, int Nq, int Kq, int splits, hipStream_t st) {
+                                const float* Wq, float* dXq, int Mq, int Nq, int Kq, int splits, const void* const* gA,
+                                const void* const* gB, int granks, hipStream_t st) {
   if (M0 <= 0 || N0 <= 0 || M1 <= 0 || N1 <= 0 || K <= 0 || M0 % 4 || N0 % 4 || M1 % 4 || N1 > 16 || ldy1 % 4 || ldy1 < N1)
     return ERR_SHAPE;
   if (Mq <= 0 || Nq <= 0 || Kq <= 0 || Kq % 4 || splits < 2) return ERR_SHAPE;
   if (!aligned16(X0) || !aligned16(dY0) || !aligned16(X1) || !aligned16(dY1) || !aligned16(dYq) || !aligned16(Wq)) return ERR_SHAPE;
+  if (granks < 0 || granks > 8 || (granks > 0 && (!gA || !gB || K % 20))) return ERR_SHAPE;
   GemmTrio32 g;
-  g.d0 = base_params32(X0, dY0, dW0, M0, N0, K, M0, N0, N0, 1, 20);
+  for (int r = 0; r < 8; ++r) {
+    g.gA[r] = r < granks ? static_cast<const float*>(gA[r]) : nullptr;
+    g.gB[r] = r < granks ? static_cast<const float*>(gB[r]) : nullptr;
+    if (r < granks && (!g.gA[r] || !g.gB[r] || !aligned16(g.gA[r]) || !aligned16(g.gB[r]))) return ERR_SHAPE;
+  }
+  g.d0 = base_params32(X0, dY0, dW0, M0, N0, granks > 0 ? granks * K : K, M0, N0, N0, 1, 20);
+  g.d0.kseg = granks > 0 ? K : 0;
   g.d1 = base_params32(X1, dY1, dW1, M1, N1, K, M1, ldy1, N1, 1, 20);
   g.mt0 = dtf_cdiv(M0, 128);
   g.mt1 = dtf_cdiv(M1, 128);
@@ -135,7 +179,10 @@ DTF_API int dtf_fc_bwd_trio_f32(const float* X0, const float* dY0, float* dW0, i
 #ifdef DTF_GEMM32_STAMPS
   g.q.aux_out = g.d0.aux_out = g.d1.aux_out = g_trio_stamps;
 #endif
-  hipLaunchKernelGGL(fc_bwd_trio_f32_kernel, dim3(g.nblk_q + g.nblk0 + nblk1), dim3(256), 0, st, g);
+  if (granks > 0)
+    hipLaunchKernelGGL(fc_bwd_trio_f32_kernel<true>, dim3(g.nblk_q + g.nblk0 + nblk1), dim3(256), 0, st, g);
+  else
+    hipLaunchKernelGGL(fc_bwd_trio_f32_kernel<false>, dim3(g.nblk_q + g.nblk0 + nblk1), dim3(256), 0, st, g);
   DTF_CHECK_LAUNCH();
   return 0;
 }

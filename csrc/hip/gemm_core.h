@@ -46,6 +46,7 @@ struct GemmParams {
   void* aux_out;
   ConvGeom g;
   int accumulate;  // epilogues that support it add to the existing output instead of overwriting
+  int kseg;        // segmented-K loaders (f32_fc.hip): A / B are tables of operand blocks of kseg k-rows each; 0 = plain
 };
 
 // ------------------------------------------------------------------ raw element loads (convert later)

@@ -327,12 +327,17 @@ class NativeMnistEngine(_EngineBase):
         return self.grad_hook is None and self.world == 1 and not self.cfg.G_fc1_dst and not self.cfg.G_src
 
     def gather_supported(self) -> bool:
-        """The activation-gather schedule rides on the fused fc backward launch (batch <= 128, split-K data gradient)."""
-        return self.dtype == "bf16" and self.batch_size <= 128 and self.cfg.bwd_splits > 1
+        """The activation-gather schedule rides on the fused fc backward launch (split-K data gradient; bf16: batch <= 128,
+        fp32: the batch a multiple of the filter-gradient GEMM's K slab of 20, so a slab never straddles two ranks)."""
+        if self.cfg.bwd_splits <= 1:
+            return False
+        return self.batch_size % 20 == 0 if self.dtype == "fp32" else self.batch_size <= 128
 
     def gather_bytes(self) -> Tuple[int, int]:
-        """Bytes of the two fc1 filter-gradient operands a rank publishes: bf16 pool2 [B,3136] and dh [B,1024]."""
-        return self.batch_size * 3136 * 2, self.batch_size * 1024 * 2
+        """Bytes of the two fc1 filter-gradient operands a rank publishes: pool2 [B,3136] and dh [B,1024] in the compute
+        dtype."""
+        es = 4 if self.dtype == "fp32" else 2
+        return self.batch_size * 3136 * es, self.batch_size * 1024 * es
 
     def set_gather(self, ipc=None) -> None:
         """Data-parallel "gather" schedule: a training step keeps its pool2 / dh in this rank's stage buffer of ``ipc``

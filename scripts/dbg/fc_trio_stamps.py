@@ -5,7 +5,7 @@ import numpy as np, torch
 here = os.path.dirname(os.path.abspath(__file__))
 lib = C.CDLL(os.path.join(here, "libf32fc_stamps.so"))
 P, I = C.c_void_p, C.c_int
-lib.dtf_fc_bwd_trio_f32.argtypes = [P, P, P, I, I, P, P, I, P, I, I, I, P, P, P, I, I, I, I, P]
+lib.dtf_fc_bwd_trio_f32.argtypes = [P, P, P, I, I, P, P, I, P, I, I, I, P, P, P, I, I, I, I, P, P, I, P]
 lib.dtf_dbg_set_trio_stamps.argtypes = [P]
 B, splits = 100, 4
 dev = "cuda"
@@ -21,7 +21,7 @@ for it in range(5):
     junk = torch.empty(64 << 20, dtype=torch.float32, device=dev).normal_()
     dX.zero_(); st.zero_(); torch.cuda.synchronize()
     rc = lib.dtf_fc_bwd_trio_f32(pool2.data_ptr(), dh.data_ptr(), dW0.data_ptr(), 3136, 1024, hdrop.data_ptr(), dz.data_ptr(), 16,
-                                 dW1.data_ptr(), 1024, 10, B, dh.data_ptr(), W.data_ptr(), dX.data_ptr(), B, 3136, 1024, splits, 0)
+                                 dW1.data_ptr(), 1024, 10, B, dh.data_ptr(), W.data_ptr(), dX.data_ptr(), B, 3136, 1024, splits, None, None, 0, 0)
     torch.cuda.synchronize()
     assert rc == 0, rc
 t = st.cpu().numpy().astype(np.int64)

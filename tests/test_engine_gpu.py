@@ -156,7 +156,7 @@ def test_training_reaches_high_accuracy_on_synthetic():
     assert acc2 > 0.8, (loss2, acc2)
 
 
-@pytest.mark.parametrize("comm", ["ipc-gather", "ipc-zerocopy", "ipc-inline", "ipc-overlap", "ipc-auto", "rccl"])
+@pytest.mark.parametrize("comm", ["ipc-gather", "ipc-gather-bf16", "ipc-zerocopy", "ipc-inline", "ipc-overlap", "ipc-auto", "rccl"])
 def test_native_data_parallel_path_two_ranks_one_gpu(tmp_path, comm):
     """The multi-GPU step with 2 ranks sharing the single test GPU (RCCL refuses duplicate devices, so the process
     group is gloo).  ``ipc-*`` = fwd+bwd | direct IPC all-reduce | Adam as one hipGraph, in each of its schedules
@@ -168,6 +168,8 @@ def test_native_data_parallel_path_two_ranks_one_gpu(tmp_path, comm):
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dtype = "bf16" if comm.endswith("-bf16") else "fp32"   # (fp32 = the headline engine)
+    comm = comm[:-5] if comm.endswith("-bf16") else comm
     port = {"ipc-gather": "29574", "ipc-zerocopy": "29577", "ipc-inline": "29576", "ipc-overlap": "29579", "ipc-auto": "29575",
             "rccl": "29578"}[comm]
     env = dict(os.environ, MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -180,9 +182,7 @@ def test_native_data_parallel_path_two_ranks_one_gpu(tmp_path, comm):
         comm = "ipc"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", port, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5",
-           "--backend", "gloo", "--train-size", "4000", "--comm", comm, "--ref-steps", "0"]
-    if schedule == "ipc-gather":  # (exchanges bf16 operands: a schedule of the bf16 engine; the others run the fp32 headline engine)
-        cmd += ["--dtype", "bf16"]
+           "--backend", "gloo", "--train-size", "4000", "--comm", comm, "--ref-steps", "0", "--dtype", dtype]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]

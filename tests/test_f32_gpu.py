@@ -69,6 +69,48 @@ def test_fc_backward_weight_f32(ops, M, N, Kb, ldy):
     assert got.shape == (M, N) and relerr(got, ref) < 2e-6
 
 
+@pytest.mark.parametrize("granks", [0, 2, 3])
+def test_fc_backward_trio_f32(granks):
+    """The fused fc backward launch (fc1 data gradient | fc1 dW | fc2 dW); with ``granks`` > 0 the fc1 filter gradient is
+    summed over the ranks' operand blocks (the "gather" data-parallel schedule), blocks at unrelated addresses."""
+    import ctypes as C
+    from distributed_tensorflow_amd import native
+    lib = native.hip()
+    P, I = C.c_void_p, C.c_int
+    lib.dtf_fc_bwd_trio_f32.argtypes = [P, P, P, I, I, P, P, I, P, I, I, I, P, P, P, I, I, I, I, P, P, I, P]
+    lib.dtf_fc_bwd_trio_f32.restype = I
+    torch.manual_seed(5 + granks)
+    B, n = 100, max(1, granks)
+    xs = [torch.randn(B, 3136, device=dev()) for _ in range(n)]
+    pad = torch.empty(4099, device=dev())  # (keeps the blocks from being evenly spaced)
+    dhs = [torch.randn(B, 1024, device=dev()) for _ in range(n)]
+    hdrop = torch.randn(B, 1024, device=dev())
+    dz = torch.zeros(B, 16, device=dev())
+    dz[:, :10] = torch.randn(B, 10, device=dev())
+    w = torch.randn(3136, 1024, device=dev()) * 0.05
+    dW0 = torch.full((3136, 1024), float("nan"), device=dev())
+    dW1 = torch.full((1024, 10), float("nan"), device=dev())
+    dX = torch.zeros(B, 3136, device=dev())
+    ga = (P * 8)(*[x.data_ptr() for x in xs])
+    gb = (P * 8)(*[d.data_ptr() for d in dhs])
+    torch.cuda.synchronize()
+    rc = lib.dtf_fc_bwd_trio_f32(xs[0].data_ptr(), dhs[0].data_ptr(), dW0.data_ptr(), 3136, 1024, hdrop.data_ptr(), dz.data_ptr(),
+                                 16, dW1.data_ptr(), 1024, 10, B, dhs[0].data_ptr(), w.data_ptr(), dX.data_ptr(), B, 3136, 1024,
+                                 8, ga if granks else None, gb if granks else None, granks, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref0 = sum(x.double().t() @ d.double() for x, d in zip(xs, dhs))
+    assert relerr(dW0, ref0) < 2e-6
+    assert relerr(dW1, hdrop.double().t() @ dz[:, :10].double()) < 2e-6
+    assert relerr(dX, dhs[0].double() @ w.double().t()) < 1e-5
+    # a batch whose K slabs would straddle two ranks' blocks is refused, not mis-summed
+    if granks:
+        assert lib.dtf_fc_bwd_trio_f32(xs[0].data_ptr(), dhs[0].data_ptr(), dW0.data_ptr(), 3136, 1024, hdrop.data_ptr(),
+                                       dz.data_ptr(), 16, dW1.data_ptr(), 1024, 10, 50, dhs[0].data_ptr(), w.data_ptr(),
+                                       dX.data_ptr(), 50, 3136, 1024, 8, ga, gb, granks, None) == -22
+    del pad
+
+
 def _conv2_ref(x, w, b):
     c = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), b.double(), padding=2)
     return c, F.max_pool2d(torch.relu(c), 2).permute(0, 2, 3, 1)

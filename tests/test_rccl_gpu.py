@@ -175,8 +175,8 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("schedule,dtype", [("ipc-inline", "fp32"), ("ipc-zerocopy", "fp32"), ("ipc-gather", "bf16"),
-                                            ("ipc-inline", "bf16")])
+@pytest.mark.parametrize("schedule,dtype", [("ipc-inline", "fp32"), ("ipc-zerocopy", "fp32"), ("ipc-gather", "fp32"),
+                                            ("ipc-gather", "bf16"), ("ipc-inline", "bf16")])
 def test_checked_step_validates_the_production_exchange(tmp_path, schedule, dtype):
     """``check_exchange`` (the ``--check_replicas`` assertion): the gradient the optimizer consumed under the production
     schedule equals the host-ordered sum of the ranks' local gradients; the checked step leaves counters, metrics and
