@@ -77,8 +77,10 @@ class NativeMnistEngine(_EngineBase):
         # every GEMM-shaped op on the exact-fp32 MFMA.  bf16 = bf16 MFMA operands, fp32 accumulation and master weights.
         self.dtype = dtype
         f32 = dtype == "fp32"
-        if f32:  # the fp32 kernels' own tile geometry (f32_fc.hip): 14 K-slabs of 224 forward, 4 of 256 backward
-            fc1_splits, bwd_splits = int(os.environ.get("DTF_FC1_SPLITS", 14)), int(os.environ.get("DTF_BWD_SPLITS", 4))
+        if f32:  # the fp32 kernels' own tile geometry (f32_fc.hip): 14 K-slabs of 224 forward, 6 of <= 192 backward
+            # (backward 4 -> 6: the data-gradient workgroups of the fused fc backward launch are its longest; 143.8 -> 142.0 us
+            # per step, scripts/gpu_sweep_knobs.sh; 8 and more lose again)
+            fc1_splits, bwd_splits = int(os.environ.get("DTF_FC1_SPLITS", 14)), int(os.environ.get("DTF_BWD_SPLITS", 6))
         self.lib = native.hip()
         native.check(self.lib.dtf_conv2_lds_init() or self.lib.dtf_conv2_bwd_lds_init() or self.lib.dtf_conv2_f32_init(),
                      "LDS kernel attribute setup")  # before any stream capture
