@@ -156,7 +156,7 @@ struct Ep32Atomic {  // C[m][n] += acc
 // LDS floats a workgroup of the body below needs
 template <int BM, int BN, class AL, class BL>
 constexpr int dtf_gemm32_lds() {
-  return (AL::LDS + BL::LDS) > BM * (BN + 4) ? (AL::LDS + BL::LDS) : BM * (BN + 4);
+  return 2 * (AL::LDS + BL::LDS) > BM * (BN + 4) ? 2 * (AL::LDS + BL::LDS) : BM * (BN + 4);  // two slab images | output image
 }
 
 // ------------------------------------------------------------------ the kernel body
@@ -166,11 +166,11 @@ constexpr int dtf_gemm32_lds() {
 // latencies, address arithmetic and staging of one run in the shadow of the other's MFMAs (one wave per SIMD: the
 // multiply phase of a slab took 2 850 cycles for 1 792 cycles of MFMA, phase stamps of scripts/dbg/fc_fwd_stamps.py).
 // The sets' partial sums are added in a fixed order in the LDS output image.
-// PF register sets of staged slabs are in flight ahead of the one being multiplied.
+// Two register sets of staged slabs are in flight ahead of the one being multiplied (PF = 2).
 // -DDTF_GEMM32_STAMPS (diagnostic builds only, scripts/dbg): thread 0 of every workgroup records the shader clock at the
 // phase boundaries of its slab loop into p.aux_out[workgroup][64]
 #ifdef DTF_GEMM32_STAMPS
-#define DTF_STAMP(i) do { const int _i = (i); if (threadIdx.x == 0 && _i < 64) stamps[_i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DTF_STAMP(i) do { const int _i = (i); if (threadIdx.x == 0 && _i < 62) stamps[_i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define DTF_STAMP(i) do { } while (0)
 #endif
@@ -182,8 +182,6 @@ __device__ __forceinline__ void dtf_gemm32_body(const GemmParams& p, const int m
   static_assert(TM >= 1 && TN >= 1 && BM % (WM * 16) == 0 && BN % (WN * 16) == 0, "tile");
   static_assert(PLAIN ? (BK % 4 == 0) : (BK % 16 == 0), "slab depth");
   static_assert(TM * TN >= 2, "the 16x16x4 f32 MFMA needs two independent accumulators to issue back to back");
-  float* __restrict__ As = smem;
-  float* __restrict__ Bs = smem + AL::LDS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ks = wave / (WM * WN), wmn = wave % (WM * WN);
   const int wm = wmn / WN, wn = wmn % WN;
@@ -194,6 +192,10 @@ __device__ __forceinline__ void dtf_gemm32_body(const GemmParams& p, const int m
   unsigned long long* stamps = reinterpret_cast<unsigned long long*>(p.aux_out) +
                                ((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 64;
   int si = 0;
+  if (threadIdx.x == 0) {  // placement: HW_ID (wave / SIMD / CU / SH / SE) and XCC_ID
+    stamps[62] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
+    stamps[63] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+  }
 #endif
   DTF_STAMP(si++);
 
@@ -205,10 +207,15 @@ __device__ __forceinline__ void dtf_gemm32_body(const GemmParams& p, const int m
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[a][b][i] = 0.f;
 
-  AL al[PF];
-  BL bl[PF];
+  // Two LDS images of a slab: slab i + 1 is stored while slab i is being multiplied, so the loop has ONE barrier per slab and
+  // the register -> LDS copy is off the critical path (single image: two barriers per slab and every wave idle around them
+  // for ~60 % of the slab time, scripts/dbg/fc_trio_stamps.py).
+  static_assert(PF == 2, "two register sets: slab i + 1 waits in registers while slab i + 2 / i + 3 is in flight");
+  constexpr int STAGE = AL::LDS + BL::LDS;
+  AL al[2];
+  BL bl[2];
 #pragma unroll
-  for (int s = 0; s < PF; ++s) {
+  for (int s = 0; s < 2; ++s) {
     al[s].init(p, m0, tid);
     bl[s].init(p, n0, tid);
     if (s == 0 || kbeg + s * BK < kend) {
@@ -217,20 +224,31 @@ __device__ __forceinline__ void dtf_gemm32_body(const GemmParams& p, const int m
     }
   }
   const int arow = wm * (BM / WM) + r, brow = wn * (BN / WN) + r;
-  for (int k = kbeg; k < kend; k += PF * BK) {
+  al[0].store(smem, tid);
+  bl[0].store(smem + AL::LDS, tid);
+  if (kbeg + 2 * BK < kend) {
+    al[0].load(kbeg + 2 * BK, kend, tid);
+    bl[0].load(kbeg + 2 * BK, kend, tid);
+  }
+  __syncthreads();
+  DTF_STAMP(si++);
+  for (int k = kbeg; k < kend; k += 2 * BK) {
 #pragma unroll
-    for (int s = 0; s < PF; ++s) {
+    for (int s = 0; s < 2; ++s) {
       if (s > 0 && k + s * BK >= kend) break;  // (workgroup-uniform)
-      __syncthreads();
-      DTF_STAMP(si++);
-      al[s].store(As, tid);
-      bl[s].store(Bs, tid);
-      __syncthreads();
-      DTF_STAMP(si++);
-      if (k + (s + PF) * BK < kend) {
-        al[s].load(k + (s + PF) * BK, kend, tid);
-        bl[s].load(k + (s + PF) * BK, kend, tid);
+      const float* __restrict__ As = smem + s * STAGE;
+      const float* __restrict__ Bs = As + AL::LDS;
+      // slab (k + s BK) is in image s; the next one goes from register set 1 - s into image 1 - s (last read before the
+      // barrier that ended the previous slab), and that register set is refilled with the slab after the next two
+      if (k + (s + 1) * BK < kend) {
+        al[1 - s].store(smem + (1 - s) * STAGE, tid);
+        bl[1 - s].store(smem + (1 - s) * STAGE + AL::LDS, tid);
+        if (k + (s + 3) * BK < kend) {
+          al[1 - s].load(k + (s + 3) * BK, kend, tid);
+          bl[1 - s].load(k + (s + 3) * BK, kend, tid);
+        }
       }
+      DTF_STAMP(si++);
       if constexpr (PLAIN) {
 #pragma unroll
         for (int t0 = 0; t0 < BK / 4; t0 += KW) {
@@ -264,6 +282,8 @@ __device__ __forceinline__ void dtf_gemm32_body(const GemmParams& p, const int m
               for (int b = 0; b < TN; ++b) acc[a][b] = mfma16f32(af[a][j], bf[b][j], acc[a][b]);
         }
       }
+      __syncthreads();
+      DTF_STAMP(si++);
     }
   }
   DTF_STAMP(si++);
