@@ -37,16 +37,22 @@ template <int R, int NT, int BK, bool IS_A>
 struct F32ColKSeg : F32ColK<R, NT, BK, IS_A> {
   using Base = F32ColK<R, NT, BK, IS_A>;
   const float* const* tab;
-  int seg;
+  const float* nxt;  // block pointer of the slab this register set loads next (fetched one load() early: a table read
+  int seg, nxt_s;    // in front of a slab's loads would put its latency into every slab, +6.5 us on the launch)
   __device__ __forceinline__ void init(const GemmParams& p, int r0_, int tid) {
     Base::init(p, r0_, tid);
     tab = reinterpret_cast<const float* const*>(IS_A ? p.A : p.B);
     seg = p.kseg;
+    nxt_s = -1;
+    nxt = nullptr;
   }
-  __device__ __forceinline__ void load(int k0_, int, int tid) {
+  __device__ __forceinline__ void load(int k0_, int kend_, int tid) {
     const int s = k0_ / seg;
-    this->src = tab[s];
+    this->src = s == nxt_s ? nxt : tab[s];
     Base::load(k0_ - s * seg, seg, tid);
+    nxt_s = (k0_ + 2 * BK) / seg;  // (the two register sets of the body alternate slabs)
+    if (k0_ + 2 * BK < kend_) nxt = tab[nxt_s];
+    else nxt_s = -1;
   }
 };
 using DwAg = F32ColKSeg<128, 256, 20, true>;
@@ -117,7 +123,7 @@ constexpr int TRIO32_LDS = dtf_gemm32_lds<112, 64, BdA, BdB>() > dtf_gemm32_lds<
 
 // (GATHER is a template parameter for the reason given at fc_bwd_trio_kernel in gemm_api.hip)
 template <bool GATHER>
-__global__ __launch_bounds__(256) void fc_bwd_trio_f32_kernel(const GemmTrio32 g) {
+__global__ __launch_bounds__(256, 3) void fc_bwd_trio_f32_kernel(const GemmTrio32 g) {
   __shared__ __attribute__((aligned(16))) float smem[TRIO32_LDS];
   const int id = blockIdx.x;
   if (id < g.nblk_q) {
