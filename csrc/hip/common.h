@@ -10,6 +10,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // hardware RNE convert (v_cvt_pk_bf16_f32); keeps NaN a NaN (MI355X_MICROARCH "Correctness boundaries")
 __device__ __forceinline__ uint16_t f2bf(float f) {

@@ -69,24 +69,34 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
       patch[r][c] = t.x;
       patch[r][c + 1] = t.y;
     }
-  float acc[4][8];
+  // channel pairs on v_pk_fma_f32 (two fp32 fmas per lane and instruction: this loop is the kernel's VALU time)
+  f32x2 acc2[4][4];
 #pragma unroll
   for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[s][j] = 0.f;
+    for (int j = 0; j < 4; ++j) acc2[s][j] = f32x2{0.f, 0.f};
 #pragma unroll
   for (int dy = 0; dy < 5; ++dy)
 #pragma unroll
     for (int dx = 0; dx < 5; ++dx) {
       const float4 w0 = *reinterpret_cast<const float4*>(&wl[(dy * 5 + dx) * 8]);      // LDS broadcast reads
       const float4 w1 = *reinterpret_cast<const float4*>(&wl[(dy * 5 + dx) * 8 + 4]);
-      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+      const f32x2 wv[4] = {f32x2{w0.x, w0.y}, f32x2{w0.z, w0.w}, f32x2{w1.x, w1.y}, f32x2{w1.z, w1.w}};
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const float pv = patch[(s >> 1) + dy][(s & 1) + dx];
+        const f32x2 pv2 = f32x2{pv, pv};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[s][j] = fmaf(pv, wv[j], acc[s][j]);
+        for (int j = 0; j < 4; ++j) acc2[s][j] = __builtin_elementwise_fma(pv2, wv[j], acc2[s][j]);
       }
+    }
+  float acc[4][8];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[s][2 * j] = acc2[s][j][0];
+      acc[s][2 * j + 1] = acc2[s][j][1];
     }
   uint32_t ov[4];
   float of[8];
