@@ -6,13 +6,13 @@
 // what matters is that every SIMD gets the same number of MFMAs and never waits:
 //  * forward: one workgroup per 20 pooling windows of the whole batch (245 workgroups at batch 100), 8 waves = (output-
 //    channel half, input-channel quarter): every wave issues the same 500 MFMAs on 10 accumulator tiles.
-//  * data gradient: one workgroup per (image, half of the input channels), the four waves split K (output-channel quarters
-//    of every tap): 1300 MFMAs each on 13 accumulator tiles.
+//  * data gradient: the same shape, one workgroup per 80 consecutive input positions of the batch (245 workgroups), 8 waves
+//    that split K (8 output channels of every tap each): 500 MFMAs on 10 accumulator tiles per wave.
 //    In both, the halo'd image sits in LDS, a wave streams its own disjoint slice of the filter straight from L2 into
-//    registers one tap ahead (no barrier inside the k loop), and the partial sums are combined through LDS at the end.
-//  * filter gradient: one workgroup per (4 images, half of the output channels, filter row); per image the waves take
-//    the 49 position groups round-robin with a per-image rotation, so over the 4 images each wave issues exactly 49 x 20
-//    MFMAs; 250 workgroups at batch 100.
+//    registers one filter row ahead (no barrier inside the k loop), and the partial sums are combined through LDS at the end.
+//  * filter gradient: one workgroup per (4 images, half of the output channels, filter row), 8 waves = (k group, input-
+//    channel tile); per image the k groups take the 49 position groups round-robin with a per-image rotation, so over the
+//    4 images every wave issues the same number of MFMAs; 250 workgroups at batch 100.
 // A fragments that run over channels use the freedom in the k order (f32_gemm.h): one ds_read_b64 / b128 feeds 2 / 4 MFMAs.
 #include "common.h"
 #include "conv1_dw_body.h"
