@@ -117,7 +117,7 @@ out["transport_after"] = tr.comm
 tr.train_steps(5)
 out["in_sync"] = tr.replicas_in_sync()
 out["host_step"], out["device_step"] = eng.global_step, int(eng.step_t.item())
-print("RESULT " + json.dumps(out), flush=True)
+json.dump(out, open(os.path.join(sys.argv[2], "r%d.json" % rank), "w"))  # (two ranks' stdout lines can interleave)
 dist.barrier()
 tr.close()
 dist.destroy_process_group()
@@ -133,11 +133,10 @@ def test_expired_ipc_wait_skips_the_optimizer_on_every_rank(tmp_path):
     env = dict(os.environ, MASTER_PORT="29643", HSA_ENABLE_IPC_MODE_LEGACY="0", DTF_DP_SCHEDULE="ipc-inline",
                DTF_IPC_TIMEOUT_S="0.4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29643", str(script), REPO]
+           "--master-port", "29643", str(script), REPO, str(tmp_path)]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
-    res = [json.loads(l.split("RESULT ", 1)[1]) for l in r.stdout.splitlines() if "RESULT " in l]
-    assert len(res) == 2, r.stdout[-3000:]
+    res = [json.load(open(str(tmp_path / ("r%d.json" % k)))) for k in range(2)]
     for o in res:
         assert o["skipped"] == 1 and o["unchanged"] and o["step_after"] == o["step_before"] and o["grad_discarded"], o
         assert o["healthy"] is False and o["transport_after"] == "rccl" and o["in_sync"] is True, o
