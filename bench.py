@@ -251,7 +251,10 @@ def main():
             "ipc_wait_timeouts": timeouts,
             "allreduce_us_at_startup": trainer.transport_us,
         }
-        print(json.dumps(out), flush=True)
+        # ONE write call for the whole line: with unbuffered stdio print() issues the text and the newline separately, and
+        # another rank's output on the shared pipe could land between them
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
     trainer.close()

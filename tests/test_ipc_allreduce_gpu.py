@@ -98,7 +98,8 @@ if rank == 0:            # rank 1 never joins this all-reduce: rank 0's kernels 
     torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 res = {"self_test": ok, "errors": comm.errors(), "seconds": dt}
-print(json.dumps({"rank": rank, **res}), flush=True)
+sys.stdout.write(json.dumps({"rank": rank, **res}) + "\n")  # (ONE write: the ranks share the pipe, print() makes two)
+sys.stdout.flush()
 dist.barrier()
 comm.close()
 dist.destroy_process_group()
