@@ -392,20 +392,25 @@ __global__ __launch_bounds__(256) void maxpool3x3_arg_kernel(const uint16_t* __r
     t /= Wo;
     const int ho = (int)(t % Ho);
     const int b = (int)(t / Ho);
+    uint4 v[9];  // (all nine taps requested before the first compare)
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9)
+      v[t9] = *reinterpret_cast<const uint4*>(x + (((long)b * H + ho * stride + t9 / 3) * W + wo * stride + t9 % 3) * in_cs + c0);
     float best[8];
     unsigned am[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { best[j] = -3.0e38f; am[j] = 0; }
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
+    for (int t9 = 0; t9 < 9; ++t9) {
+      float f[8];
+      unpack8(v[t9], f);
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        float f[8];
-        unpack8(*reinterpret_cast<const uint4*>(x + (((long)b * H + ho * stride + dy) * W + wo * stride + dx) * in_cs + c0), f);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (f[j] > best[j]) { best[j] = f[j]; am[j] = dy * 3 + dx; }
+      for (int j = 0; j < 8; ++j) {
+        const bool gt = f[j] > best[j];
+        best[j] = gt ? f[j] : best[j];
+        am[j] = gt ? (unsigned)t9 : am[j];
       }
+    }
     const long o = ((long)b * Ho + ho) * Wo + wo;
     *reinterpret_cast<uint4*>(out + o * out_cs + c0) = pack8(best);
     *reinterpret_cast<uint2*>(arg + o * C + c0) =
@@ -424,6 +429,7 @@ DTF_API int dtf_maxpool3x3_arg(const void* x, void* out, void* argmax, int B, in
 }
 
 // dx[b,h,w,c] (+)= sum over the windows (ho,wo) containing (h,w) whose argmax is (h,w) of dy[b,ho,wo,c]  (gather, no atomics)
+template <int NW>
 __global__ __launch_bounds__(256) void maxpool3x3_bwd_kernel(const uint16_t* __restrict__ dy, int dy_cs,
                                                              const uint8_t* __restrict__ arg, uint16_t* __restrict__ dx,
                                                              int dx_cs, int B, int H, int W, int C, int Ho, int Wo, int stride,
@@ -437,28 +443,37 @@ __global__ __launch_bounds__(256) void maxpool3x3_bwd_kernel(const uint16_t* __r
     t /= W;
     const int h = (int)(t % H);
     const int b = (int)(t / H);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // Position (h, w) lies in at most NW x NW windows (NW = 2 for stride >= 2, 3 for stride 1): their gradients, argmax bytes
+    // and the old dx are all requested before the first is used (clamped address + select instead of data-dependent loops:
+    // those compile to one branch, load and s_waitcnt per window).
     const int ho_lo = h >= 2 ? (h - 2 + stride - 1) / stride : 0, ho_hi = min(h / stride, Ho - 1);
     const int wo_lo = w >= 2 ? (w - 2 + stride - 1) / stride : 0, wo_hi = min(w / stride, Wo - 1);
-    for (int ho = ho_lo; ho <= ho_hi; ++ho)
-      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
-        const unsigned want = (unsigned)((h - ho * stride) * 3 + (w - wo * stride));
-        const long o = ((long)b * Ho + ho) * Wo + wo;
-        const uint2 a = *reinterpret_cast<const uint2*>(arg + o * C + c0);
-        float g[8];
-        unpack8(*reinterpret_cast<const uint4*>(dy + o * dy_cs + c0), g);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const unsigned aj = ((j < 4 ? a.x : a.y) >> (8 * (j & 3))) & 0xffu;
-          if (aj == want) acc[j] += g[j];
-        }
-      }
     uint16_t* dst = dx + (((long)b * H + h) * W + w) * dx_cs + c0;
-    if (accumulate) {
-      float old[8];
-      unpack8(*reinterpret_cast<const uint4*>(dst), old);
+    uint4 gv[NW * NW], oldv = make_uint4(0, 0, 0, 0);
+    uint2 av[NW * NW];
+    bool ok[NW * NW];
+    unsigned want[NW * NW];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += old[j];
+    for (int t = 0; t < NW * NW; ++t) {
+      const int ho = ho_lo + t / NW, wo = wo_lo + t % NW;
+      ok[t] = ho <= ho_hi && wo <= wo_hi;
+      want[t] = (unsigned)((h - ho * stride) * 3 + (w - wo * stride));
+      const long o = ok[t] ? ((long)b * Ho + ho) * Wo + wo : 0L;
+      av[t] = *reinterpret_cast<const uint2*>(arg + o * C + c0);
+      gv[t] = *reinterpret_cast<const uint4*>(dy + o * dy_cs + c0);
+    }
+    if (accumulate) oldv = *reinterpret_cast<const uint4*>(dst);
+    float acc[8];
+    unpack8(oldv, acc);
+#pragma unroll
+    for (int t = 0; t < NW * NW; ++t) {
+      float g[8];
+      unpack8(gv[t], g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned aj = ((j < 4 ? av[t].x : av[t].y) >> (8 * (j & 3))) & 0xffu;
+        acc[j] += (ok[t] && aj == want[t]) ? g[j] : 0.f;
+      }
     }
     *reinterpret_cast<uint4*>(dst) = pack8(acc);
   }
@@ -468,9 +483,14 @@ DTF_API int dtf_maxpool3x3_bwd(const void* dy, int dy_cs, const void* argmax, vo
                                int C, int stride, int accumulate, hipStream_t st) {
   if (B <= 0 || C % 8 || dy_cs % 8 || dx_cs % 8 || H < 3 || W < 3 || stride < 1) return ERR_SHAPE;
   const int Ho = (H - 3) / stride + 1, Wo = (W - 3) / stride + 1;
-  hipLaunchKernelGGL(maxpool3x3_bwd_kernel, dim3(ew_blocks((long)B * H * W * (C / 8))), dim3(256), 0, st,
-                     (const uint16_t*)dy, dy_cs, (const uint8_t*)argmax, (uint16_t*)dx, dx_cs, B, H, W, C, Ho, Wo, stride,
-                     accumulate);
+  if (stride >= 2)
+    hipLaunchKernelGGL(maxpool3x3_bwd_kernel<2>, dim3(ew_blocks((long)B * H * W * (C / 8))), dim3(256), 0, st,
+                       (const uint16_t*)dy, dy_cs, (const uint8_t*)argmax, (uint16_t*)dx, dx_cs, B, H, W, C, Ho, Wo, stride,
+                       accumulate);
+  else
+    hipLaunchKernelGGL(maxpool3x3_bwd_kernel<3>, dim3(ew_blocks((long)B * H * W * (C / 8))), dim3(256), 0, st,
+                       (const uint16_t*)dy, dy_cs, (const uint8_t*)argmax, (uint16_t*)dx, dx_cs, B, H, W, C, Ho, Wo, stride,
+                       accumulate);
   DTF_CHECK_LAUNCH();
   return 0;
 }
@@ -488,24 +508,27 @@ __global__ __launch_bounds__(256) void avgpool3x3_bwd_kernel(const uint16_t* __r
     t /= W;
     const int h = (int)(t % H);
     const int b = (int)(t / H);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int ho = max(h - 1, 0); ho <= min(h + 1, H - 1); ++ho) {
-      const int nr = min(ho + 1, H - 1) - max(ho - 1, 0) + 1;
-      for (int wo = max(w - 1, 0); wo <= min(w + 1, W - 1); ++wo) {
-        const int nc = min(wo + 1, W - 1) - max(wo - 1, 0) + 1;
-        const float inv = 1.f / (float)(nr * nc);
-        float g[8];
-        unpack8(*reinterpret_cast<const uint4*>(dy + (((long)b * H + ho) * W + wo) * dy_cs + c0), g);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += g[j] * inv;
-      }
-    }
+    // the nine candidate windows and the old dx are requested before the first is used (see maxpool3x3_bwd_kernel)
     uint16_t* dst = dx + (((long)b * H + h) * W + w) * dx_cs + c0;
-    if (accumulate) {
-      float old[8];
-      unpack8(*reinterpret_cast<const uint4*>(dst), old);
+    uint4 gv[9], oldv = make_uint4(0, 0, 0, 0);
+    float inv[9];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += old[j];
+    for (int t9 = 0; t9 < 9; ++t9) {
+      const int ho = h - 1 + t9 / 3, wo = w - 1 + t9 % 3;
+      const bool ok = (unsigned)ho < (unsigned)H && (unsigned)wo < (unsigned)W;
+      const int nr = min(ho + 1, H - 1) - max(ho - 1, 0) + 1, nc = min(wo + 1, W - 1) - max(wo - 1, 0) + 1;
+      inv[t9] = ok ? 1.f / (float)(nr * nc) : 0.f;
+      gv[t9] = *reinterpret_cast<const uint4*>(dy + (ok ? (((long)b * H + ho) * W + wo) * dy_cs + c0 : 0L));
+    }
+    if (accumulate) oldv = *reinterpret_cast<const uint4*>(dst);
+    float acc[8];
+    unpack8(oldv, acc);
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) {
+      float g[8];
+      unpack8(gv[t9], g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(g[j], inv[t9], acc[j]);
     }
     *reinterpret_cast<uint4*>(dst) = pack8(acc);
   }

@@ -350,8 +350,12 @@ __device__ __forceinline__ void conv2_bwd_data_f32_body(float* __restrict__ smem
     const int mt = t >> 1, nt = t & 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      // (clamped address + select: a conditional load becomes a branch with its own s_waitcnt, and the eight of them a
+      // chain of eight dependent round trips to L2 in the prologue: 12.4k cycles before the k loop, measured)
       const int p = P0 + mt * 16 + 4 * q + i;
-      pm[u][i] = (t < 2 * BD_MT && p < npos) ? pool1[(long)p * 32 + nt * 16 + r] : 0.f;
+      const bool ok = t < 2 * BD_MT && p < npos;
+      const float v = pool1[ok ? (long)p * 32 + nt * 16 + r : 0L];
+      pm[u][i] = ok ? v : 0.f;
     }
   }
   f32x4 acc[BD_MT][2];

@@ -504,10 +504,31 @@ struct EpBf16Acc {  // out[m*ldc + n] = bf16(acc (+ existing out when p.accumula
   template <int TM, int TN>
   static __device__ __forceinline__ void run(const GemmParams& p, f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int) {
     uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
-    DTF_EP_FOREACH(if (row < p.M && col < p.N) {
-      const long o = (long)row * p.ldc + col;
-      C[o] = (uint16_t)f2bf(p.accumulate ? v + bf2f(C[o]) : v);
-    })
+    if (!p.accumulate) {  // (workgroup-uniform)
+      DTF_EP_FOREACH(if (row < p.M && col < p.N) C[(long)row * p.ldc + col] = (uint16_t)f2bf(v);)
+      return;
+    }
+    // The 16 old values of a 32x32 tile are requested together (clamped address + select), then added and stored: a load
+    // under `if (row < M && col < N)` is a branch with its own s_waitcnt, i.e. 16 x TM x TN dependent round trips to L2
+    // per lane (found in the ISA: every data-gradient kernel of the fine-tune step spent its epilogue that way).
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int col = nbase + tn * 32 + (lane & 31);
+        uint16_t old[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = mbase + tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+          const bool ok = row < p.M && col < p.N;
+          old[i] = C[ok ? (long)row * p.ldc + col : 0L];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = mbase + tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+          if (row < p.M && col < p.N) C[(long)row * p.ldc + col] = (uint16_t)f2bf(acc[tm][tn][i] + bf2f(old[i]));
+        }
+      }
   }
 };
 

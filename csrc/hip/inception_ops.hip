@@ -38,26 +38,32 @@ __global__ __launch_bounds__(256) void pool3x3_kernel(const uint16_t* __restrict
     t /= Wo;
     const int ho = (int)(t % Ho);
     const int b = (int)(t / Ho);
+    // all nine taps are requested before the first is used (clamped address + select; with the loads under `if (ok)` the
+    // compiler emits nine branches with a load and an s_waitcnt each: nine dependent round trips per output, found in the ISA)
+    const int h0 = MODE == 0 ? ho * stride : ho - 1, w0 = MODE == 0 ? wo * stride : wo - 1;
+    uint4 v[9];
+    bool ok[9];
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) {
+      const int hi = h0 + t9 / 3, wi = w0 + t9 % 3;
+      ok[t9] = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+      v[t9] = *reinterpret_cast<const uint4*>(x + (ok[t9] ? (((long)b * H + hi) * W + wi) * in_cs + c0 : 0L));
+    }
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = MODE == 0 ? -3.0e38f : 0.f;
     int cnt = 0;
-    const int h0 = MODE == 0 ? ho * stride : ho - 1, w0 = MODE == 0 ? wo * stride : wo - 1;
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
+    for (int t9 = 0; t9 < 9; ++t9) {
+      float f[8];
+      unpack8(v[t9], f);
+      cnt += ok[t9] ? 1 : 0;
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int hi = h0 + dy, wi = w0 + dx;
-        const bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
-        const uint4 v = *reinterpret_cast<const uint4*>(x + (ok ? (((long)b * H + hi) * W + wi) * in_cs + c0 : 0L));
-        float f[8];
-        unpack8(v, f);
-        if (ok) {
-          ++cnt;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] = MODE == 0 ? fmaxf(acc[j], f[j]) : acc[j] + f[j];
-        }
+      for (int j = 0; j < 8; ++j) {
+        const float fj = ok[t9] ? f[j] : (MODE == 0 ? -3.0e38f : 0.f);
+        acc[j] = MODE == 0 ? fmaxf(acc[j], fj) : acc[j] + fj;
       }
+    }
     if (MODE == 1) {
       const float inv = 1.f / (float)cnt;
 #pragma unroll
