@@ -207,16 +207,31 @@ __global__ __launch_bounds__(256) void bn_finalize_relu_fwd_kernel(const float* 
     }
   }
   __syncthreads();
-  const int c8n = C >> 3;
-  const long total = M * c8n;
-  for (long gi = (long)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (long)gridDim.x * 256) {
-    const int c0 = (int)(gi % c8n) * 8;
-    const long m = gi / c8n;
-    float f[8];
-    unpack8(*reinterpret_cast<const uint4*>(z + m * C + c0), f);
+  // A lane keeps ONE group of 8 channels (scale / shift in registers, no per-element LDS or parameter reads) and walks the
+  // rows with four 16-byte loads in flight (clamped address + select): a one-load-per-iteration grid-stride loop keeps
+  // ~4 MB in flight on the whole chip, less than HBM latency x bandwidth needs.
+  const int c8n = C >> 3, rpb = 256 / c8n;
+  const int ry = threadIdx.x / c8n, c0 = (threadIdx.x - ry * c8n) * 8;
+  if (ry >= rpb) return;
+  float sc[8], sf[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * sm[c0 + j] + sm[C + c0 + j], 0.f);
-    *reinterpret_cast<uint4*>(y + m * y_cs + c0) = pack8(f);
+  for (int j = 0; j < 8; ++j) { sc[j] = sm[c0 + j]; sf[j] = sm[C + c0 + j]; }
+  const long stride = (long)gridDim.x * rpb;
+  for (long r = (long)blockIdx.x * rpb + ry; r < M; r += 4 * stride) {
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long rr = r + u * stride < M ? r + u * stride : r;
+      v[u] = *reinterpret_cast<const uint4*>(z + rr * C + c0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float f[8];
+      unpack8(v[u], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * sc[j] + sf[j], 0.f);
+      if (r + u * stride < M) *reinterpret_cast<uint4*>(y + (r + u * stride) * y_cs + c0) = pack8(f);
+    }
   }
 }
 
@@ -346,25 +361,39 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const uint16_t* 
     }
   }
   __syncthreads();
-  const int c8n = C >> 3;
-  const long total = M * c8n;
-  for (long gi = (long)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (long)gridDim.x * 256) {
-    const int c0 = (int)(gi % c8n) * 8;
-    const long m = gi / c8n;
-    float g[8], zz[8], mean[8], rstd[8], sc[8], sf[8];
-    unpack8(*reinterpret_cast<const uint4*>(dy + m * dy_cs + c0), g);
-    unpack8(*reinterpret_cast<const uint4*>(z + m * C + c0), zz);
-    ld8f(bn + c0, mean);
-    ld8f(bn + C + c0, rstd);
-    ld8f(bn + 2 * C + c0, sc);
-    ld8f(bn + 3 * C + c0, sf);
+  // one group of 8 channels per lane, parameters in registers, four rows in flight (see bn_finalize_relu_fwd_kernel)
+  const int c8n = C >> 3, rpb = 256 / c8n;
+  const int ry = threadIdx.x / c8n, c0 = (threadIdx.x - ry * c8n) * 8;
+  if (ry >= rpb) return;
+  float mean[8], rstd[8], sc[8], sf[8], a1[8], a2[8];
+  ld8f(bn + c0, mean);
+  ld8f(bn + C + c0, rstd);
+  ld8f(bn + 2 * C + c0, sc);
+  ld8f(bn + 3 * C + c0, sf);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float gj = zz[j] * sc[j] + sf[j] > 0.f ? g[j] : 0.f;
-      const float xh = (zz[j] - mean[j]) * rstd[j];
-      zz[j] = sc[j] * (gj - sm[c0 + j] * inv_m - xh * sm[C + c0 + j] * inv_m);
+  for (int j = 0; j < 8; ++j) { a1[j] = sm[c0 + j] * inv_m; a2[j] = sm[C + c0 + j] * inv_m; }
+  const long stride = (long)gridDim.x * rpb;
+  for (long r = (long)blockIdx.x * rpb + ry; r < M; r += 4 * stride) {
+    uint4 gv[4], zv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long rr = r + u * stride < M ? r + u * stride : r;
+      gv[u] = *reinterpret_cast<const uint4*>(dy + rr * dy_cs + c0);
+      zv[u] = *reinterpret_cast<const uint4*>(z + rr * C + c0);
     }
-    *reinterpret_cast<uint4*>(z + m * C + c0) = pack8(zz);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float g[8], zz[8];
+      unpack8(gv[u], g);
+      unpack8(zv[u], zz);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gj = zz[j] * sc[j] + sf[j] > 0.f ? g[j] : 0.f;
+        const float xh = (zz[j] - mean[j]) * rstd[j];
+        zz[j] = sc[j] * (gj - a1[j] - xh * a2[j]);
+      }
+      if (r + u * stride < M) *reinterpret_cast<uint4*>(z + (r + u * stride) * C + c0) = pack8(zz);
+    }
   }
 }
 
