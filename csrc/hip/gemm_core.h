@@ -418,12 +418,22 @@ struct LoadConvDwA {
     body                                                                            \
   }
 
+// (the bias of a column is loaded once per 32-column tile, ahead of the element loop: inside it, under the range check, the
+// compiler emits branch + load + s_waitcnt per element — 16 x TM x TN dependent round trips per lane, see
+// scripts/dbg/isa_serial_loads.py)
 struct EpStoreF32 {  // C[z][m][n] = acc (+bias) (relu)
   template <int TM, int TN>
   static __device__ __forceinline__ void run(const GemmParams& p, f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int z) {
     float* C = reinterpret_cast<float*>(p.C) + (long)z * p.slab_stride;
+    float bv[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = nbase + tn * 32 + (lane & 31);
+      const float b = p.bias ? p.bias[col < p.N ? col : 0] : 0.f;
+      bv[tn] = col < p.N ? b : 0.f;
+    }
     DTF_EP_FOREACH(if (row < p.M && col < p.N) {
-      float o = v + (p.bias ? p.bias[col] : 0.f);
+      float o = v + bv[tn];
       if (p.relu) o = fmaxf(o, 0.f);
       C[(long)row * p.ldc + col] = o;
     })
@@ -442,8 +452,15 @@ struct EpBiasReluBf16 {  // out[m*ldc + n] = bf16(relu(acc + bias[n]))   (conv i
   template <int TM, int TN>
   static __device__ __forceinline__ void run(const GemmParams& p, f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int) {
     uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
+    float bv[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = nbase + tn * 32 + (lane & 31);
+      const float b = p.bias ? p.bias[col < p.N ? col : 0] : 0.f;
+      bv[tn] = col < p.N ? b : 0.f;
+    }
     DTF_EP_FOREACH(if (row < p.M && col < p.N) {
-      float o = v + (p.bias ? p.bias[col] : 0.f);
+      float o = v + bv[tn];
       if (p.relu) o = fmaxf(o, 0.f);
       C[(long)row * p.ldc + col] = f2bf(o);
     })
@@ -455,11 +472,24 @@ struct EpMaskMulF32 {  // C = acc * (mask_bf16 > 0): conv bwd-data through the R
   static __device__ __forceinline__ void run(const GemmParams& p, f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int) {
     float* C = reinterpret_cast<float*>(p.C);
     const uint16_t* mask = reinterpret_cast<const uint16_t*>(p.aux_in);
-    DTF_EP_FOREACH(if (row < p.M && col < p.N) {
-      const long o = (long)row * p.ldc + col;
-      const uint16_t mk = mask[o];
-      C[o] = ((mk & 0x7fffu) != 0 && (mk & 0x8000u) == 0) ? v : 0.f;
-    })
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int col = nbase + tn * 32 + (lane & 31);
+        uint16_t mk[16];  // (the 16 mask values of a tile are requested together: clamped address + select)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = mbase + tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+          mk[i] = mask[(row < p.M && col < p.N) ? (long)row * p.ldc + col : 0L];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = mbase + tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+          if (row < p.M && col < p.N)
+            C[(long)row * p.ldc + col] = ((mk[i] & 0x7fffu) != 0 && (mk[i] & 0x8000u) == 0) ? acc[tm][tn][i] : 0.f;
+        }
+      }
   }
 };
 
