@@ -125,10 +125,16 @@ struct Ep32Store {  // C[z][m][n] = acc (+bias) (relu)
       const int row = c / (BN / 4), col = (c % (BN / 4)) * 4;
       if (m0 + row >= p.M || n0 + col >= p.N) continue;
       f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * (BN + 4) + col);
+      if (p.bias) {  // (workgroup-uniform; the four loads are requested together: clamped address + select)
+        float b[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (p.bias && n0 + col + j < p.N) v[j] += p.bias[n0 + col + j];
-        if (p.relu) v[j] = fmaxf(v[j], 0.f);
+        for (int j = 0; j < 4; ++j) b[j] = p.bias[n0 + col + j < p.N ? n0 + col + j : 0];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += n0 + col + j < p.N ? b[j] : 0.f;
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
       }
       float* dst = C + (long)(m0 + row) * p.ldc + n0 + col;
       if (vec && n0 + col + 3 < p.N) {

@@ -76,28 +76,34 @@ __device__ __forceinline__ bool wait_flag(const unsigned* flag, unsigned want, u
 // expires in the LAST phase is known to that rank only — leaves the others with complete sums: nobody applies a partial
 // one, the replicas may differ by one whole update, and DataParallelTrainer.ensure_healthy() re-synchronises them.
 // Call from every thread of the block after the phase's waits; `recorder`: this block accounts for the rank.
+// (`recorder` is workgroup-uniform.  The peers' counts are read by one lane per peer, all at once: one lane reading them in a
+// loop is world - 1 dependent round trips over xGMI, ~10 us per exchange on 8 GPUs.)
 __device__ __forceinline__ void settle_waits(const IpcComm& c, const bool timed_out, const bool recorder, const bool decide) {
-  __shared__ unsigned nerr;
-  if (threadIdx.x == 0) nerr = 0u;
+  __shared__ unsigned nerr, peers, own;
+  if (threadIdx.x == 0) { nerr = 0u; peers = 0u; }
   __syncthreads();
   if (timed_out) atomicAdd(&nerr, 1u);
   __syncthreads();
-  if (recorder && threadIdx.x == 0) {
+  if (!recorder) return;
+  if (threadIdx.x == 0) {
     unsigned mine = __hip_atomic_load(c.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (nerr) {
       mine += nerr;
       __hip_atomic_store(c.error, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(err_pub(c.base[c.rank]), mine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (decide && c.skip) {
-      unsigned sum = mine;
-      for (int p = 0; p < c.world; ++p)
-        if (p != c.rank) sum += __hip_atomic_load(err_pub(c.base[p]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      unsigned* seen = c.epoch + 3;
-      if (sum != *seen) {
-        *seen = sum;
-        __hip_atomic_store(c.skip, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      }
+    own = mine;
+  }
+  if (!(decide && c.skip)) return;
+  if ((int)threadIdx.x < c.world && (int)threadIdx.x != c.rank)
+    atomicAdd(&peers, __hip_atomic_load(err_pub(c.base[threadIdx.x]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned sum = own + peers;
+    unsigned* seen = c.epoch + 3;
+    if (sum != *seen) {
+      *seen = sum;
+      __hip_atomic_store(c.skip, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -289,23 +295,31 @@ __global__ __launch_bounds__(256) void ipc_sync_gather_kernel(const IpcComm c, f
       }
     }
   }
+  __shared__ unsigned last, peers;
   if (threadIdx.x == 0) {
-    const unsigned prev = atomicAdd(ticket, 1u);
-    if (prev == gridDim.x - 1) {  // every workgroup's waits are over: publish this rank's error count, look at the peers'
-      *ticket = 0u;
-      *c.epoch = e;
-      const unsigned mine = __hip_atomic_load(c.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(err_pub(c.base[c.rank]), mine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (c.skip) {
-        unsigned sum = mine;
-        for (int q = 0; q < c.world; ++q)
-          if (q != c.rank) sum += __hip_atomic_load(err_pub(c.base[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        unsigned* seen = c.epoch + 3;
-        if (sum != *seen) {
-          *seen = sum;
-          __hip_atomic_store(c.skip, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    peers = 0u;
+  }
+  __syncthreads();
+  if (!last) return;  // (workgroup-uniform)
+  // every workgroup's waits are over: publish this rank's error count, look at the peers' (one lane per peer, see settle_waits)
+  unsigned mine = 0u;
+  if (threadIdx.x == 0) {
+    *ticket = 0u;
+    *c.epoch = e;
+    mine = __hip_atomic_load(c.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(err_pub(c.base[c.rank]), mine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (!c.skip) return;
+  if ((int)threadIdx.x < c.world && (int)threadIdx.x != c.rank)
+    atomicAdd(&peers, __hip_atomic_load(err_pub(c.base[threadIdx.x]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned sum = mine + peers;
+    unsigned* seen = c.epoch + 3;
+    if (sum != *seen) {
+      *seen = sum;
+      __hip_atomic_store(c.skip, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
