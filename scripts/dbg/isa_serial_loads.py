@@ -44,3 +44,32 @@ for src, out, p in procs:
             found += 1
             print("%-18s %3d single-load waits in a row   %s" % (os.path.basename(src), r, k[:110]))
 print("%d kernel(s) with a run of >= %d serialised loads" % (found, min_run))
+
+# ---- second pass: loops whose body requests at most two loads before it waits for all of them (a streaming loop with one
+# or two loads in flight per lane: the bandwidth-latency product of HBM needs more)
+print()
+print("loops with <= 2 loads in flight per iteration (body has a full vmcnt(0) wait):")
+for src, out, p in procs:
+    if not os.path.exists(out):
+        continue
+    lines = open(out).read().split("\n")
+    kern, labels = None, {}
+    for i, line in enumerate(lines):
+        m = re.match(r"^(\w+):\s*;\s*@", line)
+        if m:
+            kern, labels = m.group(1), {}
+            continue
+        m = re.match(r"^(\.LBB\d+_\d+):", line)
+        if m:
+            labels[m.group(1)] = i
+            continue
+        m = re.match(r"\s+s_cbranch_\w+\s+(\.LBB\d+_\d+)", line)
+        if m and m.group(1) in labels and kern:  # backward branch = loop
+            body = lines[labels[m.group(1)]:i]
+            if any(re.match(r"^\.LBB", b) for b in body[1:]):
+                continue  # (only innermost, single-block loops)
+            nload = sum(1 for b in body if load.search(b) and " lds" not in b)
+            full = sum(1 for b in body if "s_waitcnt" in b and "vmcnt(0)" in b)
+            nmfma = sum(1 for b in body if "v_mfma" in b)
+            if 1 <= nload <= 2 and full >= 1 and nmfma == 0:
+                print("%-18s %d load(s) per iteration   %s" % (os.path.basename(src), nload, kern[:100]))
