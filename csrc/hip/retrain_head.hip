@@ -124,9 +124,19 @@ __global__ __launch_bounds__(256) void retrain_head_bwd_kernel(const float* __re
   if (t < (long)BN * C) {
     const int c = (int)(t / BN), k = (int)(t % BN);
     float g = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const long src = rows ? rows[b] : b;
-      g = fmaf(cache[src * BN + k], dz[(long)b * C + c], g);
+    // eight batch rows requested together (row index -> cache row is a dependent pair of loads: one pair per iteration is
+    // B dependent round trips, 31 us at batch 100); summed in batch order as before
+    for (int b0 = 0; b0 < B; b0 += 8) {
+      float xv[8], dv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + u < B ? b0 + u : B - 1;
+        const long src = rows ? rows[b] : b;
+        xv[u] = cache[src * BN + k];
+        dv[u] = dz[(long)b * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) g = b0 + u < B ? fmaf(xv[u], dv[u], g) : g;
     }
     if (fused_lr > 0.f) W[(long)k * C + c] -= fused_lr * g; else gW[(long)k * C + c] = g;
   } else if (t < (long)BN * C + C) {
