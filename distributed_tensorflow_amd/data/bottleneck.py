@@ -268,16 +268,23 @@ class BottleneckCache:
 
     # -------------------------------------------------------------- samplers
     def sample_rows(self, category: str, how_many: int, seed: int = 0) -> torch.Tensor:
-        """Device int32 row indices.  ``how_many >= 0``: class-balanced with replacement;
+        """Device int32 row indices.  ``how_many >= 0``: class-balanced with replacement (on a GPU the returned tensor is a
+        per-(split, size) buffer, overwritten by the next draw of the same split and size: use it, or copy it, before then);
         ``how_many < 0``: every image of the split in label-major order (``retrain1/retrain.py:341-353``)."""
         s = CATEGORIES.index(category)
         if how_many < 0:
             return torch.from_numpy(self.index.rows_of(category).astype(np.int32)).to(self.device)
-        offs = self.offsets[:, s].contiguous()
-        cnts = self.counts[:, s].contiguous()
+        # (per-split offset / count columns and the output buffer are kept: the retrain loop draws twice per step, and the
+        # slicing, .contiguous() and torch.empty of a fresh draw cost more host time than the step's kernels take)
+        memo = self.__dict__.setdefault("_sample_memo", {})
+        if s not in memo:
+            memo[s] = (self.offsets[:, s].contiguous(), self.counts[:, s].contiguous(), {})
+        offs, cnts, bufs = memo[s]
         self._draws += 1
         if self.device.type == "cuda":
-            rows = torch.empty(how_many, dtype=torch.int32, device=self.device)
+            if how_many not in bufs:
+                bufs[how_many] = torch.empty(how_many, dtype=torch.int32, device=self.device)
+            rows = bufs[how_many]  # (reused: every consumer is enqueued on the same stream before the next draw)
             native.check(native.hip().dtf_sample_rows(offs.data_ptr(), cnts.data_ptr(), self.index.num_classes, how_many,
                                                       seed, self._draws, rows.data_ptr(),
                                                       torch.cuda.current_stream().cuda_stream), "sample_rows")

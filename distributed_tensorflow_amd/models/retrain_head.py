@@ -89,7 +89,7 @@ class RetrainHead:
         B = int(rows.shape[0]) if rows is not None else int(cache.shape[0])
         p = RetrainHeadParams()
         p.cache, p.labels_all, p.rows = cache.data_ptr(), labels_all.data_ptr(), native.ptr(rows)
-        p.W, p.b = self.weights.data_ptr(), self.biases.data_ptr()
+        p.W, p.b = self.P.data_ptr(), self.P.data_ptr() + 4 * BOTTLENECK * self.C  # (= weights / biases: views cost host time)
         p.B, p.C, p.grad_scale = B, self.C, 1.0 / B
         p.double_softmax, p.training = int(self.double_softmax), int(training)
         probs = torch.empty(B, self.C, dtype=torch.float32, device=self.device) if want_probs else None
@@ -161,7 +161,8 @@ class RetrainHead:
             lib = native.hip()
             if self.world == 1:
                 native.check(lib.dtf_retrain_head_bwd(cache.data_ptr(), native.ptr(rows), self._dz.data_ptr(), B, self.C,
-                                                      self.weights.data_ptr(), self.biases.data_ptr(), 0, 0, self.lr, st), "head bwd")
+                                                      self.P.data_ptr(), self.P.data_ptr() + 4 * BOTTLENECK * self.C, 0, 0,
+                                                      self.lr, st), "head bwd")
             else:
                 from ..ops import hip_ops
                 from ..parallel.ddp import all_reduce_
