@@ -235,107 +235,6 @@ def _l2err(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def _cos(a, b):
-    a, b = a.float().flatten(), b.float().flatten()
-    return float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
-
-
-def test_full_network_step_matches_autograd_layerwise():
-    """A random-init 47-layer BatchNorm net amplifies bf16 rounding noise ~1.5x per block (measured: exact in the stem,
-    4% at mixed_4, 30% at mixed_10 against the bf16-simulating oracle), so the end-to-end comparison is only a loose
-    sanity check; the rigorous check is teacher-forced: every conv's forward and all of its gradients are recomputed
-    with autograd from the native executor's own input activation and upstream gradient."""
-    from distributed_tensorflow_amd.models.inception_train import InceptionTrainer, torch_train_step
-    from distributed_tensorflow_amd.models.inception_v3 import BN_EPS
-    torch.manual_seed(0)
-    B, C = 4, 5
-    tr = InceptionTrainer(C, B, "cuda", lr=0.01, seed=3)
-    x = torch.zeros(B, 299, 299, 8, device="cuda")
-    x[..., :3] = torch.randn(B, 299, 299, 3, device="cuda")
-    x = x.to(BF)
-    labels = torch.tensor([0, 3, 1, 4], device="cuda", dtype=torch.int32)
-    params = {k: tr.layout.view(tr.P, k).clone() for k in tr.layout.entries}
-    tr.fwd_bwd(x, labels)
-    torch.cuda.synchronize()
-    loss_ref, grads, feat_ref = torch_train_step(tr.graph, params, x[..., :3].float().permute(0, 3, 1, 2).contiguous(), labels,
-                                                 bf16_sim=True)
-    loss, acc = tr.metrics()
-    cos_feat, dloss = _cos(tr.feat, feat_ref), abs(loss - float(loss_ref))
-    print("end to end: cos(features) %.5f, |loss - oracle| %.5f" % (cos_feat, dloss))
-    assert cos_feat > 0.98, cos_feat
-    assert dloss < 5e-2, dloss
-    # head gradients from the native features
-    W = params["final_training_ops/weights/final_weights"].clone().requires_grad_(True)
-    b = params["final_training_ops/biases/final_biases"].clone().requires_grad_(True)
-    f = tr.feat.clone().requires_grad_(True)
-    l = F.cross_entropy(f @ W + b, labels.long())
-    gW, gb_, gf = torch.autograd.grad(l, (W, b, f))
-    assert _relerr(tr.grad("final_training_ops/weights/final_weights"), gW) < 1e-3
-    assert _relerr(tr.grad("final_training_ops/biases/final_biases"), gb_) < 1e-3
-    assert _relerr(tr.dfeat, gf) < 1e-3
-    consumers = {}
-    for op in tr.graph.ops:
-        consumers[op.src] = consumers.get(op.src, 0) + 1
-    worst = {"y": 0.0, "dW": 0.0, "dgamma": 0.0, "dbeta": 0.0, "dx": 0.0}
-    n_dx = 0
-    for op in tr.graph.ops:
-        if op.kind != "conv":
-            continue
-        s = op.conv
-        src = x if op.src == "input" else tr.act[op.src]
-        xin = src.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
-        w = _r(params[s.name + "/conv2d_params"]).permute(3, 2, 0, 1).contiguous().requires_grad_(True)
-        gm = params[s.name + "/batchnorm/gamma"].clone().requires_grad_(True)
-        bt = params[s.name + "/batchnorm/beta"].clone().requires_grad_(True)
-        z = F.conv2d(xin, w, stride=s.stride, padding=s.pad)
-        z = z + (_r(z) - z).detach()
-        mean, var = z.mean((0, 2, 3), keepdim=True), z.var((0, 2, 3), unbiased=False, keepdim=True)
-        y = F.relu((z - mean) * torch.rsqrt(var + BN_EPS) * gm.view(1, -1, 1, 1) + bt.view(1, -1, 1, 1))
-        y_nat = tr.act[op.dst][..., op.dst_off:op.dst_off + s.cout].float().permute(0, 3, 1, 2)
-        dy = tr.dact[op.dst][..., op.dst_off:op.dst_off + s.cout].float().permute(0, 3, 1, 2)
-        gx, gw, gg, gb = torch.autograd.grad(y, (xin, w, gm, bt), dy)
-        errs = {"y": _l2err(y_nat, y.detach()), "dW": _l2err(tr.grad(s.name + "/conv2d_params"), gw.permute(2, 3, 1, 0)),
-                "dgamma": _l2err(tr.grad(s.name + "/batchnorm/gamma"), gg), "dbeta": _l2err(tr.grad(s.name + "/batchnorm/beta"), gb)}
-        if op.src != "input" and consumers[op.src] == 1:
-            errs["dx"] = _l2err(tr.dact[op.src], gx.permute(0, 2, 3, 1))
-            n_dx += 1
-        for k, v in errs.items():
-            worst[k] = max(worst[k], v)
-            assert v < 2e-2, (s.name, k, v)
-    print("worst layerwise relative L2 errors:", worst)
-    assert n_dx > 40
-    # branch points: the gradient of a block input is the sum over its four consumers
-    for blk_src, blk in (("mixed_8", "mixed_9"), ("pool_1:out", "mixed")):
-        xin = tr.act[blk_src].float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
-        total = torch.zeros_like(xin)
-        for op in tr.graph.ops:
-            if op.src != blk_src:
-                continue
-            if op.kind == "conv":
-                s = op.conv
-                w = _r(params[s.name + "/conv2d_params"]).permute(3, 2, 0, 1).contiguous()
-                z = F.conv2d(xin, w, stride=s.stride, padding=s.pad)
-                z = z + (_r(z) - z).detach()
-                mean, var = z.mean((0, 2, 3), keepdim=True), z.var((0, 2, 3), unbiased=False, keepdim=True)
-                y = F.relu((z - mean) * torch.rsqrt(var + BN_EPS) * params[s.name + "/batchnorm/gamma"].view(1, -1, 1, 1)
-                           + params[s.name + "/batchnorm/beta"].view(1, -1, 1, 1))
-                dy = tr.dact[op.dst][..., op.dst_off:op.dst_off + s.cout].float().permute(0, 3, 1, 2)
-            elif op.kind == "avgpool":
-                y = F.avg_pool2d(xin, 3, 1, 1, count_include_pad=False)
-                dy = tr.dact[op.dst].float().permute(0, 3, 1, 2)
-            else:
-                continue
-            total = total + torch.autograd.grad(y, xin, dy)[0]
-        assert _l2err(tr.dact[blk_src], total.permute(0, 2, 3, 1)) < 2e-2, blk_src
-    # the optimizer step consumes and clears the gradient arena
-    p0 = tr.P.clone()
-    g0 = tr.G.clone()
-    tr.apply()
-    torch.cuda.synchronize()
-    assert torch.allclose(tr.P, p0 - 0.01 * g0, atol=1e-6) and float(tr.G.abs().max()) == 0.0
-    assert int(tr.step_t.item()) == 1
-
-
 def test_every_conv_core_variant_agrees_on_every_layer():
     """The autotuner picks a conv core per layer and pass from timings, so WHICH kernel variant runs a layer differs from
     run to run: here every variant it may pick (forward 1..5, filter gradient 1..3, data gradient 1..5 with and without
