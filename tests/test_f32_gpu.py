@@ -69,7 +69,7 @@ def test_fc_backward_weight_f32(ops, M, N, Kb, ldy):
     assert got.shape == (M, N) and relerr(got, ref) < 2e-6
 
 
-@pytest.mark.parametrize("granks", [0, 2, 3])
+@pytest.mark.parametrize("granks", [0, 2, 3, 8])
 def test_fc_backward_trio_f32(granks):
     """The fused fc backward launch (fc1 data gradient | fc1 dW | fc2 dW); with ``granks`` > 0 the fc1 filter gradient is
     summed over the ranks' operand blocks (the "gather" data-parallel schedule), blocks at unrelated addresses."""

@@ -62,7 +62,11 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("world", [2, 4])
+# (8 ranks, the size of one xGMI node, on request: DTF_TEST_IPC_WORLDS=2,4,8; the default keeps the suite short)
+_WORLDS = [int(w) for w in os.environ.get("DTF_TEST_IPC_WORLDS", "2,4").split(",")]
+
+
+@pytest.mark.parametrize("world", _WORLDS)
 def test_ipc_allreduce_ranks_sharing_one_gpu(tmp_path, world):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "ipc_worker.py"
