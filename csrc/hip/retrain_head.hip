@@ -158,9 +158,11 @@ DTF_API int dtf_retrain_head_bwd(const float* cache, const int* rows, const floa
 }
 
 // dx[b][k] = sum_c dz[b][c] * W[k][c]: the gradient w.r.t. the bottleneck, needed only when the backbone is fine-tuned
-// (SURVEY §2.6 config 5).  thread -> (b, k); consecutive lanes write consecutive k.
+// (SURVEY §2.6 config 5).  thread -> (b, k); consecutive lanes write consecutive k.  `clear` (optional): two floats set to
+// zero, the metric slot of the NEXT step (the fine-tune trainer alternates two slots, so no memset launch is needed).
 __global__ __launch_bounds__(256) void retrain_head_dx_kernel(const float* __restrict__ dz, const float* __restrict__ W,
-                                                              float* __restrict__ dx, int B, int C) {
+                                                              float* __restrict__ dx, int B, int C, float* __restrict__ clear) {
+  if (clear && blockIdx.x == 0 && threadIdx.x < 2) clear[threadIdx.x] = 0.f;
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   if (t >= (long)B * BN) return;
   const int b = (int)(t / BN), k = (int)(t % BN);
@@ -169,9 +171,9 @@ __global__ __launch_bounds__(256) void retrain_head_dx_kernel(const float* __res
   dx[t] = g;
 }
 
-DTF_API int dtf_retrain_head_dx(const float* dz, const float* W, float* dx, int B, int C, hipStream_t st) {
+DTF_API int dtf_retrain_head_dx(const float* dz, const float* W, float* dx, int B, int C, float* clear, hipStream_t st) {
   if (B <= 0 || C <= 0) return ERR_SHAPE;
-  hipLaunchKernelGGL(retrain_head_dx_kernel, dim3(dtf_cdiv((long)B * BN, 256)), dim3(256), 0, st, dz, W, dx, B, C);
+  hipLaunchKernelGGL(retrain_head_dx_kernel, dim3(dtf_cdiv((long)B * BN, 256)), dim3(256), 0, st, dz, W, dx, B, C, clear);
   DTF_CHECK_LAUNCH();
   return 0;
 }

@@ -251,8 +251,7 @@ class InceptionTrainer:
         self.bn = torch.zeros(4 * self.stat_total, dtype=torch.float32, device=dev)  # mean, rstd, scale, shift per conv
         self.feat = torch.zeros(B, BOTTLENECK_TENSOR_SIZE, dtype=torch.float32, device=dev)
         self.dfeat = torch.zeros_like(self.feat)
-        self.last_loss = torch.zeros((), dtype=torch.float32, device=dev)
-        self.last_correct = torch.zeros((), dtype=torch.float32, device=dev)
+        self._last_metrics = torch.zeros(2, dtype=torch.float32, device=dev)  # (loss sum, correct count) of the last step
 
     def activation_bytes(self) -> int:
         n = sum(t.numel() * t.element_size() for d in (self.act, self.dact, self.z) for t in d.values())
@@ -434,23 +433,27 @@ class InceptionTrainer:
         B = self.B
         if not hasattr(self, "_head_dz"):
             self._head_dz = torch.empty(B, self.C, dtype=torch.float32, device=self.device)
-            self._head_metrics = torch.zeros(2, dtype=torch.float32, device=self.device)
+            # two (loss sum, correct count) slots used in turn: a step's last head kernel clears the other one, and
+            # metrics() divides on the host, so the step holds no memset or element-wise launch
+            self._head_metrics = torch.zeros(2, 2, dtype=torch.float32, device=self.device)
+            self._head_par = 0
             self._head_labels = torch.empty(B, dtype=torch.int32, device=self.device)
         self._head_labels.copy_(labels)
-        self._head_metrics.zero_()
+        cur, nxt = self._head_metrics[self._head_par], self._head_metrics[self._head_par ^ 1]
+        self._head_par ^= 1
         p = RetrainHeadParams()
         p.cache, p.labels_all, p.rows = self.feat.data_ptr(), self._head_labels.data_ptr(), None
         p.W, p.b, p.B, p.C, p.grad_scale = W.data_ptr(), b.data_ptr(), B, self.C, 1.0 / B
         p.double_softmax, p.training = int(self.double_softmax), 1
-        p.probs, p.pred, p.dz, p.metrics = None, None, self._head_dz.data_ptr(), self._head_metrics.data_ptr()
+        p.probs, p.pred, p.dz, p.metrics = None, None, self._head_dz.data_ptr(), cur.data_ptr()
         native.check(lib.dtf_retrain_head_fwd(C.byref(p), st), "head fwd")
         native.check(lib.dtf_retrain_head_bwd(self.feat.data_ptr(), None, self._head_dz.data_ptr(), B, self.C, None, None,
                                               self.grad("final_training_ops/weights/final_weights").data_ptr(),
                                               self.grad("final_training_ops/biases/final_biases").data_ptr(), 0.0, st), "head bwd")
-        native.check(lib.dtf_retrain_head_dx(self._head_dz.data_ptr(), W.data_ptr(), self.dfeat.data_ptr(), B, self.C, st), "head dx")
-        # (loss sum, correct count) stay on the device; metrics() reads them
-        self.last_loss = self._head_metrics[0] / B
-        self.last_correct = self._head_metrics[1]
+        native.check(lib.dtf_retrain_head_dx(self._head_dz.data_ptr(), W.data_ptr(), self.dfeat.data_ptr(), B, self.C,
+                                             nxt.data_ptr(), st), "head dx")
+        # (loss sum, correct count) stay on the device, valid until the step after the next; metrics() reads them
+        self._last_metrics = cur
 
     def _dw_splits(self, K: int, Cout: int, npos: int) -> int:
         blocks = ((K + 127) // 128) * ((Cout + 63) // 64)
@@ -531,7 +534,8 @@ class InceptionTrainer:
         self.apply()
 
     def metrics(self) -> Tuple[float, float]:
-        return float(self.last_loss.item()), float(self.last_correct.item()) / self.B
+        loss_sum, correct = self._last_metrics.tolist()
+        return loss_sum / self.B, correct / self.B
 
     def flops_per_step(self) -> float:
         from .inception_v3 import graph_flops

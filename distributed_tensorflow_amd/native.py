@@ -177,7 +177,7 @@ def hip() -> C.CDLL:
         _sig(lib, "dtf_sample_rows", I, [P, P, I, I, C.c_ulonglong, C.c_ulonglong, P, P])
         _sig(lib, "dtf_retrain_head_fwd", I, [P, P])
         _sig(lib, "dtf_retrain_head_bwd", I, [P, P, P, I, I, P, P, P, P, F, P])
-        _sig(lib, "dtf_retrain_head_dx", I, [P, P, P, I, I, P])
+        _sig(lib, "dtf_retrain_head_dx", I, [P, P, P, I, I, P, P])
         for extra in _HIP_EXTRA_SIGS:
             if hasattr(lib, extra[0]):
                 _sig(lib, *extra)
