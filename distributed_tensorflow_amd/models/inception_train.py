@@ -452,7 +452,7 @@ class InceptionTrainer:
                                               self.grad("final_training_ops/biases/final_biases").data_ptr(), 0.0, st), "head bwd")
         native.check(lib.dtf_retrain_head_dx(self._head_dz.data_ptr(), W.data_ptr(), self.dfeat.data_ptr(), B, self.C,
                                              nxt.data_ptr(), st), "head dx")
-        # (loss sum, correct count) stay on the device, valid until the step after the next; metrics() reads them
+        # (loss sum, correct count) stay on the device until the next step clears that slot; metrics() reads them
         self._last_metrics = cur
 
     def _dw_splits(self, K: int, Cout: int, npos: int) -> int:
