@@ -32,6 +32,14 @@ struct IG2Params {
   const uint16_t* Wp;
   int mtiles, ntiles;
   unsigned magic_c, magic_kw;  // floor(2^32 / d) + 1 for d = channels per tap, KW
+  // Stride-2 backward-data by parity class (template flag S2).  With stride 2 a tap (dy, dx) reaches an output only from
+  // input pixels with dy = h + pad_h and dx = w + pad_w (mod 2), so in pixel order three quarters of a tile's MFMAs
+  // multiply zeros.  Here the M rows are ordered class by class (class = 2 * parity(h + pad_h) + parity(w + pad_w)), every
+  // class padded to whole tiles, and a tile runs only the K-steps that touch a tap of its class (smask).
+  int tile0[4];                 // first m tile of class c (non-decreasing; mtiles = end of class 3)
+  int rows[4];                  // rows of class c = B * nh * nw
+  int nh[4], nw[4], h0[4], w0[4];  // class c holds the pixels (h0 + 2i, w0 + 2j), i < nh, j < nw
+  unsigned long long smask[4];  // bit t: K-step t (64 k) touches a tap of class c
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -46,7 +54,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // Tile variants: BM x BN x stages.  256-row tiles keep one workgroup per CU (120-144 KB of LDS) and pay off when an M
 // tile has many K-steps; 128-row tiles (72 / 64 KB) put two workgroups on a CU, whose prologues and epilogues then
 // overlap — the better shape for the short K loops (K = 192..800) that dominate this network.
-template <int BM, int BN, int S, int MODE, class EP>
+template <int TM, int TN>
+__device__ __forceinline__ void ep_acc_s2(const IG2Params& q, int cls, f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane);
+
+template <int BM, int BN, int S, int MODE, class EP, bool S2 = false>
 __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm2_kernel(const IG2Params q) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the buffer-resource builtins do not exist in the host pass)
   constexpr int BK = 64;
@@ -63,7 +74,10 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm2_kernel(cons
   const int id = blockIdx.x, xcd = id & 7, local = id >> 3;
   const int nt = local % q.ntiles, mt = (local / q.ntiles) * 8 + xcd;
   if (mt >= q.mtiles) return;
-  const int m0 = mt * BM, n0 = nt * BN;
+  static_assert(!S2 || MODE == 1, "parity classes exist for the stride-2 data gradient only");
+  int cls = 0;
+  if (S2) cls = (mt >= q.tile0[1] ? 1 : 0) + (mt >= q.tile0[2] ? 1 : 0) + (mt >= q.tile0[3] ? 1 : 0);
+  const int m0 = S2 ? (mt - q.tile0[cls]) * BM : mt * BM, n0 = nt * BN;  // (S2: row index inside the class)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane >> 3;
   // this lane's logical k offset inside a K-step (swizzle on the global side): LDS row R stores chunk c at position
@@ -83,7 +97,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm2_kernel(cons
 #pragma unroll
   for (int i = 0; i < A_PER; ++i) {
     const int m = m0 + (wave * A_PER + i) * 8 + lrow;
-    const bool okr = m < p.M;
+    const bool okr = S2 ? m < q.rows[cls] : m < p.M;
     unsigned rowbits = 0, colbits = 0;
     if (MODE == 0) {
       const int wo = m % g.Wo, t = m / g.Wo;
@@ -93,9 +107,19 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm2_kernel(cons
       for (int d = 0; d < g.KH; ++d) rowbits |= ((unsigned)(hi0 + d) < (unsigned)g.H ? 1u : 0u) << d;
       for (int d = 0; d < g.KW; ++d) colbits |= ((unsigned)(wi0 + d) < (unsigned)g.W ? 1u : 0u) << d;
     } else {
-      const int w = m % g.W, t = m / g.W;
-      const int im = t / g.H;
-      const int hb = t % g.H + g.pad_h, wb = w + g.pad_w;
+      int w, hh, im;
+      if (S2) {
+        const int mm = okr ? m : 0, nwc = q.nw[cls], nhc = q.nh[cls], t = mm / nwc;
+        w = q.w0[cls] + 2 * (mm - t * nwc);
+        im = t / nhc;
+        hh = q.h0[cls] + 2 * (t - im * nhc);
+      } else {
+        const int t = m / g.W;
+        w = m % g.W;
+        im = t / g.H;
+        hh = t % g.H;
+      }
+      const int hb = hh + g.pad_h, wb = w + g.pad_w;
       abase_off[i] = (unsigned)(im * g.Ho * g.Wo * g.cstride + (hb * g.Wo + wb) * cs_eff) * 2u;
       for (int d = 0; d < g.KH; ++d) {
         const int hz = hb - d;
@@ -154,20 +178,30 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm2_kernel(cons
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
   const int nsteps = (p.K + BK - 1) / BK;
-  issue(0, 0);
-  if (S == 3) issue(1, 1);  // steps >= nsteps only fetch out-of-range zeros (k >= K)
+  // S2: the steps of this tile's class, in order; once they run out the prefetches ask for step nsteps (zeros, as below)
+  unsigned long long pend = S2 ? q.smask[cls] : 0ull;
+  const int nrun = S2 ? __builtin_popcountll(pend) : nsteps;
+  auto next_step = [&](int linear) -> int {
+    if (!S2) return linear;
+    if (!pend) return nsteps;
+    const int t = __builtin_ctzll(pend);
+    pend &= pend - 1;
+    return t;
+  };
+  issue(next_step(0), 0);
+  if (S == 3) issue(next_step(1), 1);  // steps >= nsteps only fetch out-of-range zeros (k >= K)
 
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
   const int sw = (r >> 1) & 7;  // fragment rows start at multiples of 32: (R >> 1) & 7 == (r >> 1) & 7
-  for (int t = 0; t < nsteps; ++t) {
+  for (int t = 0; t < nrun; ++t) {
     wait_vmcnt<(S - 2) * LPS>();  // this wave's loads of stage t have landed (with S == 3 stage t+1 stays in flight)
     // Bare s_barrier, not __syncthreads(): the latter's fence makes hipcc emit s_waitcnt vmcnt(0), which would drain
     // the stage that is supposed to stay in flight.  After it everyone's stage-t data is in LDS and everyone is done
     // reading the stage consumed at step t-1 (its ds_reads were waited on before the MFMAs that used them).
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    issue(t + S - 1, (t + S - 1) % S);
+    issue(next_step(t + S - 1), (t + S - 1) % S);
     const unsigned char* As = smem + (t % S) * STAGE;
     const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
@@ -185,24 +219,66 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm2_kernel(cons
     }
   }
   wait_vmcnt<0>();  // drain the out-of-range prefetches before the LDS is released
-  EP::template run<2, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, 0);
+  if (S2)
+    ep_acc_s2<2, 2>(q, cls, acc, m0 + wm * 64, n0 + wn * 64, lane);
+  else
+    EP::template run<2, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, 0);
 #endif
 }
 
-template <int BM, int BN, int S, int MODE, class EP>
+// EpBf16Acc for rows in parity-class order: row -> pixel (im, h0 + 2i, w0 + 2j) of the class, then the same
+// "request the 16 old values of a 32x32 tile together" accumulate as EpBf16Acc.
+template <int TM, int TN>
+__device__ __forceinline__ void ep_acc_s2(const IG2Params& q, int cls, f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane) {
+  const GemmParams& p = q.gp;
+  uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
+  const int rows = q.rows[cls], nwc = q.nw[cls], nhc = q.nh[cls], h0 = q.h0[cls], w0 = q.w0[cls];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    long off[16];
+    bool okr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ml = mbase + tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+      okr[i] = ml < rows;
+      const int mm = okr[i] ? ml : 0, t = mm / nwc, im = t / nhc;
+      off[i] = ((long)(im * p.g.H + h0 + 2 * (t - im * nhc)) * p.g.W + (w0 + 2 * (mm - t * nwc))) * p.ldc;
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = nbase + tn * 32 + (lane & 31);
+      const bool cok = col < p.N;
+      if (!p.accumulate) {  // (workgroup-uniform)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (okr[i] && cok) C[off[i] + col] = (uint16_t)f2bf(acc[tm][tn][i]);
+      } else {
+        uint16_t old[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) old[i] = C[(okr[i] && cok) ? off[i] + col : 0L];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (okr[i] && cok) C[off[i] + col] = (uint16_t)f2bf(acc[tm][tn][i] + bf2f(old[i]));
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int S, int MODE, class EP, bool S2 = false>
 int launch_one(IG2Params& q, hipStream_t st) {
   constexpr int NTHREADS = (BM / 64) * (BN / 64) * 64;
   constexpr int LDS = S * (BM * 128 + BN * 128);
-  q.mtiles = dtf_cdiv(q.gp.M, BM);
+  if (!S2) q.mtiles = dtf_cdiv(q.gp.M, BM);  // (S2: the caller has laid out the classes in tiles of BM rows)
   q.ntiles = dtf_cdiv(q.gp.N, BN);
   const int mt8 = (q.mtiles + 7) / 8 * 8;
-  hipLaunchKernelGGL((igemm2_kernel<BM, BN, S, MODE, EP>), dim3(mt8 * q.ntiles), dim3(NTHREADS), LDS, st, q);
+  hipLaunchKernelGGL((igemm2_kernel<BM, BN, S, MODE, EP, S2>), dim3(mt8 * q.ntiles), dim3(NTHREADS), LDS, st, q);
   DTF_CHECK_LAUNCH();
   return 0;
 }
 
 // variant bit 0: 128-row tiles (3 stages at BN = 64, 2 at BN = 128: two workgroups per CU) instead of 256-row tiles;
 // variant bit 1: 64-column tiles even when N > 64 (N = 160 or 192 fills 64-wide tiles far better than 128-wide ones)
+// variant bit 2 (backward-data of stride-2 layers only): rows by parity class, see IG2Params / dtf_conv_bwd_data_v2
 template <int BN, int MODE, class EP>
 int launch_igemm2(IG2Params& q, int variant, hipStream_t st) {
   if (variant & 1) return launch_one<128, BN, (BN == 64 ? 3 : 2), MODE, EP>(q, st);
@@ -215,9 +291,9 @@ int launch_igemm2_n(IG2Params& q, int variant, hipStream_t st) {
   return launch_igemm2<64, MODE, EP>(q, variant, st);
 }
 
-template <int BM, int BN, int S, int MODE, class EP>
+template <int BM, int BN, int S, int MODE, class EP, bool S2 = false>
 bool raise_one() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, S, MODE, EP>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, S, MODE, EP, S2>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, S * (BM * 128 + BN * 128)) == hipSuccess;
 }
 template <int BN, int MODE, class EP>
@@ -253,7 +329,9 @@ DTF_API int dtf_igemm2_init() {
   if (!g_ready) {
     if (!raise_lds_limit<64, 0, EpBf16Stats>() || !raise_lds_limit<128, 0, EpBf16Stats>() ||
         !raise_lds_limit<64, 0, EpBiasReluBf16>() || !raise_lds_limit<128, 0, EpBiasReluBf16>() ||
-        !raise_lds_limit<64, 1, EpBf16Acc>() || !raise_lds_limit<128, 1, EpBf16Acc>())
+        !raise_lds_limit<64, 1, EpBf16Acc>() || !raise_lds_limit<128, 1, EpBf16Acc>() ||
+        !raise_one<128, 64, 3, 1, EpBf16Acc, true>() || !raise_one<128, 128, 2, 1, EpBf16Acc, true>() ||
+        !raise_one<256, 64, 3, 1, EpBf16Acc, true>() || !raise_one<256, 128, 3, 1, EpBf16Acc, true>())
       return -3;
     g_ready = true;
   }
@@ -291,6 +369,34 @@ DTF_API int dtf_conv_bwd_data_v2(const void* dz, const void* Wq, void* dx, int B
   const int rc = fill(q, dz, Wq, dx, B * H * W, Cin, KH * KW * Cout, dx_cstride, H, W, Cout, Cout, Ho, Wo, KH, KW, stride, pad_h, pad_w);
   if (rc) return rc;
   q.gp.accumulate = accumulate;
+  if (variant & 4) {  // stride-2 layers by parity class (bits 0 and 1 pick the tile as for the other variants)
+    const int S2_BM = (variant & 1) ? 128 : 256;
+    const int K = KH * KW * Cout, nsteps = dtf_cdiv(K, 64);
+    if (stride != 2 || variant > 7 || nsteps > 64) return ERR_SHAPE;
+    int t0 = 0;
+    for (int c = 0; c < 4; ++c) {
+      const int ph = c >> 1, pw = c & 1;
+      q.h0[c] = (ph + pad_h) & 1;
+      q.w0[c] = (pw + pad_w) & 1;
+      q.nh[c] = q.h0[c] < H ? (H - q.h0[c] + 1) / 2 : 0;
+      q.nw[c] = q.w0[c] < W ? (W - q.w0[c] + 1) / 2 : 0;
+      q.rows[c] = B * q.nh[c] * q.nw[c];
+      q.tile0[c] = t0;
+      t0 += dtf_cdiv(q.rows[c], S2_BM);
+      unsigned long long mask = 0ull;
+      for (int t = 0; t < nsteps; ++t) {
+        const int k_hi = (t * 64 + 64 < K ? t * 64 + 64 : K) - 1;
+        for (int tap = t * 64 / Cout; tap <= k_hi / Cout; ++tap)
+          if (((tap / KW) & 1) == ph && ((tap % KW) & 1) == pw) mask |= 1ull << t;
+      }
+      q.smask[c] = mask;
+    }
+    q.mtiles = t0;
+    const bool wide = q.gp.N > 64 && !(variant & 2);
+    if (variant & 1)
+      return wide ? launch_one<128, 128, 2, 1, EpBf16Acc, true>(q, st) : launch_one<128, 64, 3, 1, EpBf16Acc, true>(q, st);
+    return wide ? launch_one<256, 128, 3, 1, EpBf16Acc, true>(q, st) : launch_one<256, 64, 3, 1, EpBf16Acc, true>(q, st);
+  }
   return launch_igemm2_n<1, EpBf16Acc>(q, variant, st);
 }
 

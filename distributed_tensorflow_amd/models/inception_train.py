@@ -359,7 +359,9 @@ class InceptionTrainer:
             res["dw"] = {c: timed(lambda c=c: self._conv_dw(op, src, c, st))
                          for c in ((1, 2, 3) if (s_.cin > 64 and s_.cout > 64) else (1, 2))}
             if op.src != "input":
-                res["bwd"] = {c: timed(lambda c=c: self._conv_bwd_data(op, src, c, 0, st)) for c in (1,) + wide_k}
+                # (6..9 = the stride-2 layers by parity class: igemm2.hip variant bit 2 on top of the tile bits)
+                by_class = ((6, 7, 8, 9) if s_.cin > 64 else (6, 7)) if s_.stride == 2 else ()
+                res["bwd"] = {c: timed(lambda c=c: self._conv_bwd_data(op, src, c, 0, st)) for c in (1,) + wide_k + by_class}
             self.tuning[name] = res
             for k, ts in res.items():
                 best = min(ts, key=ts.get)

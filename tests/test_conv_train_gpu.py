@@ -79,7 +79,8 @@ def test_conv_forward_stats_backward_data_and_filter(geom):
         assert _relerr(dW, gw.permute(2, 3, 1, 0)) < 5e-3, splits
 
 
-@pytest.mark.parametrize("geom", GEOMS + [(71, 71, 80, 192, 3, 3, 1, 0, 0), (35, 35, 96, 96, 3, 3, 1, 1, 1)])
+@pytest.mark.parametrize("geom", GEOMS + [(71, 71, 80, 192, 3, 3, 1, 0, 0), (35, 35, 96, 96, 3, 3, 1, 1, 1), (17, 18, 64, 96, 3, 3, 2, 1, 1),
+                                          (12, 9, 72, 40, 1, 3, 2, 0, 1)])
 def test_async_lds_igemm_matches_reference(geom):
     """Second-generation implicit GEMM (global_load_lds ring, csrc/hip/igemm2.hip): forward + stats, inference epilogue,
     backward-data (store and accumulate) against PyTorch on the same bf16 operands."""
@@ -132,7 +133,10 @@ def test_async_lds_igemm_matches_reference(geom):
                                Ho, Wo, splits, variant, _st()), "dw2")
         assert _relerr(dW, gw.permute(2, 3, 1, 0)) < 5e-3, (splits, variant)
     (gx,) = torch.autograd.grad(ref, x, dz.float().permute(0, 3, 1, 2))
-    for variant in (0, 1, 2, 3):
+    # (4..7 = the stride-2 data gradient by parity class; refused for stride 1)
+    assert s == 2 or lib.dtf_conv_bwd_data_v2(dz.data_ptr(), Wq.data_ptr(), xfull.data_ptr(), B, H, W, Cin, Ctot, Cout, KH, KW,
+                                              s, ph, pw, Ho, Wo, 0, 4, _st()) == -22
+    for variant in (0, 1, 2, 3) + ((4, 5, 6, 7) if s == 2 else ()):
         dxfull = torch.full((B, H, W, Ctot), 7.0, dtype=BF, device="cuda")
         for acc in (0, 1):
             chk(lib.dtf_conv_bwd_data_v2(dz.data_ptr(), Wq.data_ptr(), dxfull.data_ptr() + 2 * 8, B, H, W, Cin, Ctot, Cout, KH, KW,
@@ -237,7 +241,7 @@ def _l2err(a, b):
 
 def test_every_conv_core_variant_agrees_on_every_layer():
     """The autotuner picks a conv core per layer and pass from timings, so WHICH kernel variant runs a layer differs from
-    run to run: here every variant it may pick (forward 1..5, filter gradient 1..3, data gradient 1..5 with and without
+    run to run: here every variant it may pick (forward 1..5, filter gradient 1..3, data gradient 1..5, and 6..9 on the stride-2 layers, with and without
     accumulation) runs every one of the 94 layer geometries at batch 4 and must agree with core 1."""
     from distributed_tensorflow_amd.models.inception_train import InceptionTrainer
     torch.manual_seed(1)
@@ -293,7 +297,7 @@ def test_every_conv_core_variant_agrees_on_every_layer():
         base = torch.randn(dx.shape, device="cuda").to(BF)
         for acc in (0, 1):
             ref = None
-            for c in (1,) + wide_k:
+            for c in (1,) + wide_k + ((6, 7, 8, 9) if s.stride == 2 else ()):
                 dx.copy_(base)
                 tr._conv_bwd_data(op, src, c, acc, st)
                 got = dx[..., :s.cin].float().clone() if dx.shape[-1] != s.cin else dx.float().clone()
