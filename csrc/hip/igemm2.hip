@@ -372,7 +372,8 @@ DTF_API int dtf_conv_bwd_data_v2(const void* dz, const void* Wq, void* dx, int B
   if (variant & 4) {  // stride-2 layers by parity class (bits 0 and 1 pick the tile as for the other variants)
     const int S2_BM = (variant & 1) ? 128 : 256;
     const int K = KH * KW * Cout, nsteps = dtf_cdiv(K, 64);
-    if (stride != 2 || variant > 7 || nsteps > 64) return ERR_SHAPE;
+    if (stride != 2 || variant > 7) return ERR_SHAPE;
+    if (nsteps > 64) return launch_igemm2_n<1, EpBf16Acc>(q, variant & 3, st);  // (one 64-bit step mask per class: pixel order)
     int t0 = 0;
     for (int c = 0; c < 4; ++c) {
       const int ph = c >> 1, pw = c & 1;

@@ -80,7 +80,7 @@ def test_conv_forward_stats_backward_data_and_filter(geom):
 
 
 @pytest.mark.parametrize("geom", GEOMS + [(71, 71, 80, 192, 3, 3, 1, 0, 0), (35, 35, 96, 96, 3, 3, 1, 1, 1), (17, 18, 64, 96, 3, 3, 2, 1, 1),
-                                          (12, 9, 72, 40, 1, 3, 2, 0, 1)])
+                                          (12, 9, 72, 40, 1, 3, 2, 0, 1), (9, 9, 64, 520, 3, 3, 2, 0, 0)])  # (last: > 64 K-steps)
 def test_async_lds_igemm_matches_reference(geom):
     """Second-generation implicit GEMM (global_load_lds ring, csrc/hip/igemm2.hip): forward + stats, inference epilogue,
     backward-data (store and accumulate) against PyTorch on the same bf16 operands."""
