@@ -39,7 +39,6 @@ for run in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
     for op in tr.graph.ops:
         if op.kind == "conv":
             n = op.conv.name + "/conv2d_params"
-            o, sz = tr.layout.entries[n][0], tr.layout.view(tr.P, n).numel()
             per.append((l2(tr.layout.view(snap["G"], n), tr.layout.view(ref["G"], n)), op.conv.name))
     worst["dW"] = max(per, key=lambda t: t[0])
     print("run %d vs run 0:" % run, {k: ("%.2e" % v[0], v[1]) for k, v in worst.items()}, flush=True)
