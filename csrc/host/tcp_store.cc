@@ -84,7 +84,7 @@ struct Server {
         auto pred = [&] { return stop.load() || kv.count(key) > 0; };
         bool ok = true;
         if (timeout_ms < 0) cv.wait(l, pred);
-        else ok = cv.wait_until(l, std::chrono::system_clock::now() + std::chrono::milliseconds(timeout_ms), pred);
+        else ok = dtf::cv_wait_ms(cv, l, timeout_ms, pred);  // steady clock (system clock only under TSan, dtf_host.h)
         if (ok && kv.count(key)) { payload = kv[key]; status = (int64_t)payload.size(); }
         else status = -1;
       } else if (op == 3) {

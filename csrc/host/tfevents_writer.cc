@@ -63,9 +63,7 @@ struct EventsWriter {
   void loop() {
     std::unique_lock<std::mutex> l(mu);
     while (!stop) {
-      // (wait_until on the system clock = pthread_cond_timedwait, which the ThreadSanitizer runtime of this toolchain
-      // models; wait_for's pthread_cond_clockwait is invisible to it and yields false "double lock" reports)
-      cv.wait_until(l, std::chrono::system_clock::now() + std::chrono::milliseconds(2000));
+      dtf::cv_wait_ms(cv, l, 2000);  // steady clock (system clock only under TSan, dtf_host.h)
       l.unlock();
       drain(true);
       l.lock();

@@ -59,7 +59,7 @@ def run(FLAGS, distributed: bool) -> int:
     from ..engine.mnist_engine import make_engine
     from ..parallel import cluster as cl
     from ..parallel.ddp import DataParallelTrainer, init_process_group
-    from ..parallel.supervisor import Supervisor
+    from ..parallel.supervisor import ConsistencyError, Supervisor
     from ..utils import checkpoint as ckpt
     from ..utils.summary import FileWriter, Summary, variable_summaries
 
@@ -155,6 +155,8 @@ def run(FLAGS, distributed: bool) -> int:
             if FLAGS.fault_inject_step > step:
                 burst = min(burst, FLAGS.fault_inject_step - step)
             burst = max(1, burst)
+            if sv is not None:
+                burst = sv.steps_allowed(step, burst)  # (an agreed stop step is not overshot)
             with phase("train steps (launch)"):
                 trainer.train_steps(burst)
             if timer is not None:
@@ -181,7 +183,7 @@ def run(FLAGS, distributed: bool) -> int:
                         train_acc = float("nan")
                 _log(rank, "Iter " + str(last) + ", test_acc: " + str(test_acc) + ", train_acc = " + str(train_acc))
                 if FLAGS.check_replicas and not trainer.replicas_in_sync():
-                    raise RuntimeError("replica parameter checksums diverged at step %d" % last)
+                    raise ConsistencyError("replica parameter checksums diverged at step %d" % last)
                 if FLAGS.check_replicas and world > 1 and step < FLAGS.training_steps - 2:
                     # one checked step: what the optimizer consumed vs. the host-ordered sum of the local gradients
                     dev = trainer.check_exchange()
@@ -216,7 +218,8 @@ def run(FLAGS, distributed: bool) -> int:
         if sv is not None:
             # the chief saves whenever it is still alive — its loop ended through should_stop(), or its collective was
             # torn down under it by a peer that failed: parameters only change after a completed gradient exchange, so
-            # its state is that of the last completed step (tf.train.Supervisor's chief saves on stop the same way)
+            # its state is that of the last completed step (tf.train.Supervisor's chief saves on stop the same way).
+            # Not after its OWN consistency / kernel error: Supervisor.stop() skips the save then (state_is_suspect).
             sv.stop(final_save=True)
         elif rank == 0:
             path = ckpt.Saver(engine, with_global_step=False).save(FLAGS.checkpoint_path)

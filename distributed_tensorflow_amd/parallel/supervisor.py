@@ -23,8 +23,16 @@ Equivalent behaviour here:
   for ``2 x period`` turns into a stop request on every survivor.  ``should_stop()`` then only reads
   a local flag — no collective, so a rank that died cannot wedge it.  A survivor that is itself
   blocked inside a collective on the dead rank (RCCL has no per-call timeout) cannot poll anything:
-  if the training thread has not acknowledged a failure stop within ``fatal_grace_s`` the monitor
-  ends the process with exit status 70, and the relaunched job resumes from the last checkpoint;
+  if the training thread has not DRAINED (stream synchronised, final checkpoint written) within
+  ``fatal_grace_s`` of the stop the monitor ends the process with exit status 70, and the relaunched
+  job resumes from the last checkpoint.  Seeing the flag is not enough to disarm that watchdog:
+  a survivor that has already enqueued collectives its peer never joins blocks in its NEXT stream
+  sync (summary flush, final save), after ``should_stop()`` has returned True;
+* a stop that nobody died for (``request_stop()`` without an exception, a signal, the step budget
+  of a peer) is AGREED: every rank publishes ``its step + stop_margin_steps`` under
+  ``sv/vote/<rank>`` when it first sees the flag and keeps training to the maximum of the votes, so
+  all ranks enqueue the same number of collectives and every one of them drains.  A rank that
+  failed publishes a negative vote instead, and the survivors leave at once (watchdog armed);
 * without a store (single process, or a launcher that has none) the local flag is all-reduced (max)
   every ``stop_check_interval`` STEPS;
 * ``--fault_inject_step`` support lives in the training drivers and is exercised by the tests.
@@ -40,11 +48,26 @@ from typing import Callable, Optional
 from ..utils import checkpoint as ckpt
 
 
+class ConsistencyError(RuntimeError):
+    """A check of the replicas' state failed on this rank (checksums diverged, non-finite loss ...)."""
+
+
+def state_is_suspect(ex: Optional[BaseException]) -> bool:
+    """Whether a rank that left its loop on ``ex`` may still checkpoint.  A peer's failure, a stop request and a transport
+    error leave the parameters at the last completed step (they only change after a completed exchange); a failed
+    consistency check, an assertion of the exchange check, a native kernel error or a floating-point error do not."""
+    if ex is None:
+        return False
+    from ..native import NativeError
+    return isinstance(ex, (ConsistencyError, AssertionError, NativeError, FloatingPointError, ArithmeticError))
+
+
 class Supervisor:
     def __init__(self, trainer, *, is_chief: bool, logdir: Optional[str], saver: Optional[ckpt.Saver] = None,
                  save_model_secs: float = 600.0, checkpoint_basename: str = "model.ckpt",
                  stop_check_interval: int = 50, summary_writer=None, log_fn: Callable[[str], None] = print,
-                 store=None, heartbeat_period_s: float = 1.0, fatal_grace_s: float = 20.0):
+                 store=None, heartbeat_period_s: float = 1.0, fatal_grace_s: float = 20.0,
+                 stop_margin_steps: int = 64):
         self.trainer = trainer
         self.engine = trainer.engine
         self.is_chief = is_chief
@@ -73,8 +96,12 @@ class Supervisor:
         self.stop_reason: Optional[str] = None
         self._monitor_thread: Optional[threading.Thread] = None
         self._failure_seen_at: Optional[float] = None
-        self._acknowledged = False
+        self._acknowledged = False  # True once this rank has drained (nothing left that could block on a peer)
         self._stop_key = "sv/stop"
+        # agreed stop step (graceful stops only)
+        self.stop_margin_steps = max(1, stop_margin_steps)
+        self._vote: Optional[int] = None
+        self.stop_at: Optional[int] = None
 
     # ------------------------------------------------------------------ init / restore
     def prepare_or_wait_for_session(self) -> int:
@@ -178,20 +205,68 @@ class Supervisor:
         self._stop_local.set()
         if self.store is not None:
             try:
+                if ex is not None and self.trainer.world > 1:
+                    # this rank leaves its loop NOW: the peers must not wait for it at an agreed step
+                    self._vote = -1
+                    self.store.set("sv/vote/%d" % getattr(self.trainer, "rank", 0), b"-1")
                 self.store.add(self._stop_key, 1)  # out of band: the peers learn of it without a collective
             except ConnectionError:
                 pass
 
+    def _read_votes(self):
+        """Votes of all ranks, or None while one is missing.  A negative vote = that rank failed."""
+        votes = []
+        for r in range(self.trainer.world):
+            v = self.store.get("sv/vote/%d" % r, timeout_s=0.0)
+            if v is None:
+                return None
+            votes.append(int(v.decode()))
+        return votes
+
+    def _agree_stop_step(self, step: int) -> bool:
+        """The flag is up and nobody is known to have failed: vote, then train on to the maximum of the votes.  Returns
+        True when this rank has to leave its loop now."""
+        rank = getattr(self.trainer, "rank", 0)
+        if self._vote is None:
+            self._vote = step + self.stop_margin_steps
+            self.store.set("sv/vote/%d" % rank, str(self._vote).encode())
+        t0 = time.time()
+        while self.stop_at is None:
+            votes = None if self.dead_ranks else self._read_votes()
+            if self.dead_ranks or (votes is not None and min(votes) < 0):
+                return True  # someone is gone: no agreement possible, leave (the watchdog stays armed until drained)
+            if votes is not None:
+                self.stop_at = max(votes)
+            elif step < self._vote:
+                return False  # keep training below the own vote; look again at the next call
+            elif time.time() - t0 > max(1.0, self.fatal_grace_s):
+                return True  # a peer never voted (it is blocked or gone): same as a failure
+            else:
+                time.sleep(min(0.05, self.heartbeat_period_s / 4.0))
+        return step >= self.stop_at
+
+    def steps_allowed(self, step: int, want: int) -> int:
+        """How many of ``want`` steps a driver that launches several steps at once may still enqueue (an agreed stop
+        step must not be overshot; while the votes are still coming in the own vote is the limit)."""
+        limit = self.stop_at if self.stop_at is not None else self._vote
+        if limit is None or limit < 0:
+            return want
+        return max(1, min(want, limit - step))
+
     def should_stop(self, force_check: bool = False, steps: int = 1) -> bool:
-        """With a rendezvous store: reads the local flag the monitor thread maintains (no communication).  Without:
-        collective — every rank calls it at the same points — and the flag is all-reduced every
-        ``stop_check_interval`` STEPS (``steps`` = steps run since the previous call)."""
+        """With a rendezvous store: reads the local flag the monitor thread maintains and, for a stop nobody failed
+        for, the peers' votes from the store (no collective either way).  Without: collective — every rank calls it at
+        the same points — and the flag is all-reduced every ``stop_check_interval`` STEPS (``steps`` = steps run since
+        the previous call).  Returning True does NOT disarm the watchdog: only a completed drain (``stop()``) does."""
         if self._stop_global:
-            self._acknowledged = True
             return True
         if self.store is not None and self.trainer.world > 1:
             if self._stop_local.is_set():
-                self._stop_global = self._acknowledged = True
+                try:
+                    failed = self.last_exception is not None or bool(self.dead_ranks) or (self._vote is not None and self._vote < 0)
+                    self._stop_global = True if failed else self._agree_stop_step(self.engine.global_step)
+                except ConnectionError:
+                    self._stop_global = True
             return self._stop_global
         self._steps_since_check += max(1, steps)
         if force_check or self._steps_since_check >= self.stop_check_interval or self.trainer.world == 1:
@@ -199,10 +274,30 @@ class Supervisor:
             self._stop_global = self.trainer.any_rank(self._stop_local.is_set())
         return self._stop_global
 
+    def _drain(self) -> None:
+        """Wait for everything this rank has enqueued.  Unbounded by itself (RCCL has no per-call timeout): while it
+        blocks the watchdog is still armed and ends the process with status 70 after ``fatal_grace_s``."""
+        sync = getattr(self.trainer, "synchronize", None)
+        if sync is not None:
+            sync()
+        elif hasattr(self.engine, "stream"):
+            self.engine.stream.synchronize()
+
     def stop(self, final_save: bool = True) -> None:
-        """``sv.stop()``: stop services, final save on the chief, barrier."""
-        self._acknowledged = True
+        """``sv.stop()``: drain, final save on the chief, then stop the services.  The monitor (and with it the exit-70
+        watchdog) lives until the save is done: both the drain and ``state_dict()`` synchronise the stream, and a peer
+        that left its loop earlier never joins the collectives enqueued there."""
         self._stop_local.set()
+        self._drain()
+        if final_save and self.is_chief and state_is_suspect(self.last_exception):
+            # the relaunch must not restore a state that is known to be wrong: it resumes from the last autosave instead
+            self.log("Supervisor: no final checkpoint, this rank stopped on %r and its state is suspect" % (self.last_exception,))
+        elif final_save:
+            try:
+                self._save("final")
+            except Exception as e:
+                self.log("Supervisor: final save failed: %r" % (e,))
+        self._acknowledged = True  # nothing below can block on a peer
         self._saver_wake.set()
         if self._saver_thread is not None:
             self._saver_thread.join(timeout=30)
@@ -220,11 +315,6 @@ class Supervisor:
                     self.store.wait_counter("sv/done", self.trainer.world, timeout_s=30.0)
             except ConnectionError:
                 pass
-        if final_save:
-            try:
-                self._save("final")
-            except Exception as e:
-                self.log("Supervisor: final save failed: %r" % (e,))
         if self.summary_writer is not None:
             self.summary_writer.flush()
 

@@ -114,3 +114,93 @@ def test_rank_blocked_on_a_dead_peer_exits_nonzero(tmp_path):
     r = subprocess.run([sys.executable, str(script), REPO], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
     assert r.returncode == 70, (r.returncode, r.stdout[-2000:])
     assert "NOT REACHED" not in r.stdout and "stopped sending heartbeats" in r.stdout and time.time() - t0 < 20
+
+
+_BLOCKED_AFTER_STOP = r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+from distributed_tensorflow_amd.parallel.cluster import StoreClient, StoreServer
+from distributed_tensorflow_amd.parallel.supervisor import Supervisor
+class E: global_step = 0
+class T:
+    def __init__(s, r): s.engine, s.rank, s.world = E(), r, 2
+    def broadcast_state(s, src=0): pass
+    def synchronize(s):
+        print("draining", flush=True)
+        time.sleep(30)                  # the stream sync behind collectives the dead peer never joins
+server = StoreServer(0)
+peer = StoreClient("127.0.0.1", server.port)
+sv = Supervisor(T(0), is_chief=True, logdir=None, save_model_secs=0, store=StoreClient("127.0.0.1", server.port),
+                heartbeat_period_s=0.1, fatal_grace_s=0.5)
+sv.start_standard_services()
+for _ in range(5):
+    peer.add("hb/1", 1); time.sleep(0.1)
+t0 = time.time()
+while not sv.should_stop():             # this rank SEES the stop (the peer's heartbeat stopped) ...
+    time.sleep(0.01); assert time.time() - t0 < 10
+print("saw the stop", flush=True)
+sv.stop(final_save=True)                # ... and then blocks while draining: the watchdog must still be armed
+print("NOT REACHED", flush=True)
+"""
+
+
+def test_rank_that_saw_the_stop_and_then_blocks_in_its_drain_still_exits_70(tmp_path):
+    """should_stop() returning True must not disarm the exit-70 watchdog."""
+    script = tmp_path / "blocked2.py"
+    script.write_text(_BLOCKED_AFTER_STOP)
+    r = subprocess.run([sys.executable, str(script), REPO], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
+    assert r.returncode == 70, (r.returncode, r.stdout[-2000:])
+    assert "saw the stop" in r.stdout and "draining" in r.stdout and "NOT REACHED" not in r.stdout
+
+
+def test_graceful_stop_is_agreed_on_one_step():
+    """A stop nobody died for: the ranks see the flag at different steps and still leave at the same one (every rank
+    enqueues the same number of collectives, so every drain completes)."""
+    import threading
+    server, (sv0, sv1) = _pair(0.1)
+    for sv in (sv0, sv1):
+        sv.stop_margin_steps = 8
+    left = {}
+
+    def loop(sv, rank, dt):
+        while not sv.should_stop():
+            n = sv.steps_allowed(sv.engine.global_step, 3)   # (a driver that launches several steps at once)
+            sv.engine.global_step += n
+            time.sleep(dt)
+        left[rank] = sv.engine.global_step
+
+    sv0.trainer.engine, sv1.trainer.engine = sv0.engine, sv1.engine
+    sv1.engine.global_step = 5                                # rank 1 runs ahead and at another pace
+    ths = [threading.Thread(target=loop, args=(sv0, 0, 0.004)), threading.Thread(target=loop, args=(sv1, 1, 0.007))]
+    for t in ths:
+        t.start()
+    time.sleep(0.3)
+    sv0.request_stop()                                        # no exception: a plain stop request
+    for t in ths:
+        t.join(timeout=20)
+    assert not any(t.is_alive() for t in ths)
+    assert left[0] == left[1] == sv0.stop_at == sv1.stop_at, (left, sv0.stop_at, sv1.stop_at)
+    sv1.stop(final_save=False)
+    sv0.stop(final_save=False)
+    server.stop()
+
+
+def test_chief_does_not_checkpoint_after_its_own_consistency_error(tmp_path):
+    from distributed_tensorflow_amd.parallel.supervisor import ConsistencyError, Supervisor, state_is_suspect
+    assert state_is_suspect(ConsistencyError("x")) and state_is_suspect(AssertionError()) and not state_is_suspect(None)
+    assert not state_is_suspect(ConnectionError("peer closed")) and not state_is_suspect(RuntimeError("gloo: connection reset"))
+    saved, said = [], []
+
+    class _Saver:
+        def save(self, path, global_step=0):
+            saved.append(path)
+            return path
+
+    sv = Supervisor(_Trainer(0, 1), is_chief=True, logdir=str(tmp_path), saver=_Saver(), save_model_secs=0, log_fn=said.append)
+    sv.request_stop(ConsistencyError("replica parameter checksums diverged at step 7"))
+    sv.stop(final_save=True)
+    assert not saved and any("suspect" in m for m in said)
+    sv = Supervisor(_Trainer(0, 1), is_chief=True, logdir=str(tmp_path), saver=_Saver(), save_model_secs=0, log_fn=said.append)
+    sv.request_stop(ConnectionError("peer went away"))
+    sv.stop(final_save=True)
+    assert len(saved) == 1
