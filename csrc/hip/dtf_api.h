@@ -4,6 +4,7 @@
 
 struct HeadParams;
 struct OptimParams;
+struct ShardPush;
 
 DTF_API int dtf_fc_fwd(const void* X, int x_is_f32, const float* W, float* out, int M, int N, int K, int splits,
                        const float* bias, int relu, hipStream_t st);
@@ -79,3 +80,17 @@ DTF_API int dtf_conv_dw_duo_f32(const float* dpool2, const float* pool2, const v
                                 float* db2, int B, const float* images, const int* perm, const int* step_ptr, int spe,
                                 const float* dpool1, const void* amax1, float* dW1, float* db1, const struct OptimParams* adam,
                                 hipStream_t st);
+
+// ---- "shard" data parallelism (shard_body.h): per-rank work independent of the number of ranks
+DTF_API int dtf_conv2_bwd_data_f32_push(const float* dpool2, const float* pool2, const void* amax2, const float* W,
+                                        const float* pool1, float* dpool1, int B, const struct OptimParams* adam,
+                                        const struct ShardPush* push, hipStream_t st);
+DTF_API int dtf_fc_bwd_trio_f32_shard(const float* X1, const float* dY1, int ldy1, float* dW1, int M1, int N1, int K,
+                                      const float* dYq, const float* Wq, float* dXq, int Mq, int Nq, int Kq, int splits,
+                                      const void* const* gA, const void* const* gB, int granks, int ranks_per_set, int lda0,
+                                      float* dW0_slice, int M0_slice, int N0, hipStream_t st);
+DTF_API int dtf_ipc_sync_gather_slice(const void* comm, void* dst, long bytes, int rows, int pitch4, int lo4, int w4,
+                                      long tail_off4, long tail_n4, int blocks_per_peer, hipStream_t st);
+DTF_API int dtf_ipc_shard_desc(const void* comm, long lo_floats, long n_floats, float* src, int zero_src,
+                               struct ShardPush* push);
+DTF_API const float* dtf_ipc_landing(const void* comm);

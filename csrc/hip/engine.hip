@@ -11,6 +11,7 @@
 //   apply : multi-tensor TF-Adam over the flat arena (also zeroes the atomically accumulated grads)
 #include "dtf_api.h"
 #include "dtf_structs.h"
+#include "shard_body.h"
 
 struct MnistEngine {
   int B, maxB, spe, world, double_softmax, fc1_splits, bwd_splits, dw2_splits, head_blocks, ring;
@@ -49,7 +50,15 @@ struct MnistEngine {
   int f32;
   // device words [skip flag, skipped-step count] shared with the IPC gradient exchange (OptimParams::skip); may be null
   unsigned* skip;
+  // data-parallel "shard" schedule (shard_body.h; shard_n = world size, 0 = off; fp32 only; rides on the gather fields for the
+  // operand exchange): this rank computes rows [shard_lo, shard_lo + shard_w) of the GLOBAL fc1 filter gradient and pushes
+  // them into every rank's landing buffer (the result buffers of the IpcComm at shard_comm), where W_fc1's Adam update reads
+  const void* shard_comm;
+  int shard_n, shard_lo, shard_w;
 };
+
+// "shard" schedule: source ranks per K set of the slice GEMM (one set: plain stores; more: atomics into the zeroed slice)
+static constexpr int SHARD_RANKS_PER_SET = 2;
 
 #define DTF_TRY(x)            \
   do {                        \
@@ -103,11 +112,16 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
     loc.pool2 = const_cast<void*>(loc.gather_A[loc.gather_rank]);
     loc.dh = const_cast<void*>(loc.gather_B[loc.gather_rank]);
   }
+  const bool shard = loc.shard_n > 0;
+  if (shard && (!loc.f32 || loc.shard_n != loc.gather_n || !loc.shard_comm || loc.shard_lo < 0 || loc.shard_w <= 0 ||
+                loc.shard_lo % 4 || loc.shard_w % 4 || loc.shard_lo + loc.shard_w > 3136 || loc.G_fc1_dst || loc.G_src))
+    return -22;
   // parts bit 2 (value 4): W_fc1's Adam update rides along with the conv filter-gradient launch at the end of part 2 (its
   // gradient is final after part 1 and W_fc1 has been read by then); the caller finishes with dtf_mnist_apply_part(e, 2).
   // Only where this rank's fc1 gradient is the GLOBAL one: a single replica, or the gather schedule.
   const bool early_adam = (parts & 4) != 0;
   parts &= 3;
+  if (shard && (parts & 2) && !early_adam) return -22;  // (the landing buffer is read by the hosted W_fc1 update only)
   if (early_adam && ((e->world > 1 && e->gather_n == 0) || e->G_fc1_dst || e->G_src || e->off_Wfc1 != 0 || e->off_bfc1 % 4))
     return -22;
   if (e->G_fc1_dst && e->off_Wfc1 != 0) return -22;
@@ -149,11 +163,23 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
       // this rank's fc1 operands (pool2 [B,3136], dh [B,1024] in the compute dtype) are complete: tell the peers, wait for
       // theirs, and pull theirs into local memory (one pass over each xGMI link)
       if (e->gather_bytes != (long)B * (3136 + 1024) * (e->f32 ? 4 : 2) || !e->gather_local) return -22;
-      DTF_TRY(dtf_ipc_sync_gather(e->gather_comm, e->gather_local, e->gather_bytes, 16, st));
+      if (shard)  // only the columns of pool2 this rank's gradient slice needs, and dh
+        DTF_TRY(dtf_ipc_sync_gather_slice(e->gather_comm, e->gather_local, e->gather_bytes, B, 3136 / 4, e->shard_lo / 4,
+                                          e->shard_w / 4, (long)B * 784, (long)B * 256, 16, st));
+      else
+        DTF_TRY(dtf_ipc_sync_gather(e->gather_comm, e->gather_local, e->gather_bytes, 16, st));
     }
     if (e->f32) {
       const float* x2 = (const float*)e->pool2; const float* dh = (const float*)e->dh;
-      if (trio_ok(e)) {
+      if (shard) {
+        const void* gA[8];
+        for (int p = 0; p < 8; ++p)
+          gA[p] = p < e->gather_n ? (const void*)((const float*)e->gather_A[p] + e->shard_lo) : nullptr;
+        DTF_TRY(dtf_fc_bwd_trio_f32_shard((const float*)e->h_drop, (const float*)e->dz, 16, e->G + e->off_Wfc2, 1024, 10, B, dh,
+                                          e->P + e->off_Wfc1, e->dpool2, B, 3136, 1024, e->bwd_splits, gA, e->gather_B,
+                                          e->gather_n, SHARD_RANKS_PER_SET, 3136,
+                                          e->G + e->off_Wfc1 + (long)e->shard_lo * 1024, e->shard_w, 1024, st));
+      } else if (trio_ok(e)) {
         DTF_TRY(dtf_fc_bwd_trio_f32(x2, dh, dW_fc1, 3136, 1024, (const float*)e->h_drop, (const float*)e->dz, 16,
                                     e->G + e->off_Wfc2, 1024, 10, B, dh, e->P + e->off_Wfc1, e->dpool2, B, 3136, 1024,
                                     e->bwd_splits, e->gather_A, e->gather_B, gather ? e->gather_n : 0, st));
@@ -195,12 +221,20 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
     // W_fc1's Adam update rides in the filter-gradient launch.  (Measured alternative for fp32: in the data-gradient
     // launch, whose 245 workgroups leave 267 resident slots — that launch grows from 24.8 to 33.6 us while the
     // filter-gradient launch only shrinks from 34.8 to 29.4 us: the ~20 us of streaming needs the longer host.)
+    ShardPush push{};
+    if (shard) {
+      DTF_TRY(dtf_ipc_shard_desc(e->shard_comm, (long)e->shard_lo * 1024, (long)e->shard_w * 1024,
+                                 e->G + e->off_Wfc1 + (long)e->shard_lo * 1024, e->shard_n > SHARD_RANKS_PER_SET, &push));
+      fc1.Gsrc = dtf_ipc_landing(e->shard_comm);  // the assembled global gradient (the push below zeroes the slice in G)
+    }
     if (e->f32)
-      DTF_TRY(dtf_conv2_bwd_data_f32(e->dpool2, (const float*)e->pool2, e->amax2, e->P + e->off_Wc2, (const float*)e->pool1,
-                                     e->dpool1, B, nullptr, st));
+      DTF_TRY(dtf_conv2_bwd_data_f32_push(e->dpool2, (const float*)e->pool2, e->amax2, e->P + e->off_Wc2,
+                                          (const float*)e->pool1, e->dpool1, B, nullptr, shard ? &push : nullptr, st));
     else
       DTF_TRY(dtf_conv2_bwd_data_lds_packed(e->dpool2, e->pool2, e->amax2, e->wc2b, e->pool1, e->dpool1, e->G + e->off_bc2, B,
                                             st));
+    // shard schedule: every rank's slice has left with the launch above; one-wave barrier "mine has landed / all have landed"
+    if (shard) DTF_TRY(dtf_ipc_sync(e->shard_comm, st));
     if (e->f32)
       DTF_TRY(dtf_conv_dw_duo_f32(e->dpool2, (const float*)e->pool2, e->amax2, (const float*)e->pool1, e->G + e->off_Wc2,
                                   e->G + e->off_bc2, B,

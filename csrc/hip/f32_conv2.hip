@@ -17,6 +17,8 @@
 #include "common.h"
 #include "conv1_dw_body.h"
 #include "adam_body.h"
+#include "shard_body.h"
+#include "dtf_api.h"
 #include "f32_gemm.h"
 
 // -DDTF_CONV_STAMPS (diagnostic builds only, scripts/dbg): thread 0 of every workgroup records (shader clock, 100 MHz
@@ -447,6 +449,8 @@ struct ConvBwdData32 {
   int B, nbd;
   OptimParams adam;  // adam.n == 0: no optimizer workgroups
   int nadam;
+  ShardPush push;    // "shard" data parallelism (shard_body.h): this rank's slice of the fc1 filter gradient leaves for every
+  int npush;         // rank's landing buffer from npush trailing workgroups (link-bound: they only occupy resident slots)
 };
 
 __global__ __launch_bounds__(512) void conv2_bwd_data_f32_kernel(const ConvBwdData32 a) {
@@ -454,8 +458,10 @@ __global__ __launch_bounds__(512) void conv2_bwd_data_f32_kernel(const ConvBwdDa
   const int id = blockIdx.x;
   if (id < a.nbd)
     conv2_bwd_data_f32_body(smem32, id, a.dpool2, a.pool2, a.amax2, a.W, a.pool1, a.dpool1, a.B);
-  else
+  else if (id < a.nbd + a.nadam)
     adam_tf_body(a.adam, id - a.nbd, a.nadam, 512);
+  else
+    shard_push_body(a.push, id - a.nbd - a.nadam, a.npush, 512);
 }
 
 // ------------------------------------------------------------------ filter gradient
@@ -660,8 +666,16 @@ DTF_API int dtf_conv2_fwd_f32(const float* x, const float* W, const float* bias,
 
 DTF_API int dtf_conv2_bwd_data_f32(const float* dpool2, const float* pool2, const void* amax2, const float* W,
                                    const float* pool1, float* dpool1, int B, const OptimParams* adam, hipStream_t st) {
+  return dtf_conv2_bwd_data_f32_push(dpool2, pool2, amax2, W, pool1, dpool1, B, adam, nullptr, st);
+}
+
+DTF_API int dtf_conv2_bwd_data_f32_push(const float* dpool2, const float* pool2, const void* amax2, const float* W,
+                                        const float* pool1, float* dpool1, int B, const OptimParams* adam,
+                                        const ShardPush* push, hipStream_t st) {
   if (B <= 0) return ERR_SHAPE;
   if (adam && (adam->n <= 0 || adam->n % 4 || adam->zero_from % 4 || !adam->step)) return ERR_SHAPE;
+  if (push && (push->n4 <= 0 || !push->src || push->world < 1 || push->world > 8 || push->rank < 0 || push->rank >= push->world))
+    return ERR_SHAPE;
   if (!g_f32_attr_set) {
     const int rc = dtf_conv2_f32_init();
     if (rc) return rc;
@@ -676,7 +690,18 @@ DTF_API int dtf_conv2_bwd_data_f32(const float* dpool2, const float* pool2, cons
     a.adam.ticket = nullptr;  // (the step is advanced by the optimizer launch that covers the rest of the arena)
     a.nadam = 512 - a.nbd > 64 ? 512 - a.nbd : 64;
   }
-  hipLaunchKernelGGL(conv2_bwd_data_f32_kernel, dim3(a.nbd + a.nadam), dim3(512), BD_LDS, st, a);
+  a.push = ShardPush{};
+  a.npush = 0;
+  if (push) {
+    for (int p = 0; p < push->world; ++p)
+      if (!push->dst[p]) return ERR_SHAPE;
+    a.push = *push;
+    // 2048 float4 per workgroup and pass; never more workgroups than the resident slots the data-gradient role leaves
+    const long want = (push->n4 + 2047) / 2048;
+    const int room = 512 - a.nbd - a.nadam > 32 ? 512 - a.nbd - a.nadam : 32;
+    a.npush = (int)(want < room ? want : room);
+  }
+  hipLaunchKernelGGL(conv2_bwd_data_f32_kernel, dim3(a.nbd + a.nadam + a.npush), dim3(512), BD_LDS, st, a);
   DTF_CHECK_LAUNCH();
   return 0;
 }

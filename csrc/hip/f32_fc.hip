@@ -117,12 +117,17 @@ struct GemmTrio32 {
   // all-reduced afterwards; d0.K = granks * batch, d0.kseg = batch
   const float* gA[8];
   const float* gB[8];
+  int ksets;  // shard modes: K sets of problem 0 (see the kernel)
 };
 constexpr int TRIO32_LDS = dtf_gemm32_lds<112, 64, BdA, BdB>() > dtf_gemm32_lds<128, 64, DwA, DwB>()
                                ? dtf_gemm32_lds<112, 64, BdA, BdB>() : dtf_gemm32_lds<128, 64, DwA, DwB>();
 
-// (GATHER is a template parameter for the reason given at fc_bwd_trio_kernel in gemm_api.hip)
-template <bool GATHER>
+// (the mode is a template parameter for the reason given at fc_bwd_trio_kernel in gemm_api.hip)
+// MODE 0: this rank's operands; 1 ("gather"): K runs over all ranks' operand pairs; 2 / 3 ("shard"): problem 0 is this
+// rank's row slice of the global gradient -- per-rank MFMA work independent of the number of ranks (shard_body.h).  3: one
+// K set, plain stores; 2: several K sets of ranks_per_set source ranks each (enough workgroups to fill the chip at 8 ranks),
+// accumulated with atomics into a pre-zeroed slice.
+template <int MODE>
 __global__ __launch_bounds__(256, 3) void fc_bwd_trio_f32_kernel(const GemmTrio32 g) {
   __shared__ __attribute__((aligned(16))) float smem[TRIO32_LDS];
   const int id = blockIdx.x;
@@ -131,7 +136,17 @@ __global__ __launch_bounds__(256, 3) void fc_bwd_trio_f32_kernel(const GemmTrio3
     dtf_gemm32_body<112, 64, 32, 1, 4, BdA, BdB, Ep32Atomic>(g.q, mt * 112, (r % g.q_nt) * 64, r / g.q_nt, smem);
   } else if (id < g.nblk_q + g.nblk0) {
     const int k = id - g.nblk_q;
-    if constexpr (GATHER) {
+    if constexpr (MODE == 2 || MODE == 3) {
+      // K sets of d0.kchunk = ranks_per_set x batch k-rows: set z multiplies the operand blocks of its source ranks
+      const int per = g.nblk0 / g.ksets, z = k / per, kk = k % per;
+      GemmParams d = g.d0;
+      d.A = g.gA;
+      d.B = g.gB;
+      if constexpr (MODE == 2)
+        dtf_gemm32_body<128, 64, 20, 4, 1, DwAg, DwBg, Ep32Atomic>(d, (kk % g.mt0) * 128, (kk / g.mt0) * 64, z, smem);
+      else
+        dtf_gemm32_body<128, 64, 20, 4, 1, DwAg, DwBg, Ep32Store>(d, (kk % g.mt0) * 128, (kk / g.mt0) * 64, 0, smem);
+    } else if constexpr (MODE == 1) {
       GemmParams d = g.d0;
       d.A = g.gA;
       d.B = g.gB;
@@ -164,6 +179,7 @@ DTF_API int dtf_fc_bwd_trio_f32(const float* X0, const float* dY0, float* dW0, i
   if (!aligned16(X0) || !aligned16(dY0) || !aligned16(X1) || !aligned16(dY1) || !aligned16(dYq) || !aligned16(Wq)) return ERR_SHAPE;
   if (granks < 0 || granks > 8 || (granks > 0 && (!gA || !gB || K % 20))) return ERR_SHAPE;
   GemmTrio32 g;
+  g.ksets = 1;
   for (int r = 0; r < 8; ++r) {
     g.gA[r] = r < granks ? static_cast<const float*>(gA[r]) : nullptr;
     g.gB[r] = r < granks ? static_cast<const float*>(gB[r]) : nullptr;
@@ -186,9 +202,57 @@ DTF_API int dtf_fc_bwd_trio_f32(const float* X0, const float* dY0, float* dW0, i
   g.q.aux_out = g.d0.aux_out = g.d1.aux_out = g_trio_stamps;
 #endif
   if (granks > 0)
-    hipLaunchKernelGGL(fc_bwd_trio_f32_kernel<true>, dim3(g.nblk_q + g.nblk0 + nblk1), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(fc_bwd_trio_f32_kernel<1>, dim3(g.nblk_q + g.nblk0 + nblk1), dim3(256), 0, st, g);
   else
-    hipLaunchKernelGGL(fc_bwd_trio_f32_kernel<false>, dim3(g.nblk_q + g.nblk0 + nblk1), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(fc_bwd_trio_f32_kernel<0>, dim3(g.nblk_q + g.nblk0 + nblk1), dim3(256), 0, st, g);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// The same launch for the "shard" data-parallel schedule (shard_body.h):
+//   dW0_slice[M0_slice][N0] += sum over r < granks of gA[r]^T gB[r]
+// gA[r]: rank r's [K][>= M0_slice] operand block with row pitch lda0, already offset to the slice's first column;
+// gB[r]: rank r's [K][N0] block.  K (a multiple of 20) is split into sets of ranks_per_set source ranks: with more than one
+// set the sets accumulate with atomics and dW0_slice must be zero on entry (the push that follows re-zeroes it); one set
+// stores.  Problems 1 and q as in dtf_fc_bwd_trio_f32.
+DTF_API int dtf_fc_bwd_trio_f32_shard(const float* X1, const float* dY1, int ldy1, float* dW1, int M1, int N1, int K,
+                                      const float* dYq, const float* Wq, float* dXq, int Mq, int Nq, int Kq, int splits,
+                                      const void* const* gA, const void* const* gB, int granks, int ranks_per_set, int lda0,
+                                      float* dW0_slice, int M0_slice, int N0, hipStream_t st) {
+  if (M0_slice <= 0 || N0 <= 0 || M1 <= 0 || N1 <= 0 || K <= 0 || M0_slice % 4 || N0 % 4 || M1 % 4 || N1 > 16 || ldy1 % 4 ||
+      ldy1 < N1 || lda0 % 4 || lda0 < M0_slice)
+    return ERR_SHAPE;
+  if (Mq <= 0 || Nq <= 0 || Kq <= 0 || Kq % 4 || splits < 2) return ERR_SHAPE;
+  if (!aligned16(X1) || !aligned16(dY1) || !aligned16(dYq) || !aligned16(Wq) || !aligned16(dW0_slice)) return ERR_SHAPE;
+  if (granks < 1 || granks > 8 || !gA || !gB || ranks_per_set < 1 || K % 20) return ERR_SHAPE;
+  GemmTrio32 g;
+  g.ksets = dtf_cdiv(granks, ranks_per_set);
+  for (int r = 0; r < 8; ++r) {
+    g.gA[r] = r < granks ? static_cast<const float*>(gA[r]) : nullptr;
+    g.gB[r] = r < granks ? static_cast<const float*>(gB[r]) : nullptr;
+    if (r < granks && (!g.gA[r] || !g.gB[r] || !aligned16(g.gA[r]) || !aligned16(g.gB[r]))) return ERR_SHAPE;
+  }
+  g.d0 = base_params32(nullptr, nullptr, dW0_slice, M0_slice, N0, granks * K, lda0, N0, N0, 1, 20);
+  g.d0.kseg = K;
+  g.d0.kchunk = ranks_per_set * K;  // (a multiple of the slab depth: K % 20 == 0)
+  g.d1 = base_params32(X1, dY1, dW1, M1, N1, K, M1, ldy1, N1, 1, 20);
+  g.mt0 = dtf_cdiv(M0_slice, 128);
+  g.mt1 = dtf_cdiv(M1, 128);
+  g.nblk0 = g.mt0 * dtf_cdiv(N0, 64) * g.ksets;
+  const int nblk1 = g.mt1 * dtf_cdiv(N1, 16);
+  g.q = base_params32(dYq, Wq, dXq, Mq, Nq, Kq, Kq, Kq, Nq, splits, 32);
+  const int s = eff_splits32(g.q);
+  if (s < 2) return ERR_SHAPE;
+  g.q_mt = dtf_cdiv(Mq, 112);
+  g.q_nt = dtf_cdiv(Nq, 64);
+  g.nblk_q = g.q_mt * g.q_nt * s;
+#ifdef DTF_GEMM32_STAMPS
+  g.q.aux_out = g.d0.aux_out = g.d1.aux_out = g_trio_stamps;
+#endif
+  if (g.ksets > 1)
+    hipLaunchKernelGGL(fc_bwd_trio_f32_kernel<2>, dim3(g.nblk_q + g.nblk0 + nblk1), dim3(256), 0, st, g);
+  else
+    hipLaunchKernelGGL(fc_bwd_trio_f32_kernel<3>, dim3(g.nblk_q + g.nblk0 + nblk1), dim3(256), 0, st, g);
   DTF_CHECK_LAUNCH();
   return 0;
 }

@@ -29,6 +29,7 @@
 #include "common.h"
 #include "dtf_structs.h"
 #include "adam_body.h"
+#include "shard_body.h"
 #include "dtf_api.h"
 
 namespace {
@@ -265,8 +266,13 @@ __global__ __launch_bounds__(256) void ipc_gather_copy_kernel(const IpcComm c, f
 // peer's operands.  The epoch word is read by every workgroup before the last one to finish advances it (arrival
 // ticket in the device word after `error`), so no workgroup can see the new value early.  Same ordering contract as
 // dtf_ipc_sync + dtf_ipc_gather_copy: when the launch has completed, every peer has announced and been read.
+// SLICE ("shard" schedule, shard_body.h): of a peer's stage buffer only `rows` row pieces of w4 float4 (at lo4 inside
+// rows of pitch4 float4: the columns of pool2 this rank's gradient slice needs) and a contiguous tail (dh) are pulled, to the
+// same offsets of the local copy; n4 is unused.
+struct GatherSlice { int rows, pitch4, lo4, w4; long tail_off4, tail_n4; };
+template <bool SLICE>
 __global__ __launch_bounds__(256) void ipc_sync_gather_kernel(const IpcComm c, f32x4* __restrict__ dst, long n4,
-                                                             int blocks_per_peer) {
+                                                             int blocks_per_peer, const GatherSlice gs) {
   const unsigned e = *c.epoch + 1u;
   unsigned* ticket = c.epoch + 2;
   if (blockIdx.x == 0 && threadIdx.x < c.world)
@@ -280,18 +286,25 @@ __global__ __launch_bounds__(256) void ipc_sync_gather_kernel(const IpcComm c, f
     }
     __syncthreads();
     const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(stage_of(c.base[p]));
-    f32x4* __restrict__ d = dst + (long)p * n4;
-    for (long base = (long)sub * 256 * COPY_U + threadIdx.x; base < n4; base += (long)blocks_per_peer * 256 * COPY_U) {
+    const long total = SLICE ? (long)gs.rows * gs.w4 + gs.tail_n4 : n4;
+    f32x4* __restrict__ d = dst + (long)p * (SLICE ? gs.tail_off4 + gs.tail_n4 : n4);
+    // unit i of the pull -> float4 offset inside the (identically laid out) source and destination buffers
+    auto at = [&](long i) -> long {
+      if (!SLICE) return i;
+      const long body = (long)gs.rows * gs.w4;
+      return i < body ? (i / gs.w4) * gs.pitch4 + gs.lo4 + i % gs.w4 : gs.tail_off4 + (i - body);
+    };
+    for (long base = (long)sub * 256 * COPY_U + threadIdx.x; base < total; base += (long)blocks_per_peer * 256 * COPY_U) {
       f32x4 v[COPY_U];
 #pragma unroll
       for (int u = 0; u < COPY_U; ++u) {
         const long i = base + u * 256;
-        v[u] = src[i < n4 ? i : base];
+        v[u] = src[at(i < total ? i : base)];
       }
 #pragma unroll
       for (int u = 0; u < COPY_U; ++u) {
         const long i = base + u * 256;
-        if (i < n4) d[i] = v[u];
+        if (i < total) d[at(i)] = v[u];
       }
     }
   }
@@ -456,10 +469,55 @@ DTF_API int dtf_ipc_sync_gather(const void* comm, void* dst, long bytes, int blo
   if (blocks_per_peer < 1) blocks_per_peer = 16;
   if (blocks_per_peer > 64) blocks_per_peer = 64;
   const int grid = c.world > 1 ? (c.world - 1) * blocks_per_peer : 1;
-  hipLaunchKernelGGL(ipc_sync_gather_kernel, dim3(grid), dim3(256), 0, st, c, reinterpret_cast<f32x4*>(dst), bytes / 16,
-                     blocks_per_peer);
+  hipLaunchKernelGGL(ipc_sync_gather_kernel<false>, dim3(grid), dim3(256), 0, st, c, reinterpret_cast<f32x4*>(dst), bytes / 16,
+                     blocks_per_peer, GatherSlice{});
   DTF_CHECK_LAUNCH();
   return 0;
+}
+
+// dtf_ipc_sync_gather for the "shard" schedule: every rank's stage buffer holds [rows][pitch4] float4 (pool2) and, at
+// tail_off4, tail_n4 float4 (dh); this rank needs columns [lo4, lo4 + w4) of the rows and the whole tail.  dst[p][bytes]
+// mirrors the stage layout (only the pulled parts are written).
+DTF_API int dtf_ipc_sync_gather_slice(const void* comm, void* dst, long bytes, int rows, int pitch4, int lo4, int w4,
+                                      long tail_off4, long tail_n4, int blocks_per_peer, hipStream_t st) {
+  const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
+  if (!dst || bytes <= 0 || bytes % 16 || bytes / 4 > c.n_max || c.world < 1 || c.world > MAX_RANKS || c.rank < 0 ||
+      c.rank >= c.world || c.error != c.epoch + 1)
+    return -22;
+  if (rows <= 0 || pitch4 <= 0 || lo4 < 0 || w4 <= 0 || lo4 + w4 > pitch4 || tail_n4 < 0 || tail_off4 < (long)rows * pitch4 ||
+      (tail_off4 + tail_n4) * 16 != bytes)
+    return -22;
+  if (blocks_per_peer < 1) blocks_per_peer = 16;
+  if (blocks_per_peer > 64) blocks_per_peer = 64;
+  const int grid = c.world > 1 ? (c.world - 1) * blocks_per_peer : 1;
+  const GatherSlice gs{rows, pitch4, lo4, w4, tail_off4, tail_n4};
+  hipLaunchKernelGGL(ipc_sync_gather_kernel<true>, dim3(grid), dim3(256), 0, st, c, reinterpret_cast<f32x4*>(dst), 0L,
+                     blocks_per_peer, gs);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// Descriptor of the "shard" schedule's gradient push (shard_body.h) over the communicator whose RESULT buffers are the
+// landing buffers: rank r's slice [lo, lo + n) (floats, multiples of 4) of the landing buffer is written by rank r on every
+// rank; `src` is the slice inside this rank's gradient arena.  dtf_ipc_sync on the same communicator, after the pushing
+// launch, is the arrival barrier.
+DTF_API int dtf_ipc_shard_desc(const void* comm, long lo_floats, long n_floats, float* src, int zero_src, ShardPush* push) {
+  const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
+  if (c.world < 1 || c.world > MAX_RANKS || c.rank < 0 || c.rank >= c.world || !push) return -22;
+  if (lo_floats < 0 || n_floats <= 0 || lo_floats % 4 || n_floats % 4 || lo_floats + n_floats > c.n_max || !src) return -22;
+  *push = ShardPush{};
+  push->src = src;
+  push->n4 = n_floats / 4;
+  for (int p = 0; p < c.world; ++p) push->dst[p] = reinterpret_cast<float*>(c.base[p] + HDR_BYTES) + c.n_max + lo_floats;
+  push->world = c.world;
+  push->rank = c.rank;
+  push->zero_src = zero_src;
+  return 0;
+}
+
+DTF_API const float* dtf_ipc_landing(const void* comm) {
+  const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
+  return reinterpret_cast<const float*>(c.base[c.rank] + HDR_BYTES) + c.n_max;
 }
 
 // ---- general-purpose collectives over the same buffers (not on the training hot path: each is bracketed by barriers,

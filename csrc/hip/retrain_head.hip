@@ -29,6 +29,7 @@ struct RetrainHeadParams {
   float* dz;              // [B][C]  (training)
   int* pred;              // [B]     (optional)
   float* metrics;         // [2] loss sum, correct count (atomics)
+  float* logits;          // [B][C]  (optional: the pre-activations, for the reference's per-step histograms)
 };
 
 __global__ __launch_bounds__(256) void retrain_head_fwd_kernel(const RetrainHeadParams p) {
@@ -48,7 +49,10 @@ __global__ __launch_bounds__(256) void retrain_head_fwd_kernel(const RetrainHead
     if (lane == 0) part[wave * p.C + c] = s;
   }
   __syncthreads();
-  for (int c = tid; c < p.C; c += 256) z[c] = part[c] + part[p.C + c] + part[2 * p.C + c] + part[3 * p.C + c] + p.b[c];
+  for (int c = tid; c < p.C; c += 256) {
+    z[c] = part[c] + part[p.C + c] + part[2 * p.C + c] + part[3 * p.C + c] + p.b[c];
+    if (p.logits) p.logits[(long)row * p.C + c] = z[c];
+  }
   __syncthreads();
   if (wave != 0) return;
   // one wave does the softmax algebra; lanes stride over classes

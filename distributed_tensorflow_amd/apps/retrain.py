@@ -63,16 +63,14 @@ def _head_summary(head, prefix_scalars, batch=None):
     """What ``merged`` holds for the retrain graph (``retrain1/retrain.py:249-258,271-283,295``): the variable
     summaries of the new layer, the ``pre_activations`` / ``activations`` histograms of ``batch`` = (bottlenecks [B,2048])
     and the cross-entropy / accuracy scalars."""
-    import torch
     from ..utils.summary import Summary, variable_summaries
     s = Summary()
     s.merge(variable_summaries("final_training_ops/weights", head.weights))
     s.merge(variable_summaries("final_training_ops/biases", head.biases))
     if batch is not None:
-        with torch.no_grad():
-            logits = batch.to(head.device, torch.float32) @ head.weights + head.biases
-            s.histogram("final_training_ops/Wx_plus_b/pre_activations", logits)
-            s.histogram("final_training_ops/activations", torch.softmax(logits, 1))
+        probs, logits = head.activations(batch)  # (the head's own forward kernel on a GPU)
+        s.histogram("final_training_ops/Wx_plus_b/pre_activations", logits)
+        s.histogram("final_training_ops/activations", probs)
     for k, v in prefix_scalars.items():
         s.scalar(k, v)
     return s
@@ -207,7 +205,10 @@ def run(FLAGS, distributed: bool) -> int:
     pipeline = None
     if os.environ.get("DTF_EXTRACT_PIPELINE", "1") != "0" and (device.type == "cuda" or os.environ.get("DTF_EXTRACT_PIPELINE") == "1"):
         from ..data.pipeline import DecodePipeline
-        pipeline = DecodePipeline(device, batch_size=FLAGS.extract_batch_size)
+        # reference recipe by default: full-size decode, bilinear resize on the GPU (retrain1/retrain.py:34-35: DecodeJpeg
+        # -> ResizeBilinear inside the graph); --decode_draft asks libjpeg for a reduced-scale decode of large sources
+        pipeline = DecodePipeline(device, batch_size=FLAGS.extract_batch_size,
+                                  draft=(2 * 299 if getattr(FLAGS, "decode_draft", False) else 0))
 
     # ---- backbone
     backbone_kind = getattr(FLAGS, "backbone", "auto")
@@ -308,6 +309,19 @@ def run(FLAGS, distributed: bool) -> int:
     ring = torch.zeros(RING, 4, dtype=torch.float32, device=device)  # train ce-sum, train correct, val ce-sum, val correct
     head.use_metrics_ring(ring)
     flushed = head.global_step
+    # --step_histograms: the rest of `merged` on every step too (variable_summaries of the new layer's weights and biases,
+    # the pre_activations / activations histograms, for the training and for the validation batch): one statistics launch
+    # per tensor into a device ring, read back with the scalars
+    stats = cap_t = cap_v = None
+    if getattr(FLAGS, "step_histograms", False):
+        from ..utils.summary import StatsRing
+        RING = 256
+        stats = StatsRing([("final_training_ops/weights", True), ("final_training_ops/biases", True),
+                           ("final_training_ops/Wx_plus_b/pre_activations", False), ("final_training_ops/activations", False),
+                           ("final_training_ops/weights", True), ("final_training_ops/biases", True),
+                           ("final_training_ops/Wx_plus_b/pre_activations", False), ("final_training_ops/activations", False)],
+                          device, slots=RING)
+        cap_t = tuple(torch.empty(FLAGS.train_batch_size, class_count, dtype=torch.float32, device=device) for _ in range(2))
 
     def flush_ring(upto: int) -> None:
         nonlocal flushed
@@ -319,15 +333,28 @@ def run(FLAGS, distributed: bool) -> int:
             all_reduce_(t)
             t /= world
         host = t.cpu().numpy()
+        per_step = stats.flush(flushed, upto) if stats is not None and train_writer is not None else {}
         if train_writer is not None:
+            from ..utils.summary import Summary
             for st in range(flushed, upto):
                 r = host[st % RING]
-                train_writer.add_scalars({"cross_entropy": r[0] / FLAGS.train_batch_size,
-                                          "accuracy": r[1] / FLAGS.train_batch_size}, st)
-                validation_writer.add_scalars({"cross_entropy": r[2] / max(1, FLAGS.validation_batch_size),
-                                               "accuracy": r[3] / max(1, FLAGS.validation_batch_size)}, st)
+                ts = Summary().scalar("cross_entropy", r[0] / FLAGS.train_batch_size).scalar("accuracy", r[1] / FLAGS.train_batch_size)
+                vs = Summary().scalar("cross_entropy", r[2] / max(1, val_rows_n)).scalar("accuracy", r[3] / max(1, val_rows_n))
+                if st in per_step:  # entries 0-3: the training run of `merged`, 4-7: the validation run
+                    full = per_step[st]
+                    nh = len(full.histograms) // 2
+                    ts.scalars += full.scalars[:len(full.scalars) // 2]
+                    vs.scalars += full.scalars[len(full.scalars) // 2:]
+                    ts.histograms += full.histograms[:nh]
+                    vs.histograms += full.histograms[nh:]
+                train_writer.add_summary(ts, st)
+                validation_writer.add_summary(vs, st)
         ring.zero_()
         flushed = upto
+
+    # --validation_batch_size -1 = the whole split (retrain1/retrain.py:553-560): the same rows on every step, built once
+    whole_val = cache.sample_rows("validation", -1, seed=seed + 977) if FLAGS.validation_batch_size < 0 else None
+    val_rows_n = int(whole_val.numel()) if whole_val is not None else FLAGS.validation_batch_size
 
     start_time = time.time()
     steps = FLAGS.training_steps
@@ -351,16 +378,29 @@ def run(FLAGS, distributed: bool) -> int:
                 else:
                     feats, labels = get_random_distorted_bottlenecks(index, FLAGS.train_batch_size, "training", backbone,
                                                                      preproc, distortion, rng)
-                head.train_step(feats, labels, None, ring_slot=i % RING)
+                head.train_step(feats, labels, None, ring_slot=i % RING, capture=cap_t)
                 train_src = (feats, labels, None)
             else:
                 rows = cache.sample_rows("training", FLAGS.train_batch_size, seed=seed + rank)
-                head.train_step(cache.values, cache.labels, rows, ring_slot=i % RING)
+                head.train_step(cache.values, cache.labels, rows, ring_slot=i % RING, capture=cap_t)
                 train_src = (cache.values, cache.labels, rows)
+            if stats is not None:  # (the activations are those of the forward pass, the variables those after the update)
+                stats.record(i, 0, head.weights)
+                stats.record(i, 1, head.biases)
+                stats.record(i, 2, cap_t[1])
+                stats.record(i, 3, cap_t[0])
             # the validation batch of this step (every step, like the reference's second sess.run(merged, ...))
-            vrows = cache.sample_rows("validation", FLAGS.validation_batch_size, seed=seed + 977)
+            vrows = whole_val if whole_val is not None else cache.sample_rows("validation", FLAGS.validation_batch_size,
+                                                                                seed=seed + 977)
             if vrows.numel() > 0:
-                head.accumulate_metrics(cache.values, cache.labels, vrows, ring_slot=i % RING, column=2)
+                if stats is not None and (cap_v is None or cap_v[0].shape[0] != vrows.numel()):
+                    cap_v = tuple(torch.empty(int(vrows.numel()), class_count, dtype=torch.float32, device=device) for _ in range(2))
+                head.accumulate_metrics(cache.values, cache.labels, vrows, ring_slot=i % RING, column=2, capture=cap_v)
+                if stats is not None:
+                    stats.record(i, 4, head.weights)
+                    stats.record(i, 5, head.biases)
+                    stats.record(i, 6, cap_v[1])
+                    stats.record(i, 7, cap_v[0])
             is_last_step = (i + 1 == steps)
             log_now = (i % FLAGS.eval_step_interval) == 0 or is_last_step
             if log_now or (i + 1 - flushed) >= RING:
@@ -375,14 +415,17 @@ def run(FLAGS, distributed: bool) -> int:
                                      device="cpu" if dist.get_backend() == "gloo" else device)
                     dist.all_reduce(t)
                     ce, train_acc, vce, val_acc = (t / world).tolist()
-                if train_writer is not None:
+                if train_writer is not None and stats is None:  # (with --step_histograms every step already carries them)
                     tb = train_src[0] if train_src[2] is None else train_src[0].index_select(0, train_src[2].long())
                     train_writer.add_summary(_head_summary(head, {}, tb), i)
                     vb = cache.values.index_select(0, vrows.long()) if vrows.numel() > 0 else None
                     validation_writer.add_summary(_head_summary(head, {}, vb), i)
-                _log(rank, "%s: Step %d: Train accuracy = %.1f%% Cross entropy = %f Validation accuracy = %.1f%%%s" % (
-                    datetime.now(), i, train_acc * 100, ce, val_acc * 100,
-                    " (N=%d)" % FLAGS.validation_batch_size if distributed else ""))
+                if distributed:  # retrain2's own line (retrain2/retrain2.py:481-487): comma-separated, N = validation rows
+                    _log(rank, "%s: Step %d: Train accuracy = %.1f%%,Cross entropy = %f,Validation accuracy = %.1f%% (N=%d)" % (
+                        datetime.now(), i, train_acc * 100, ce, val_acc * 100, int(vrows.numel())))
+                else:            # retrain1/retrain.py:455-457
+                    _log(rank, "%s: Step %d: Train accuracy = %.1f%% Cross entropy = %f Validation accuracy = %.1f%%" % (
+                        datetime.now(), i, train_acc * 100, ce, val_acc * 100))
             i += 1
     except BaseException as e:  # noqa: BLE001
         rc = 1

@@ -368,6 +368,36 @@ class NativeMnistEngine(_EngineBase):
             self.cfg.gather_rank = ipc.rank
         self._drop_graph()
 
+    @staticmethod
+    def shard_rows(rank: int, world: int, rows: int = 3136) -> Tuple[int, int]:
+        """Rows [lo, hi) of the fc1 filter gradient that ``rank`` of ``world`` computes under the shard schedule (multiples of
+        4: the GEMM's operand alignment; 3136 = 4 x 784 splits evenly for 2 / 4 / 7 / 8 ranks)."""
+        q = rows // 4
+        return (q * rank // world) * 4, (q * (rank + 1) // world) * 4
+
+    def shard_supported(self) -> bool:
+        """The shard schedule is built from the exact-fp32 kernels and rides on the gather schedule's operand exchange."""
+        return self.dtype == "fp32" and self.gather_supported()
+
+    def set_shard(self, ipc_act=None, ipc_w=None) -> None:
+        """Data-parallel "shard" schedule (``csrc/hip/shard_body.h``): per-rank work independent of the world size.  The
+        operands travel as under ``set_gather`` (``ipc_act``), but each rank pulls only the pool2 columns of ITS rows of
+        the fc1 filter gradient, computes those rows of the global gradient, and pushes them into every rank's landing
+        buffer (the result buffers of ``ipc_w``, an IpcAllReduce of at least fc1_grad_numel() floats), from where W_fc1's
+        Adam update reads.  ``None`` switches it off (and the gather exchange with it).  Drops the captured graphs.
+        The caller zeroes G's fc1 segment before the first shard step (the slice is accumulated with atomics)."""
+        if ipc_act is None or ipc_w is None:
+            self.cfg.shard_n = 0
+            self.cfg.shard_comm = None
+            self.set_gather(None)
+            return
+        assert self.shard_supported() and ipc_w.n_max >= self.fc1_grad_numel() and ipc_w.world == ipc_act.world
+        self.set_gather(ipc_act)
+        lo, hi = self.shard_rows(ipc_act.rank, ipc_act.world)
+        self.cfg.shard_comm = ipc_w.comm_addr
+        self.cfg.shard_n, self.cfg.shard_lo, self.cfg.shard_w = ipc_act.world, lo, hi - lo
+        self._drop_graph()
+
     def set_grad_hook(self, hook) -> None:
         """``hook.after_part1(stream)`` / ``hook.after_part2(stream)`` run inside the ``full`` segment after the fc
         gradients resp. all gradients have been enqueued (``stream`` is the engine's torch stream)."""

@@ -147,6 +147,14 @@ def build_retrain_parser(distributed: bool) -> argparse.ArgumentParser:
                    help="also read/write reference-compatible <image>.txt bottleneck files")
     p.add_argument("--extract_batch_size", type=int, default=64,
                    help="images per batched Inception-v3 forward during bottleneck extraction")
+    p.add_argument("--decode_draft", type="bool", nargs="?", const=True, default=False,
+                   help="decode JPEGs of at least twice the network's input size at reduced scale (libjpeg DCT-domain "
+                        "down-scaling, PIL draft): faster extraction, but NOT the reference recipe (full decode + bilinear "
+                        "resize inside the graph, retrain1/retrain.py:34-35); off by default")
+    p.add_argument("--step_histograms", type="bool", nargs="?", const=True, default=False,
+                   help="write the variable summaries and the pre_activations / activations histograms of the new layer "
+                        "on EVERY step for the train and the validation batch like the reference's `merged` "
+                        "(retrain1/retrain.py:249-258,271-279,440-446), through a device ring; default: at logging points")
     # full fine-tune mode (BASELINE config 5): train every Inception-v3 layer instead of the head only
     p.add_argument("--finetune", type="bool", nargs="?", const=True, default=False,
                    help="Fine-tune the whole network (training-mode batch norm, all conv gradients).")

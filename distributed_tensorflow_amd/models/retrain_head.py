@@ -27,9 +27,7 @@ class RetrainHeadParams(C.Structure):  # csrc/hip/retrain_head.hip
     _fields_ = [("cache", C.c_void_p), ("labels_all", C.c_void_p), ("rows", C.c_void_p), ("W", C.c_void_p),
                 ("b", C.c_void_p), ("B", C.c_int), ("C", C.c_int), ("grad_scale", C.c_float),
                 ("double_softmax", C.c_int), ("training", C.c_int), ("probs", C.c_void_p), ("dz", C.c_void_p),
-                ("pred", C.c_void_p), ("metrics", C.c_void_p)]
-
-
+                ("pred", C.c_void_p), ("metrics", C.c_void_p), ("logits", C.c_void_p)]
 
 
 class RetrainHead:
@@ -85,7 +83,9 @@ class RetrainHead:
         self.global_step = int(np.asarray(t.get("Variable", 0)).reshape(-1)[0])
 
     # ------------------------------------------------------------------ forward / eval
-    def _fwd_native(self, cache, labels_all, rows, training: bool, want_probs: bool, metrics_ptr: int = 0):
+    def _fwd_native(self, cache, labels_all, rows, training: bool, want_probs: bool, metrics_ptr: int = 0, capture=None):
+        """``capture``: optional (probs [B,C], logits [B,C]) fp32 device tensors the kernel also fills (the activations /
+        pre_activations the reference histograms on every step)."""
         B = int(rows.shape[0]) if rows is not None else int(cache.shape[0])
         p = RetrainHeadParams()
         p.cache, p.labels_all, p.rows = cache.data_ptr(), labels_all.data_ptr(), native.ptr(rows)
@@ -97,6 +97,9 @@ class RetrainHead:
         if training and (self._dz is None or self._dz.shape[0] != B):
             self._dz = torch.empty(B, self.C, dtype=torch.float32, device=self.device)
         p.probs, p.pred, p.dz = native.ptr(probs), native.ptr(pred), native.ptr(self._dz if training else None)
+        if capture is not None:
+            assert capture[0].shape == (B, self.C) and capture[1].shape == (B, self.C)
+            p.probs, p.logits = capture[0].data_ptr(), capture[1].data_ptr()
         if metrics_ptr:
             p.metrics = metrics_ptr  # (a slot of the per-step ring: accumulates, zeroed by the driver)
         else:
@@ -130,33 +133,51 @@ class RetrainHead:
 
     def predict(self, bottlenecks: torch.Tensor) -> torch.Tensor:
         """``final_result``: softmax probabilities for ``[B,2048]`` bottlenecks."""
+        return self.activations(bottlenecks)[0]
+
+    def activations(self, bottlenecks: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(``final_result`` probabilities, ``Wx_plus_b`` pre-activations), both [B,C], of ``[B,2048]`` bottlenecks; on a GPU
+        from the head's own forward kernel (``csrc/hip/retrain_head.hip``), no library GEMM."""
+        x = bottlenecks.to(self.device, torch.float32).contiguous()
+        if self.native:
+            B = int(x.shape[0])
+            probs = torch.empty(B, self.C, dtype=torch.float32, device=self.device)
+            logits = torch.empty(B, self.C, dtype=torch.float32, device=self.device)
+            if B:
+                labels = torch.zeros(B, dtype=torch.int32, device=self.device)
+                self._fwd_native(x, labels, None, False, False, capture=(probs, logits))
+            return probs, logits
         with torch.no_grad():
-            return torch.softmax(bottlenecks.to(self.device, torch.float32) @ self.weights + self.biases, 1)
+            logits = x @ self.weights + self.biases
+            return torch.softmax(logits, 1), logits
 
     # ------------------------------------------------------------------ training
     def accumulate_metrics(self, cache: torch.Tensor, labels_all: torch.Tensor, rows: Optional[torch.Tensor],
-                           ring_slot: int, column: int = 2) -> None:
+                           ring_slot: int, column: int = 2, capture=None) -> None:
         """Forward only; loss sum and correct count of ``cache[rows]`` are added to ``ring[ring_slot, column:column+2]``."""
         assert self._ring is not None and column in (0, 2)
         if self.native:
             self._fwd_native(cache, labels_all, rows, False, False,
-                             metrics_ptr=self._ring.data_ptr() + (ring_slot * 4 + column) * 4)
+                             metrics_ptr=self._ring.data_ptr() + (ring_slot * 4 + column) * 4, capture=capture)
         else:
             x = cache if rows is None else cache.index_select(0, rows.long())
             y = labels_all if rows is None else labels_all.index_select(0, rows.long())
             with torch.no_grad():
                 loss, probs = self._fwd_eager(x, y)
+            if capture is not None:
+                capture[0].copy_(probs)
+                capture[1].copy_(x @ self.weights + self.biases)
             self._ring[ring_slot, column] += loss * x.shape[0]
             self._ring[ring_slot, column + 1] += (probs.argmax(1) == y.long()).sum()
 
     def train_step(self, cache: torch.Tensor, labels_all: torch.Tensor, rows: Optional[torch.Tensor] = None,
-                   group=None, ring_slot: Optional[int] = None) -> Tuple[float, float]:
+                   group=None, ring_slot: Optional[int] = None, capture=None) -> Tuple[float, float]:
         """One SGD step on ``cache[rows]``; returns (cross-entropy, accuracy) of the batch *before* the update
         as device-synchronising floats only when asked through ``last_metrics``."""
         use_ring = ring_slot is not None and self._ring is not None
         if self.native:
             B, _, _ = self._fwd_native(cache, labels_all, rows, True, False,
-                                       metrics_ptr=self._ring.data_ptr() + ring_slot * 16 if use_ring else 0)
+                                       metrics_ptr=self._ring.data_ptr() + ring_slot * 16 if use_ring else 0, capture=capture)
             st = torch.cuda.current_stream().cuda_stream
             lib = native.hip()
             if self.world == 1:
@@ -180,6 +201,9 @@ class RetrainHead:
             b = leaf[BOTTLENECK * self.C:BOTTLENECK * self.C + self.C]
             logits = x @ w + b
             p = torch.softmax(logits, 1)
+            if capture is not None:
+                capture[0].copy_(p.detach())
+                capture[1].copy_(logits.detach())
             z = p if self.double_softmax else logits
             loss = torch.nn.functional.nll_loss(torch.log_softmax(z, 1), y.long())
             (g,) = torch.autograd.grad(loss, leaf)

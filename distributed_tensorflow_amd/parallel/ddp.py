@@ -231,6 +231,7 @@ class DataParallelTrainer:
         self.schedule_us = None
         self.schedule = None
         self.ipc_act = None
+        self.ipc_w = None          # landing buffers of the shard schedule (fc1 filter gradient, 12.8 MB per rank)
         self._shared_gpu = False
         import time
         t_start = self._t_start = time.perf_counter()
@@ -273,9 +274,10 @@ class DataParallelTrainer:
     def _all_ranks_ok(self, ok: bool) -> bool:
         """Agreement (process group, collective stream): did every rank succeed?"""
         t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cpu" if self._stage_host else self.engine.device)
-        with self._ctx():
+        with self._ctx():  # (the read is ordered on the collective stream too: .item() outside would use the caller's)
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
-        return float(t.item()) > 0
+            ok_all = float(t.item()) > 0
+        return ok_all
 
     def _try_rccl(self) -> None:
         """Create the native RCCL communicator (collective).  Every rank reports whether its part worked; if any failed
@@ -300,7 +302,8 @@ class DataParallelTrainer:
         with self._ctx():
             flag = torch.tensor([ok], dtype=torch.int32, device=self.engine.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-        if int(flag.item()):
+            agreed = int(flag.item())
+        if agreed:
             self.rccl = comm
             self._note("native RCCL communicator: %d ranks, library %s, %.2f s" % (self.world, comm.version, time.perf_counter() - t0))
         else:
@@ -385,6 +388,7 @@ class DataParallelTrainer:
         training starts from exactly the state it would have had without tuning.  All ranks see the same
         max-over-ranks timings and therefore make the same choice."""
         import time
+        from . import schedule_select as sel
         e = self.engine
         forced = os.environ.get("DTF_DP_SCHEDULE", "auto")
         room = e.spe - (e.global_step % e.spe) - 1 if getattr(e, "dataset", None) is not None else steps + 8
@@ -392,138 +396,119 @@ class DataParallelTrainer:
         fc1_end = e.bucket_bounds()[0][0] + e.fc1_grad_numel()  # the fc1 filter gradient leads the arena
         zc_ok = e.bucket_bounds()[0][0] == 0 and fc1_end % 4 == 0 and (e.G.numel() - fc1_end) % 4 == 0
         shared = self._shared_gpu and not os.environ.get("DTF_IPC_FORCE_OVERLAP")
-        # "gather": exchange the fc1 filter gradient's OPERANDS (0.8 MB/rank) instead of the gradient (12.8 MB) through a
-        # second, small exchange buffer; collective set-up, so every rank decides it from the same facts
-        gather_ok = zc_ok and hasattr(e, "gather_supported") and e.gather_supported() and forced in ("auto", "ipc-gather")
-        if gather_ok and self.ipc_act is None:
-            from .ipc_comm import IpcAllReduce
-            self.ipc_act = IpcAllReduce(sum(e.gather_bytes()) // 4, e.device, group=self.group,
-                                        skip_ptr=e.skip_t.data_ptr() if hasattr(e, "skip_t") else 0)
-            gather_ok = self.ipc_act.self_test()
-            if gather_ok:
-                self.ipc_act.set_timeout(float(os.environ.get("DTF_IPC_TIMEOUT_S", "30")))
-            else:
-                self.ipc_act.close()
-                self.ipc_act = None
-        cands = (["ipc-gather"] if gather_ok else []) + (["ipc-zerocopy"] if zc_ok else []) + \
-                ([] if shared else ["ipc-overlap"]) + ["ipc-inline"] + \
-                (["rccl"] if allow_rccl and not self._stage_host and not shared else [])
-        if forced != "auto":
-            if forced not in cands:
-                raise ValueError("DTF_DP_SCHEDULE=%s is not available here (%s)" % (forced, cands))
-            cands = [forced]
-        self._ipc_hook, self._fc1_end = e.grad_hook, fc1_end
-        use = self._use_schedule
+        skip_ptr = e.skip_t.data_ptr() if hasattr(e, "skip_t") else 0
         op_timeout = float(os.environ.get("DTF_IPC_TIMEOUT_S", "30"))
 
+        def exchange_buffer(n_floats: int):
+            """A further IPC exchange buffer (collective set-up: every rank decides it from the same facts)."""
+            from .ipc_comm import IpcAllReduce
+            c = IpcAllReduce(n_floats, e.device, group=self.group, skip_ptr=skip_ptr)
+            if c.self_test():
+                c.set_timeout(op_timeout)
+                return c
+            c.close()
+            return None
+
+        # "gather": exchange the fc1 filter gradient's OPERANDS (0.8 MB/rank) instead of the gradient (12.8 MB) through a
+        # second, small exchange buffer
+        gather_ok = zc_ok and hasattr(e, "gather_supported") and e.gather_supported() and \
+            forced in ("auto", "ipc-gather", "ipc-shard")
+        if gather_ok and self.ipc_act is None:
+            self.ipc_act = exchange_buffer(sum(e.gather_bytes()) // 4)
+            gather_ok = self.ipc_act is not None
+        # "shard": the same operand exchange, but every rank computes only its 1/world row slice of the global gradient and
+        # pushes it into every rank's landing buffer: per-rank work independent of the world size (csrc/hip/shard_body.h)
+        shard_ok = gather_ok and hasattr(e, "shard_supported") and e.shard_supported() and forced in ("auto", "ipc-shard")
+        if shard_ok and self.ipc_w is None:
+            self.ipc_w = exchange_buffer(e.fc1_grad_numel())
+            shard_ok = self.ipc_w is not None
+        cands = sel.candidates(shard_ok=shard_ok, gather_ok=gather_ok and forced != "ipc-shard", zc_ok=zc_ok, shared_gpu=shared,
+                               allow_rccl=allow_rccl, host_staged=self._stage_host, forced=forced)
+        self._ipc_hook, self._fc1_end = e.grad_hook, fc1_end
+        use = self._use_schedule
+
         def set_timeouts(sec: float) -> None:  # (by-value kernel argument: takes effect at the next graph capture)
-            for c in (self.ipc, self.ipc_act):
+            for c in (self.ipc, self.ipc_act, self.ipc_w):
                 if c is not None:
                     c.set_timeout(sec)
 
-        def new_timeouts(seen: list) -> bool:
-            """Did any rank's in-kernel wait expire since the last call (agreed across ranks)?"""
-            t = torch.tensor([float(self.transport_errors())], dtype=torch.float64,
-                             device="cpu" if self._stage_host else e.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            bad = float(t.item()) > seen[0]
-            seen[0] = max(seen[0], float(t.item()))
-            return bad
-
-        # (a forced schedule other than the reference is still checked against it)
-        trial = cands if len(cands) > 1 or cands == ["ipc-inline"] else cands + ["ipc-inline"]
+        trial = sel.trial_list(cands)
         timed = steps >= 8 and len(cands) > 1
         if len(trial) > 1 and room >= 2:
             cands = trial
             with self._ctx():
                 snap = [t.clone() for t in (e.P, e.M, e.V, e.step_t)]
-            done0, times, grads = e._steps_done, [], []
+            done0 = e._steps_done
             b1 = float(e.cfg.beta1) if hasattr(e, "cfg") else float(getattr(e, "b1", 0.9))
+            budget = float(os.environ.get("DTF_DP_STARTUP_BUDGET_S", "5"))
+            trainer = self
+            dev = "cpu" if self._stage_host else e.device
 
-            def restore() -> None:
-                with self._ctx():
-                    for t, s0 in zip((e.P, e.M, e.V, e.step_t), snap):
-                        t.copy_(s0)
-                    e.metrics_ring.zero_()  # (the per-step loss/accuracy slots the trial steps accumulated into)
-                    if hasattr(e, "skip_t"):
-                        e.skip_t.zero_()
-                e.stream.synchronize()
-                e._steps_done = done0
+            class Ops(sel.TrialOps):
+                errs_seen = 0.0
+
+                def use(self, name):
+                    use(name)
+
+                def capture_ok(self):
+                    # (also the barrier: graph capture takes a different time on every rank; the waits are short here)
+                    return trainer._all_ranks_ok(trainer._capture_ok())
+
+                def first_step(self):
+                    # one step from the snapshot: Adam's first moment is linear in the gradient, m' = b1*m + (1-b1)*g, which
+                    # gives the reduced gradient this schedule produced, wherever it keeps it
+                    trainer.train_steps(1)
+                    with trainer._ctx():
+                        return (e.M - b1 * snap[1]) / (1.0 - b1)
+
+                def wait_expired(self):
+                    t = torch.tensor([float(trainer.transport_errors())], dtype=torch.float64, device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=trainer.group)
+                    bad = float(t.item()) > self.errs_seen
+                    self.errs_seen = max(self.errs_seen, float(t.item()))
+                    return bad
+
+                def time_steps(self):
+                    trainer.train_steps(7)
+                    e.stream.synchronize()
+                    dist.barrier(group=trainer.group)
+                    t0 = time.perf_counter()
+                    trainer.train_steps(steps)
+                    e.stream.synchronize()
+                    return (time.perf_counter() - t0) / steps * 1e6
+
+                def restore(self):
+                    with trainer._ctx():
+                        for t, s0 in zip((e.P, e.M, e.V, e.step_t), snap):
+                            t.copy_(s0)
+                        e.metrics_ring.zero_()  # (the per-step loss/accuracy slots the trial steps accumulated into)
+                        if hasattr(e, "skip_t"):
+                            e.skip_t.zero_()
+                    e.stream.synchronize()
+                    e._steps_done = done0
+
+                def over_budget(self):
+                    """Start-up (self-tests + trials so far) has used its budget on some rank (agreed across ranks)."""
+                    t = torch.tensor([1.0 if time.perf_counter() - trainer._t_start > budget else 0.0], dtype=torch.float64,
+                                     device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=trainer.group)
+                    return float(t.item()) > 0
+
+                def deviation(self, g, ref):
+                    with trainer._ctx():
+                        return float((g - ref).norm() / (ref.norm() + 1e-30))
+
+                def reduce_max(self, values):
+                    t = torch.tensor(values, dtype=torch.float64, device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=trainer.group)
+                    return t.cpu().tolist()
 
             set_timeouts(2.0)  # a schedule that cannot make progress on this machine must cost seconds, not minutes
-            errs_seen, broken = [0.0], set()
-            budget = float(os.environ.get("DTF_DP_STARTUP_BUDGET_S", "5"))
-
-            def over_budget() -> bool:
-                """Start-up (self-tests + trials so far) has used its budget on some rank (agreed across ranks)."""
-                t = torch.tensor([1.0 if time.perf_counter() - self._t_start > budget else 0.0], dtype=torch.float64,
-                                 device="cpu" if self._stage_host else e.device)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-                return float(t.item()) > 0
-
-            for c in cands:
-                # bounded start-up: once the budget is spent only the reference schedule is still tried
-                if times and c != "ipc-inline" and forced == "auto" and over_budget():
-                    self._note("%s: not tried (start-up budget of %.0f s spent)" % (c, budget))
-                    broken.add(c)
-                    times.append(float("inf"))
-                    grads.append(None)
-                    continue
-                t_c = time.perf_counter()
-                use(c)
-                # (also the barrier: graph capture takes a different time on every rank; the waits are short here)
-                if not self._all_ranks_ok(self._capture_ok()):
-                    self._note("%s: not eligible (graph capture failed on some rank)" % c)
-                    broken.add(c)
-                    times.append(float("inf"))
-                    grads.append(None)
-                    continue
-                # one step from the snapshot: Adam's first moment is linear in the gradient, m' = b1*m + (1-b1)*g, which
-                # gives the reduced gradient this schedule produced, wherever it keeps it
-                self.train_steps(1)
-                with self._ctx():
-                    grads.append((e.M - b1 * snap[1]) / (1.0 - b1))
-                if c != "rccl" and new_timeouts(errs_seen):
-                    self._note("%s: an in-kernel wait expired (2 s bound): not eligible" % c)
-                    broken.add(c)
-                    times.append(float("inf"))
-                    restore()
-                    continue
-                if timed:
-                    self.train_steps(7)
-                    e.stream.synchronize()
-                    dist.barrier(group=self.group)
-                    t0 = time.perf_counter()
-                    self.train_steps(steps)
-                    e.stream.synchronize()
-                    times.append((time.perf_counter() - t0) / steps * 1e6)
-                else:
-                    times.append(float(len(times)))  # untimed: keep the order of preference
-                self._note("%s: %s us/step, trial took %.2f s" % (c, ("%.1f" % times[-1]) if timed else "untimed",
-                                                               time.perf_counter() - t_c))
-                restore()
-            # every schedule computes the same gradient up to summation order (same batch, same dropout mask: both are
-            # keyed by the step): a candidate that is far from the staged in-stream all-reduce — the path the start-up
-            # self-test validated against the process group — is broken on this machine and is not eligible
-            ref = grads[cands.index("ipc-inline")]
-            with self._ctx():
-                off = [float("inf") if g is None else float((g - ref).norm() / (ref.norm() + 1e-30)) for g in grads]
-            del grads
-            t = torch.tensor(times + off, dtype=torch.float64, device="cpu" if self._stage_host else e.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            t = t.cpu().tolist()
-            times, off = t[:len(cands)], t[len(cands):]
+            times, off, broken = sel.run_trials(cands, Ops(), forced=forced, timed=timed, note=self._note, budget_s=budget)
             self.schedule_us = {c: round(v, 1) for c, v in zip(cands, times)} if timed else None
             self.schedule_deviation = {c: float("%.3g" % v) for c, v in zip(cands, off)}
             set_timeouts(op_timeout)
-            good = [i for i in range(len(cands)) if off[i] < 0.02 and cands[i] not in broken
-                    and (forced == "auto" or cands[i] == forced)]
-            if not good and forced == "auto" and "rccl" in cands:
-                good = [cands.index("rccl")]
-            if not good:
-                raise RuntimeError("no usable data-parallel schedule (%s): deviations %s, timed out %s" % (
-                    forced, self.schedule_deviation, sorted(broken)))
-            cands = [cands[min(good, key=lambda i: times[i])]]
+            cands = [sel.choose(cands, times, off, broken, forced)]
         use(cands[0])
         if self.rank == 0:
             print("data-parallel step schedule: %s %s gradient deviation from the staged all-reduce %s" % (
@@ -531,10 +516,17 @@ class DataParallelTrainer:
 
     def _use_schedule(self, c: str) -> None:
         e, hook, fc1_end = self.engine, self._ipc_hook, self._fc1_end
-        zc, ga = c == "ipc-zerocopy", c == "ipc-gather"
+        zc, sh = c == "ipc-zerocopy", c == "ipc-shard"
+        ga = c == "ipc-gather" or sh  # (the shard schedule rides on the gather schedule's operand exchange and publish)
         if self.ipc is not None or zc:
             e.set_grad_redirect(self.ipc.stage_ptr if zc else 0, self.ipc.result_ptr if zc else 0)
-        if hasattr(e, "set_gather"):
+        if hasattr(e, "set_shard"):
+            e.set_shard(None)  # (also switches the gather exchange off)
+        if sh:
+            e.set_shard(self.ipc_act, self.ipc_w)
+            with torch.cuda.stream(e.stream):
+                e.G[:fc1_end].zero_()  # this rank's slice of the fc1 gradient is accumulated with atomics and re-zeroed by the push
+        elif hasattr(e, "set_gather"):
             e.set_gather(self.ipc_act if ga else None)
         self._rccl_graph = False
         if c == "rccl":
@@ -591,9 +583,11 @@ class DataParallelTrainer:
             if self._pg_stream is None:
                 self._pg_stream = torch.cuda.Stream(device=e.device)
             self._pg_stream.wait_stream(e.stream)
-            with torch.cuda.stream(self._pg_stream):
-                yield
-            e.stream.wait_stream(self._pg_stream)
+            try:
+                with torch.cuda.stream(self._pg_stream):
+                    yield
+            finally:  # (also when the body raised: the engine's stream must not run ahead of a half-issued collective)
+                e.stream.wait_stream(self._pg_stream)
         return isolated()
 
     def _reduce_async(self, t: torch.Tensor):
@@ -645,12 +639,15 @@ class DataParallelTrainer:
         """Release the IPC exchange buffers (collective: every rank calls it, before the process group is destroyed)."""
         if self.ipc is not None:
             self.engine.set_grad_redirect(0, 0)
-            if hasattr(self.engine, "set_gather"):
+            if hasattr(self.engine, "set_shard"):
+                self.engine.set_shard(None)
+            elif hasattr(self.engine, "set_gather"):
                 self.engine.set_gather(None)
             self.engine.set_grad_hook(None)
-            if self.ipc_act is not None:
-                self.ipc_act.close()
-                self.ipc_act = None
+            for name in ("ipc_w", "ipc_act"):
+                if getattr(self, name) is not None:
+                    getattr(self, name).close()
+                    setattr(self, name, None)
             self.ipc.close()
             self.ipc = None
             self.comm = "rccl"
@@ -663,7 +660,7 @@ class DataParallelTrainer:
 
     def transport_errors(self) -> int:
         """Expired in-kernel waits of the IPC exchanges so far (synchronises); 0 when IPC is not in use."""
-        return sum(c.errors() for c in (self.ipc, self.ipc_act) if c is not None)
+        return sum(c.errors() for c in (self.ipc, self.ipc_act, self.ipc_w) if c is not None)
 
     def check_transport(self) -> None:
         """Raise if an in-kernel wait of the IPC all-reduce ever expired (a peer stalled for longer than the bound, so
@@ -708,16 +705,16 @@ class DataParallelTrainer:
             self.train_steps(1)  # (not across the reshuffle at an epoch boundary)
         b1 = float(e.cfg.beta1) if hasattr(e, "cfg") else float(getattr(e, "b1", 0.9))
         if self._native:
-            cfg, keep = e.cfg, (e.cfg.G_fc1_dst, e.cfg.G_src, e.cfg.gather_n)
+            cfg, keep = e.cfg, (e.cfg.G_fc1_dst, e.cfg.G_src, e.cfg.gather_n, e.cfg.shard_n)
             with self._ctx():
                 ring = e.metrics_ring.clone()
-            cfg.G_fc1_dst, cfg.G_src, cfg.gather_n = None, None, 0   # plain local gradients into G (graphs are untouched:
-            try:                                                      # their arguments were bound at capture)
+            cfg.G_fc1_dst, cfg.G_src, cfg.gather_n, cfg.shard_n = None, None, 0, 0   # plain local gradients into G (graphs are
+            try:                                                      # untouched: their arguments were bound at capture)
                 with torch.cuda.stream(e.stream):
                     e.G.zero_()
                     e.fwd_bwd(3)
             finally:
-                cfg.G_fc1_dst, cfg.G_src, cfg.gather_n = keep
+                cfg.G_fc1_dst, cfg.G_src, cfg.gather_n, cfg.shard_n = keep
             with self._ctx():
                 ref = e.G.clone()
                 e.G.zero_()

@@ -102,6 +102,85 @@ def device_stats(t) -> Tuple[float, float, float, float, float, np.ndarray]:
     return mn, mx, num, float(sm[0]), float(sm[1]), hist
 
 
+class StatsRing:
+    """Per-step tensor statistics without a host sync per step: ``record(step, k, tensor)`` runs the fused statistics
+    kernel (``csrc/hip/stats.hip``) into slot ``step % slots`` of a device ring, ``flush(first, last)`` reads the ring
+    back once and returns, per step, the same ``Summary`` entries ``variable_summaries`` / ``Summary.histogram`` would
+    have produced.  ``tags[k] = (tag, with_scalars)``: ``with_scalars`` adds the mean / stddev / max / min scalars of
+    ``variable_summaries`` (``retrain1/retrain.py:249-258``), otherwise the entry is a plain histogram (``:277,279``).
+    The reference evaluates all of them on every step for the train and the validation batch (``:440-446``)."""
+
+    def __init__(self, tags, device, slots: int = 256):
+        import torch
+        self.tags, self.slots, self.device = list(tags), slots, torch.device(device)
+        self.T = len(self.tags)
+        self.ncnt = 2 * _NPOS + 4
+        self.cuda = self.device.type == "cuda"
+        if self.cuda:
+            self.sums = torch.zeros(slots, self.T, 2, dtype=torch.float64, device=self.device)
+            self.counts = torch.zeros(slots, self.T, self.ncnt, dtype=torch.int32, device=self.device)
+            lim = _DEV_LIMITS.get(self.device)
+            if lim is None:
+                lim = torch.from_numpy(BUCKET_LIMITS[_NPOS + 1:_NPOS + 1 + _NPOS].copy()).to(self.device)
+                _DEV_LIMITS[self.device] = lim
+            self._lim = lim
+        else:
+            self._host = {}
+
+    def record(self, step: int, k: int, t) -> None:
+        import torch
+        slot = step % self.slots
+        if not self.cuda:
+            self._host[(slot, k)] = histogram_stats(t)
+            return
+        t = t.detach().reshape(-1)
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.float().contiguous()
+        native.check(native.hip().dtf_tensor_stats(t.data_ptr(), t.numel(), self._lim.data_ptr(), _NPOS,
+                                                   self.sums[slot, k].data_ptr(), self.counts[slot, k].data_ptr(),
+                                                   torch.cuda.current_stream(self.device).cuda_stream), "tensor_stats")
+
+    def flush(self, first: int, last: int, only=None) -> Dict[int, Summary]:
+        """Summaries of steps [first, last) (at most ``slots`` back); ``only``: indices into ``tags`` to include."""
+        assert last - first <= self.slots
+        out: Dict[int, Summary] = {}
+        if last <= first:
+            return out
+        if self.cuda:
+            sums = self.sums.cpu().numpy()
+            counts = self.counts.cpu().numpy().view(np.uint32)
+        nb = 2 * _NPOS + 2
+        for step in range(first, last):
+            slot = step % self.slots
+            s = Summary()
+            for k, (tag, with_scalars) in enumerate(self.tags):
+                if only is not None and k not in only:
+                    continue
+                if self.cuda:
+                    c = counts[slot, k]
+                    hist = c[:nb].astype(np.int64)
+                    num = float(hist.sum())
+                    mn = _order_key_decode(int(c[nb])) if num else 0.0
+                    mx = _order_key_decode(int(c[nb + 1])) if num else 0.0
+                    h = _compress(mn, mx, num, float(sums[slot, k, 0]), float(sums[slot, k, 1]), hist)
+                else:
+                    h = self._host.get((slot, k))
+                    if h is None:
+                        continue
+                if with_scalars:
+                    num = max(h["num"], 1.0)
+                    mean = h["sum"] / num
+                    s.scalar(tag + "/summaries/mean", mean)
+                    s.scalar(tag + "/summaries/stddev/stddev", max(h["sum_squares"] / num - mean * mean, 0.0) ** 0.5)
+                    s.scalar(tag + "/summaries/max", h["max"])
+                    s.scalar(tag + "/summaries/min", h["min"])
+                    s.histograms.append((tag + "/summaries/histogram", h))
+                else:
+                    s.histograms.append((tag, h))
+            out[step] = s
+        return out
+
+
 def histogram_stats(values) -> dict:
     """min/max/num/sum/sum_squares + TF-style compressed buckets of a tensor or array.  Bucket ``i`` holds
     ``limit[i-1] <= v < limit[i]`` (TF's ``Histogram::Add`` uses ``upper_bound``)."""

@@ -8,7 +8,7 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 DT=${1:-fp32}
 mkdir -p gpurun_out/dp_local
 port=29700
-for sch in plain ipc-gather ipc-zerocopy ipc-inline ipc-overlap rccl; do
+for sch in plain ipc-shard ipc-gather ipc-zerocopy ipc-inline ipc-overlap rccl; do
   port=$((port + 1))
   if [ $sch = plain ]; then
     extra=""

@@ -111,6 +111,50 @@ def test_fc_backward_trio_f32(granks):
     del pad
 
 
+@pytest.mark.parametrize("world,rank", [(1, 0), (2, 1), (3, 1), (4, 3), (8, 0), (8, 5)])
+def test_fc_backward_trio_f32_shard(world, rank):
+    """The fused fc backward launch of the "shard" data-parallel schedule: problem 0 is this rank's ROW SLICE of the global
+    fc1 filter gradient, summed over all ranks' operand blocks (one workgroup set per source rank, atomics into the
+    pre-zeroed slice); rows outside the slice are not touched.  Reference: float64."""
+    import ctypes as C
+    from distributed_tensorflow_amd import native
+    from distributed_tensorflow_amd.engine.mnist_engine import NativeMnistEngine
+    lib = native.hip()
+    P, I = C.c_void_p, C.c_int
+    lib.dtf_fc_bwd_trio_f32_shard.argtypes = [P, P, I, P, I, I, I, P, P, P, I, I, I, I, P, P, I, I, I, P, I, I, P]
+    lib.dtf_fc_bwd_trio_f32_shard.restype = I
+    torch.manual_seed(50 + 8 * world + rank)
+    B = 100
+    lo, hi = NativeMnistEngine.shard_rows(rank, world)
+    assert lo % 4 == 0 and hi % 4 == 0 and (rank < world - 1 or hi == 3136) and (rank > 0 or lo == 0)
+    xs = [torch.randn(B, 3136, device=dev()) for _ in range(world)]
+    dhs = [torch.randn(B, 1024, device=dev()) for _ in range(world)]
+    hdrop = torch.randn(B, 1024, device=dev())
+    dz = torch.zeros(B, 16, device=dev())
+    dz[:, :10] = torch.randn(B, 10, device=dev())
+    w = torch.randn(3136, 1024, device=dev()) * 0.05
+    dW0 = torch.zeros(3136, 1024, device=dev())
+    if world <= 2:
+        dW0[lo:hi] = float("nan")   # (one K set: plain stores, nothing to pre-zero)
+    dW0[:lo] = 7.0   # (other ranks' rows: must stay as they are)
+    dW0[hi:] = 7.0
+    dW1 = torch.full((1024, 10), float("nan"), device=dev())
+    dX = torch.zeros(B, 3136, device=dev())
+    ga = (P * 8)(*[x.data_ptr() + 4 * lo for x in xs])   # every block already offset to the slice's first column
+    gb = (P * 8)(*[d.data_ptr() for d in dhs])
+    torch.cuda.synchronize()
+    rc = lib.dtf_fc_bwd_trio_f32_shard(hdrop.data_ptr(), dz.data_ptr(), 16, dW1.data_ptr(), 1024, 10, B, dhs[rank].data_ptr(),
+                                       w.data_ptr(), dX.data_ptr(), B, 3136, 1024, 6, ga, gb, world, 2, 3136,
+                                       dW0.data_ptr() + 4 * lo * 1024, hi - lo, 1024, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref0 = sum(x[:, lo:hi].double().t() @ d.double() for x, d in zip(xs, dhs))
+    assert relerr(dW0[lo:hi], ref0) < 2e-6
+    assert bool((dW0[:lo] == 7.0).all()) and bool((dW0[hi:] == 7.0).all())
+    assert relerr(dW1, hdrop.double().t() @ dz[:, :10].double()) < 2e-6
+    assert relerr(dX, dhs[rank].double() @ w.double().t()) < 1e-5
+
+
 def _conv2_ref(x, w, b):
     c = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), b.double(), padding=2)
     return c, F.max_pool2d(torch.relu(c), 2).permute(0, 2, 3, 1)

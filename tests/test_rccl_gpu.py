@@ -164,6 +164,14 @@ for _ in range(2):
     out["dev"].append(tr.check_exchange())
     tr.train_steps(17)
 out["in_sync"] = tr.replicas_in_sync()
+out["errors"] = tr.transport_errors()
+if not out["in_sync"]:  # diagnostics: which tensors differ from rank 0's, in how many elements, by how much
+    mine = eng.P.cpu()
+    allp = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allp, mine)
+    out["diff"] = {k: [int((allp[r][o:o + n] != allp[0][o:o + n]).sum()) for r in range(world)] + [float((allp[rank][o:o + n] - allp[0][o:o + n]).abs().max())]
+                   for k, (o, n, _s) in eng.layout.items()}
+    out["finite"] = bool(torch.isfinite(mine).all())
 out["host_step"], out["device_step"] = eng.global_step, int(eng.step_t.item())
 lm, am = eng.read_metrics(0, eng.global_step)
 out["loss_first"], out["loss_last"] = float(lm[:5].mean()), float(lm[-5:].mean())
@@ -174,20 +182,21 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("schedule,dtype", [("ipc-inline", "fp32"), ("ipc-zerocopy", "fp32"), ("ipc-gather", "fp32"),
-                                            ("ipc-gather", "bf16"), ("ipc-inline", "bf16")])
-def test_checked_step_validates_the_production_exchange(tmp_path, schedule, dtype):
+@pytest.mark.parametrize("schedule,dtype,nproc", [("ipc-inline", "fp32", 2), ("ipc-zerocopy", "fp32", 2), ("ipc-gather", "fp32", 2),
+                                                  ("ipc-shard", "fp32", 2), ("ipc-shard", "fp32", 3),
+                                                  ("ipc-gather", "bf16", 2), ("ipc-inline", "bf16", 2)])
+def test_checked_step_validates_the_production_exchange(tmp_path, schedule, dtype, nproc):
     """``check_exchange`` (the ``--check_replicas`` assertion): the gradient the optimizer consumed under the production
     schedule equals the host-ordered sum of the ranks' local gradients; the checked step leaves counters, metrics and
     replicas consistent."""
     script = tmp_path / "checked.py"
     script.write_text(_CHECKED)
     env = dict(os.environ, MASTER_PORT="29644", HSA_ENABLE_IPC_MODE_LEGACY="0", DTF_DP_SCHEDULE=schedule)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29644", str(script), REPO, dtype, str(tmp_path)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", "29644", str(script), REPO, dtype, str(tmp_path)]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
-    res = [json.load(open(str(tmp_path / ("r%d.json" % k)))) for k in range(2)]
+    res = [json.load(open(str(tmp_path / ("r%d.json" % k)))) for k in range(nproc)]
     for o in res:
         assert o["schedule"] == schedule and max(o["dev"]) < 2e-3, o
         assert o["in_sync"] and o["host_step"] == o["device_step"] == 3 + 2 * 18, o

@@ -69,6 +69,43 @@ def test_retrain1_bundle_is_self_contained_and_test_py_classifies_held_out_image
     assert re.search(r"class 0\d \(score = 0\.\d{5}\)", r2.stdout)
 
 
+def test_step_histograms_whole_validation_split_and_retrain2_log_line(tmp_path):
+    """``--step_histograms``: `merged` in full on EVERY step for both runs (``retrain1/retrain.py:249-258,271-279,440-446``);
+    ``--validation_batch_size -1`` is normalised by the split's size; retrain2 prints its own comma-separated line with
+    N = the number of validation rows (``retrain2/retrain2.py:481-487``)."""
+    from distributed_tensorflow_amd.utils.summary import read_events
+    cwd = str(tmp_path)
+    steps = 12
+    r = _cli([os.path.join(REPO, "retrain2", "retrain2.py"), "--device", "cpu", "--synthetic", "--synthetic_classes", "3",
+              "--synthetic_images_per_class", "30", "--training_steps", str(steps), "--train_batch_size", "16",
+              "--validation_batch_size", "-1", "--eval_step_interval", "5", "--learning_rate", "0.05", "--seed", "3",
+              "--double_softmax", "false", "--step_histograms", "--job_name", "worker", "--task_index", "0",
+              "--worker_hosts", "127.0.0.1:29741", "--ps_hosts", "", "--save_model_secs", "0"], cwd)
+    assert r.returncode == 0, r.stdout[-3000:]
+    m = re.search(r"Step 10: Train accuracy = [\d.]+%,Cross entropy = [\d.]+,Validation accuracy = [\d.]+% \(N=(\d+)\)", r.stdout)
+    assert m, r.stdout[-2000:]
+    nval = int(m.group(1))
+    assert 1 <= nval < 90
+    for split, rows in (("train", 16), ("validation", nval)):
+        ev = []
+        for f in glob.glob(os.path.join(cwd, "retrain_logs", split, "events.out.tfevents.*")):
+            ev += read_events(f)
+        by_step = {e["step"]: e for e in ev if "cross_entropy" in e["scalars"]}
+        assert sorted(by_step) == list(range(steps))
+        for st, e in by_step.items():
+            assert {"final_training_ops/Wx_plus_b/pre_activations", "final_training_ops/activations",
+                    "final_training_ops/weights/summaries/histogram", "final_training_ops/biases/summaries/histogram"} \
+                <= set(e["histograms"]), (split, st, sorted(e["histograms"]))
+            assert e["histograms"]["final_training_ops/activations"]["num"] == rows * 3
+            assert e["histograms"]["final_training_ops/weights/summaries/histogram"]["num"] == 2048 * 3
+            for k in ("mean", "stddev/stddev", "max", "min"):
+                assert "final_training_ops/weights/summaries/" + k in e["scalars"]
+            assert 0.0 <= e["scalars"]["accuracy"] <= 1.0 and 0.0 < e["scalars"]["cross_entropy"] < 50.0   # (means, not sums)
+        # the activations are probabilities: every step's histogram sums to one per row
+        h = by_step[3]["histograms"]["final_training_ops/activations"]
+        assert abs(h["sum"] - rows) < 1e-3 * rows
+
+
 def test_retrain2_stop_relaunch_resume_two_ranks(tmp_path):
     """A fault on the last rank at step 12: every rank stops (out-of-band stop flag through the job's store), the chief
     saves ./logs/model.ckpt-<step>, the job exits non-zero; the relaunch restores it on the chief, broadcasts, continues
