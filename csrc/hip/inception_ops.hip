@@ -176,3 +176,45 @@ DTF_API int dtf_preprocess_images(const void* pixels, const void* desc, void* ou
   DTF_CHECK_LAUNCH();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------- batch gather
+// dst[b] = src[rows[b]] for rows of `row16` 16-byte units (the fine-tune step's batch: 1.43 MB bf16 images picked by the
+// device-side class-balanced sampler out of the HBM-resident training set, /root/reference/retrain1/retrain.py:322-340 does
+// the same pick on the host, one file at a time), and labels_out[b] = labels[rows[b]].
+// grid = (workgroups per row, B): every workgroup copies a strided share of one row, 4 x 16 B in flight per lane.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const f32x4* __restrict__ src, const int* __restrict__ rows,
+                                                          f32x4* __restrict__ dst, long row16, const int* __restrict__ labels,
+                                                          int* __restrict__ labels_out) {
+  const int b = blockIdx.y;
+  const long r = rows[b];
+  if (labels && blockIdx.x == 0 && threadIdx.x == 0) labels_out[b] = labels[r];
+  const f32x4* __restrict__ s = src + r * row16;
+  f32x4* __restrict__ d = dst + (long)b * row16;
+  constexpr int U = 4;
+  for (long base = (long)blockIdx.x * 256 * U + threadIdx.x; base < row16; base += (long)gridDim.x * 256 * U) {
+    f32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = base + u * 256;
+      v[u] = s[i < row16 ? i : base];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = base + u * 256;
+      if (i < row16) d[i] = v[u];
+    }
+  }
+}
+
+DTF_API int dtf_gather_rows(const void* src, const int* rows, void* dst, long row_bytes, int B, const int* labels,
+                            int* labels_out, hipStream_t st) {
+  if (!src || !rows || !dst || B <= 0 || row_bytes <= 0 || row_bytes % 16 || (labels && !labels_out)) return -22;
+  const long row16 = row_bytes / 16;
+  long per_row = (row16 + 256 * 4 * 4 - 1) / (256 * 4 * 4);  // ~4 passes per workgroup
+  if (per_row < 1) per_row = 1;
+  if (per_row > 64) per_row = 64;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)per_row, (unsigned)B), dim3(256), 0, st,
+                     static_cast<const f32x4*>(src), rows, static_cast<f32x4*>(dst), row16, labels, labels_out);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}

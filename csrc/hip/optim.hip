@@ -50,3 +50,39 @@ DTF_API int dtf_sgd(const OptimParams* p, hipStream_t st) {
   DTF_CHECK_LAUNCH();
   return 0;
 }
+
+// fp32 <-> bf16 casts of a gradient bucket (8 elements per lane; n % 8 == 0): the wire format of the fine-tune's optional
+// bf16 gradient exchange.  The fp32 arena stays the accumulation and optimizer format.
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float4* __restrict__ src, uint4* __restrict__ dst, long n8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const float4 a = src[2 * i], b = src[2 * i + 1];
+    dst[i] = make_uint4(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w), pack_bf2(b.x, b.y), pack_bf2(b.z, b.w));
+  }
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const uint4* __restrict__ src, float4* __restrict__ dst, long n8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const uint4 v = src[i];
+    dst[2 * i] = make_float4(bf2f(v.x & 0xffffu), bf2f(v.x >> 16), bf2f(v.y & 0xffffu), bf2f(v.y >> 16));
+    dst[2 * i + 1] = make_float4(bf2f(v.z & 0xffffu), bf2f(v.z >> 16), bf2f(v.w & 0xffffu), bf2f(v.w >> 16));
+  }
+}
+
+DTF_API int dtf_cast_f32_bf16(const float* src, void* dst, long n, hipStream_t st) {
+  if (n <= 0 || n % 8) return -22;
+  long blocks = (n / 8 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((int)blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(src),
+                     static_cast<uint4*>(dst), n / 8);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+DTF_API int dtf_cast_bf16_f32(const void* src, float* dst, long n, hipStream_t st) {
+  if (n <= 0 || n % 8) return -22;
+  long blocks = (n / 8 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((int)blocks), dim3(256), 0, st, static_cast<const uint4*>(src),
+                     reinterpret_cast<float4*>(dst), n / 8);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}

@@ -2,12 +2,17 @@
 
 The reference trains only the 2048->C head on frozen bottlenecks (``retrain1/retrain.py:372-476``); this mode keeps
 the reference's data contract (image folders -> SHA-1 split ``:78-128``, class-balanced random sampling ``:322-354``,
-optional distortions ``:137-165``, log line ``:455-457``, final test accuracy ``:467``, label file ``:474-475``) but
-back-propagates through the whole network with the native training kernels, data-parallel over RCCL.
+optional distortions ``:137-165``, log line ``:455-457`` / ``retrain2/retrain2.py:481-487``, final test accuracy ``:467``,
+``retrained_graph.pb`` + label file ``:470-475``) but back-propagates through the whole network with the native training
+kernels, data-parallel over RCCL.  ``retrain2.py --finetune`` runs under the same Supervisor as every distributed script
+of the reference (``retrain2/retrain2.py:423-431,445,508``): the chief restores the newest ``./logs/model.ckpt-<step>``
+(parameters, optimizer slots, moving statistics, step), everyone receives it, autosave every ``--save_model_secs``, stop
+flag and heartbeats out of band, ``--fault_inject_step``.
 
-The decoded + resized training images live in HBM as one bf16 NHWC tensor (1.43 MB/image: 100k images fit in half
-of one MI355X's 288 GB), so a step samples rows on the device instead of decoding JPEGs; with distortions enabled
-the batch is re-decoded and augmented on the fly by the fused preprocessing kernel.
+The decoded + resized training images live in HBM as one bf16 NHWC tensor (1.43 MB/image: 100k images fit in half of one
+MI355X's 288 GB); a step draws its batch ON THE DEVICE — the class-balanced sampler kernel of the retrain head
+(``dtf_sample_rows``) and one gather kernel into a static input buffer — so the host issues launches only.  With
+distortions enabled the batch is re-decoded and augmented on the fly by the fused preprocessing kernel.
 """
 from __future__ import annotations
 
@@ -15,6 +20,7 @@ import os
 import random
 import time
 from datetime import datetime
+from typing import Optional
 
 import numpy as np
 
@@ -25,7 +31,7 @@ def _log(rank: int, msg: str) -> None:
 
 
 def _load_split(index, preproc, category: str, rank: int, world: int, shard: bool):
-    """(images bf16 [n,299,299,8], labels int32 [n]) of one split; training is sharded rank-strided."""
+    """(images bf16 [n,299,299,8], labels int32 [n]) of one split, label-major; training is sharded rank-strided."""
     import torch
     rows = index.rows_of(category)
     if shard:
@@ -35,7 +41,7 @@ def _load_split(index, preproc, category: str, rank: int, world: int, shard: boo
         # resize), written batch by batch into one preallocated tensor
         from ..data.pipeline import DecodePipeline
         out = torch.empty(len(rows), 299, 299, 8, dtype=torch.bfloat16, device=preproc.device)
-        pipe = DecodePipeline(preproc.device, batch_size=64)
+        pipe = DecodePipeline(preproc.device, batch_size=64, draft=0)
         try:
             for first, count, x in pipe.batches([index.paths[r] for r in rows]):
                 out[first:first + count].copy_(x[:count])
@@ -52,15 +58,163 @@ def _load_split(index, preproc, category: str, rank: int, world: int, shard: boo
     return torch.cat(xs), torch.cat(ys).to(xs[0].device)
 
 
-def run(FLAGS, image_lists, image_dir: str, rank: int, world: int, device, seed: int) -> int:
+class DeviceBatchSampler:
+    """``get_random_cached_bottlenecks`` (``retrain1/retrain.py:322-340``: random class, then random image of that class,
+    with replacement) over an HBM-resident image split, entirely on the device: ``dtf_sample_rows`` draws the rows
+    (counter-based RNG keyed by (seed, draw)), ``dtf_gather_rows`` copies the picked images and labels into the caller's
+    static batch buffers.  No per-step host list, no Python loop, no host->device copy.  CPU: the same draw with torch ops."""
+
+    def __init__(self, x, y, num_classes: int, seed: int):
+        import torch
+        self.x, self.device, self.C, self.seed, self.draws = x, x.device, num_classes, int(seed), 0
+        ys = y.cpu().numpy()
+        if np.any(ys[1:] < ys[:-1]):  # (splits are loaded label-major; anything else is sorted once)
+            order = np.argsort(ys, kind="stable")
+            self.x = x = x[torch.as_tensor(order, device=x.device)]
+            ys = ys[order]
+        self.y = torch.as_tensor(ys, dtype=torch.int32, device=self.device)
+        counts = np.bincount(ys, minlength=num_classes).astype(np.int64)
+        self.counts = torch.as_tensor(counts, device=self.device)
+        self.offsets = torch.as_tensor(np.concatenate(([0], np.cumsum(counts)[:-1])).astype(np.int64), device=self.device)
+        self.row_bytes = x[0].numel() * x.element_size()
+        self._rows = {}
+
+    def sample_into(self, out_x, out_y) -> None:
+        import torch
+        B = int(out_x.shape[0])
+        self.draws += 1
+        if self.device.type == "cuda":
+            from .. import native
+            lib = native.hip()
+            if B not in self._rows:
+                self._rows[B] = torch.empty(B, dtype=torch.int32, device=self.device)
+            rows = self._rows[B]
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            native.check(lib.dtf_sample_rows(self.offsets.data_ptr(), self.counts.data_ptr(), self.C, B, self.seed, self.draws,
+                                             rows.data_ptr(), st), "sample_rows")
+            native.check(lib.dtf_gather_rows(self.x.data_ptr(), rows.data_ptr(), out_x.data_ptr(), self.row_bytes, B,
+                                             self.y.data_ptr(), out_y.data_ptr(), st), "gather_rows")
+            return
+        g = torch.Generator().manual_seed((self.seed * 1000003 + self.draws) % (2 ** 63))
+        valid = torch.nonzero(self.counts > 0).reshape(-1)
+        cls = valid[torch.randint(0, len(valid), (B,), generator=g)]
+        r = torch.randint(0, 1 << 27, (B,), generator=g)
+        rows = self.offsets[cls] + r % self.counts[cls]
+        out_x.copy_(self.x.index_select(0, rows))
+        out_y.copy_(self.y.index_select(0, rows))
+
+
+class FinetuneEngine:
+    """What the Supervisor and its saver see of the fine-tune: a global step and a state to snapshot / restore."""
+
+    def __init__(self, trainer):
+        self.trainer = trainer
+        self.global_step = 0
+
+    def state_dict(self):
+        import torch
+        if self.trainer.P.is_cuda:
+            torch.cuda.synchronize(self.trainer.P.device)
+        return {k: v.detach().cpu().numpy().copy() for k, v in self.trainer.state_tensors().items()}
+
+    def load_state_dict(self, sd) -> None:
+        import torch
+        for k, t in self.trainer.state_tensors().items():
+            if k not in sd:
+                raise KeyError("checkpoint holds no %r (written with another optimizer?)" % k)
+            src = torch.as_tensor(np.asarray(sd[k])).reshape(t.shape)
+            if src.numel() != t.numel():
+                raise ValueError("checkpoint %s has %d elements, the model %d (another class count?)" % (k, src.numel(), t.numel()))
+            t.copy_(src.to(t.device, t.dtype))
+        self.global_step = int(np.asarray(sd["step"]).reshape(-1)[0])
+
+
+class FinetuneSaver:
+    """``tf.train.Saver`` of the fine-tune job: ``logdir/model.ckpt-<global_step>`` in the native CRC container."""
+
+    def __init__(self, engine: FinetuneEngine, max_to_keep: int = 3):
+        self.engine, self.max_to_keep, self._kept = engine, max_to_keep, []
+
+    def save(self, save_path: str, global_step=None) -> str:
+        from ..utils import checkpoint as ckpt
+        path = save_path if global_step is None else "%s-%d" % (save_path, global_step)
+        sd = self.engine.state_dict()
+        sd["step"] = np.asarray([self.engine.global_step], np.int32)  # (the host's count: SGD keeps no device step)
+        ckpt.save_tensors(path, {"finetune/" + k: v for k, v in sd.items()})
+        ckpt.update_checkpoint_state(os.path.dirname(os.path.abspath(path)) or ".", path)
+        self._kept.append(path)
+        while self.max_to_keep and len(self._kept) > self.max_to_keep:
+            old = self._kept.pop(0)
+            if old != path and os.path.exists(old):
+                os.remove(old)
+        return path
+
+    def restore(self, path: str) -> int:
+        from ..utils import checkpoint as ckpt
+        t = ckpt.load_tensors(path)
+        self.engine.load_state_dict({k[len("finetune/"):]: v for k, v in t.items() if k.startswith("finetune/")})
+        return self.engine.global_step
+
+
+class _SvTrainer:
+    """The little of a trainer the Supervisor needs."""
+
+    def __init__(self, engine: FinetuneEngine, dp, rank: int, world: int):
+        self.engine, self.dp, self.rank, self.world = engine, dp, rank, world
+
+    def broadcast_state(self, src: int = 0) -> None:
+        import torch
+        import torch.distributed as dist
+        self.dp.broadcast_state(src)
+        t = torch.tensor([self.engine.global_step], dtype=torch.int64)
+        if dist.get_backend() != "gloo":
+            t = t.to(self.engine.trainer.P.device)
+        dist.broadcast(t, src=src)
+        self.engine.global_step = int(t.item())
+
+    def any_rank(self, flag: bool) -> bool:
+        if self.world == 1:
+            return bool(flag)
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        if dist.get_backend() != "gloo":
+            t = t.to(self.engine.trainer.P.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(int(t.item()))
+
+    def synchronize(self) -> None:
+        import torch
+        if self.engine.trainer.P.is_cuda:
+            torch.cuda.synchronize(self.engine.trainer.P.device)
+
+
+def export_graph(trainer, image_lists, FLAGS, seed: int):
+    """``retrained_graph.pb`` + ``retrained_labels.txt`` exactly as the head-only retrain writes them (one GraphDef of
+    Inception-v3 + the new layer, ``retrain1/retrain.py:470-475``), so ``retrain{1,2}/test.py`` loads a fine-tuned network
+    like any other.  Returns the inference network holding the trained weights and moving statistics."""
+    from ..models.inception_v3 import InceptionV3
+    from ..utils.graphdef import write_inception_graphdef
+    net = InceptionV3(device=trainer.P.device if trainer.P.is_cuda else "cpu", seed=seed)
+    trainer.export_to(net)
+    W = trainer.param("final_training_ops/weights/final_weights").detach().cpu().numpy()
+    b = trainer.param("final_training_ops/biases/final_biases").detach().cpu().numpy()
+    write_inception_graphdef(FLAGS.output_graph, net.graph, net.params, W, b, FLAGS.final_tensor_name)
+    with open(FLAGS.output_labels, "w") as f:
+        f.write("\n".join(image_lists.keys()) + "\n")
+    return net
+
+
+def run(FLAGS, image_lists, image_dir: str, rank: int, world: int, device, seed: int, distributed: bool = False,
+        server=None) -> int:
     import torch
 
     from ..data import image_lists as il
     from ..data.bottleneck import Distortion, ImagePreprocessor
     from ..models.inception_train import make_inception_trainer
     from ..models.inception_v3 import InceptionV3
+    from ..models.retrain_head import RetrainHead
     from ..parallel.finetune_dp import FinetuneDataParallel
-    from ..utils import checkpoint as ckpt
     from ..utils.summary import FileWriter, Summary
 
     begin = time.time()
@@ -79,94 +233,167 @@ def run(FLAGS, image_lists, image_dir: str, rank: int, world: int, device, seed:
     trainer = make_inception_trainer("native" if native_ok else "eager", C, B, device, lr=FLAGS.learning_rate,
                                      optimizer=FLAGS.finetune_optimizer, seed=seed, init=init,
                                      double_softmax=FLAGS.double_softmax)
-    dp = FinetuneDataParallel(trainer, bucket_mb=FLAGS.bucket_mb)
+    dp = FinetuneDataParallel(trainer, bucket_mb=FLAGS.bucket_mb, comm=getattr(FLAGS, "comm", "auto"),
+                              grad_dtype=getattr(FLAGS, "finetune_grad_dtype", "fp32"))
+    engine = FinetuneEngine(trainer)
     preproc = ImagePreprocessor(device)
     distortion = Distortion(FLAGS.flip_left_right, FLAGS.random_crop, FLAGS.random_scale, FLAGS.random_brightness)
     rng = random.Random(seed * 7919 + rank)
 
+    # ---- Supervisor (distributed script only, like the reference): restore + broadcast, autosave, stop protocol
+    sv = store = store_server = None
+    writer = FileWriter(os.path.join(FLAGS.summaries_dir, "finetune")) if rank == 0 else None
+    if distributed:
+        from ..parallel import cluster as cl
+        from ..parallel.supervisor import Supervisor
+        if world > 1:
+            store = server.connect_store() if server is not None else None
+            if store is None:
+                store, store_server = cl.job_store(rank, world)
+        sv = Supervisor(_SvTrainer(engine, dp, rank, world), is_chief=(rank == 0), logdir=FLAGS.log_dir,
+                        saver=FinetuneSaver(engine), save_model_secs=FLAGS.save_model_secs, summary_writer=writer,
+                        log_fn=lambda m: _log(rank, m), store=store,
+                        heartbeat_period_s=float(os.environ.get("DTF_HEARTBEAT_PERIOD_S", "5.0")),
+                        fatal_grace_s=float(os.environ.get("DTF_FATAL_GRACE_S", "20")), stop_margin_steps=4)
+        sv.prepare_or_wait_for_session()
+        sv.start_standard_services()
+
+    # ---- data: the training shard and the validation split live in HBM
     t0 = time.time()
-    train_x, train_y = (None, None)
+    sampler = val_sampler = None
     if not distortion.enabled:
         train_x, train_y = _load_split(index, preproc, "training", rank, world, shard=True)
         if train_x is None:
             print("rank %d has no training images" % rank)
             return -1
+        sampler = DeviceBatchSampler(train_x, train_y, C, seed + 1000 * rank)
         _log(rank, "HBM image cache: %d training images on this rank (%.1f MB) in %.2fs" % (
             train_x.shape[0], train_x.numel() * 2 / 1e6, time.time() - t0))
-    train_rows = index.rows_of("training")
-    # class-balanced sampling like get_random_cached_bottlenecks: random class, then random image of that class
-    by_class = {}
-    if train_y is not None:
-        ty = train_y.cpu().numpy()
-        for c in range(C):
-            by_class[c] = np.nonzero(ty == c)[0]
-    gen = torch.Generator(device="cpu").manual_seed(seed + 1000 * rank)
+    val_x, val_y = _load_split(index, preproc, "validation", rank, world, shard=False)
+    if val_x is not None and val_x.shape[0] > 0:
+        val_sampler = DeviceBatchSampler(val_x, val_y, C, seed + 977)
+    labels_list = list(image_lists.keys())
+    xb = torch.empty(B, 299, 299, 8, dtype=torch.bfloat16 if native_ok else torch.float32, device=device)
+    yb = torch.empty(B, dtype=torch.int32, device=device)
+    if sampler is not None and sampler.x.dtype != xb.dtype:
+        xb = xb.to(sampler.x.dtype)
+    val_metrics = torch.zeros(2, dtype=torch.float32, device=device)
 
-    def sample_batch():
-        if distortion.enabled:
-            paths, ys = [], []
-            for _ in range(B):
-                c = rng.randrange(C)
-                label = list(image_lists.keys())[c]
-                paths.append(il.get_image_path(image_lists, label, rng.randrange(il.MAX_NUM_IMAGES_PER_CLASS + 1), image_dir,
-                                               "training"))
-                ys.append(c)
-            return preproc.load(paths, distortion, rng), torch.tensor(ys, dtype=torch.int32, device=device)
-        cls = torch.randint(0, C, (B,), generator=gen).tolist()
-        rows = []
-        for c in cls:
-            pool = by_class[c] if len(by_class[c]) else np.arange(train_x.shape[0])
-            rows.append(int(pool[int(torch.randint(0, len(pool), (1,), generator=gen))]))
-        r = torch.tensor(rows, device=device)
-        return train_x.index_select(0, r), train_y.index_select(0, r)
+    def next_batch():
+        if sampler is not None:
+            sampler.sample_into(xb, yb)
+            return xb, yb
+        paths, ys = [], []
+        for _ in range(B):
+            c = rng.randrange(C)
+            paths.append(il.get_image_path(image_lists, labels_list[c], rng.randrange(il.MAX_NUM_IMAGES_PER_CLASS + 1),
+                                           image_dir, "training"))
+            ys.append(c)
+        return preproc.load(paths, distortion, rng), torch.tensor(ys, dtype=torch.int32, device=device)
 
-    writer = FileWriter(os.path.join(FLAGS.summaries_dir, "finetune")) if rank == 0 else None
+    def validation_accuracy() -> float:
+        """Two class-balanced validation batches (forward only, batch statistics), averaged over the ranks."""
+        if val_sampler is None:
+            return float("nan")
+        val_metrics.zero_()
+        for _ in range(2):
+            val_sampler.sample_into(xb, yb)
+            trainer.evaluate_batch(xb, yb, val_metrics)
+        return dp.mean_scalar(float(val_metrics[1].item()) / (2 * B))
+
     steps = FLAGS.training_steps
+    i = engine.global_step
+    start_step = i
+    rc = 0
     start = time.time()
-    for i in range(steps):
-        x, y = sample_batch()
-        dp.train_step(x, y)
-        if i % FLAGS.eval_step_interval == 0 or i + 1 == steps:
-            loss, acc = dp.mean_metrics()
-            if writer is not None:
-                writer.add_summary(Summary().scalar("cross_entropy", loss).scalar("accuracy", acc), i)
-            _log(rank, "%s: Step %d: Train accuracy = %.1f%% Cross entropy = %f" % (datetime.now(), i, acc * 100, loss))
+    try:
+        while i < steps and not (sv is not None and sv.should_stop()):
+            if FLAGS.fault_inject_step >= 0 and i == FLAGS.fault_inject_step and rank == world - 1:
+                raise RuntimeError("injected fault at step %d" % i)
+            x, y = next_batch()
+            dp.train_step(x, y)
+            i += 1
+            engine.global_step = i
+            st = i - 1
+            if st % FLAGS.eval_step_interval == 0 or i == steps:
+                loss, acc = dp.mean_metrics()
+                vacc = validation_accuracy()
+                if writer is not None:
+                    writer.add_summary(Summary().scalar("cross_entropy", loss).scalar("accuracy", acc)
+                                       .scalar("validation_accuracy", vacc), st)
+                if distributed:
+                    _log(rank, "%s: Step %d: Train accuracy = %.1f%%,Cross entropy = %f,Validation accuracy = %.1f%% (N=%d)" % (
+                        datetime.now(), st, acc * 100, loss, vacc * 100, 2 * B * world))
+                else:
+                    _log(rank, "%s: Step %d: Train accuracy = %.1f%% Cross entropy = %f Validation accuracy = %.1f%%" % (
+                        datetime.now(), st, acc * 100, loss, vacc * 100))
+                err = dp.async_error()
+                if err:
+                    raise RuntimeError("RCCL reported an asynchronous error: %s" % err)
+    except BaseException as e:  # noqa: BLE001
+        rc = 1
+        if sv is not None:
+            sv.request_stop(e)
+        _log(0, "rank %d: fine-tuning aborted: %r" % (rank, e))
+        if sv is None or world == 1:
+            raise
+    finally:
+        if sv is not None:
+            sv.stop(final_save=True)
+
+    def shutdown():
+        if writer is not None:
+            writer.close()
+        if store is not None:
+            store.close()
+        if store_server is not None:
+            store_server.stop()
+        dp.close()
+
+    if rc != 0 or (sv is not None and i < steps):
+        _log(rank, "stopped at global step %d of %d (%s)" % (i, steps, (sv.stop_reason if sv is not None else None) or "exception"))
+        shutdown()
+        return rc or 3
     if device.type == "cuda":
         torch.cuda.synchronize()
     train_time = time.time() - start
     _log(rank, "Training time: %3.2fs" % train_time)
-    if steps:
-        _log(rank, "Fine-tune throughput: %.1f images/sec (global batch %d, %d GPU%s)" % (
-            steps * B * world / max(train_time, 1e-9), B * world, world, "" if world == 1 else "s"))
+    if i > start_step:
+        _log(rank, "Fine-tune throughput: %.1f images/sec (global batch %d, %d GPU%s; batch sampling %s)" % (
+            (i - start_step) * B * world / max(train_time, 1e-9), B * world, world, "" if world == 1 else "s",
+            "on the device" if sampler is not None else "decoded and distorted per step"))
     in_sync = dp.replicas_in_sync()
     _log(rank, "replicas in sync: %s" % in_sync)
 
-    # ---- final test accuracy with the trained weights folded into the inference network (moving statistics)
-    test_acc = float("nan")
+    # ---- export + final test accuracy with the trained weights folded into the inference network (moving statistics)
     if rank == 0:
+        k_cal = int(getattr(FLAGS, "finetune_bn_recalibrate", 8))
+        if k_cal > 0 and sampler is not None and hasattr(trainer, "bn_momentum"):
+            # The moving statistics follow the batch statistics with TensorFlow's decay of 0.9997: after a short run they
+            # are still the initial ones and the frozen network would not be the network that was trained.  Re-estimate
+            # them as the plain average of the batch statistics over k training batches (momentum (j-1)/j at batch j).
+            keep = trainer.bn_momentum
+            for j in range(1, k_cal + 1):
+                sampler.sample_into(xb, yb)
+                trainer.bn_momentum = (j - 1.0) / j
+                trainer.forward(xb, training=True)
+            if k_cal % 2:  # (an even number of forwards keeps the statistic accumulators' alternation, see evaluate_batch)
+                trainer.forward(xb, training=False)
+            trainer.bn_momentum = keep
+            _log(rank, "batch-norm moving statistics re-estimated over %d training batches for the export" % k_cal)
+        net = export_graph(trainer, image_lists, FLAGS, seed)
         test_x, test_y = _load_split(index, preproc, "testing", 0, 1, shard=False)
         if test_x is not None and native_ok:
-            net = InceptionV3(device, seed=seed)
-            trainer.export_to(net)
-            W = trainer.param("final_training_ops/weights/final_weights")
-            b = trainer.param("final_training_ops/biases/final_biases")
+            head = RetrainHead(C, device)
+            head.load_tf_tensors({"final_training_ops/weights/final_weights":
+                                  trainer.param("final_training_ops/weights/final_weights").detach().cpu().numpy(),
+                                  "final_training_ops/biases/final_biases":
+                                  trainer.param("final_training_ops/biases/final_biases").detach().cpu().numpy()})
             correct = 0
             for j in range(0, test_x.shape[0], 64):
-                feats = net.forward(test_x[j:j + 64].contiguous(), use_graph=False)
-                correct += int(((feats @ W + b).argmax(1) == test_y[j:j + 64].long()).sum())
-            test_acc = correct / test_x.shape[0]
-            print("Final test accuracy = %.1f%% (N=%d)" % (test_acc * 100, test_x.shape[0]), flush=True)
-        tensors = {k: trainer.layout.view(trainer.P, k).detach().cpu().numpy() for k in trainer.layout.entries}
-        if hasattr(trainer, "moving_mean"):
-            for name, s in trainer.graph.convs.items():
-                o = trainer.stat_off[name]
-                tensors[name + "/batchnorm/moving_mean"] = trainer.moving_mean[o:o + s.cout].cpu().numpy()
-                tensors[name + "/batchnorm/moving_variance"] = trainer.moving_var[o:o + s.cout].cpu().numpy()
-        tensors["_dtf/labels"] = np.frombuffer("\n".join(image_lists.keys()).encode(), np.uint8).copy()
-        tensors["_dtf/finetuned"] = np.asarray(1, np.int64)
-        ckpt.save_tensors(FLAGS.output_graph, tensors)
-        with open(FLAGS.output_labels, "w") as f:
-            f.write("\n".join(image_lists.keys()) + "\n")
-        writer.close()
+                probs = head.predict(net.forward(test_x[j:j + 64].contiguous(), use_graph=False))  # (the head's own kernel)
+                correct += int((probs.argmax(1) == test_y[j:j + 64].long()).sum())
+            print("Final test accuracy = %.1f%% (N=%d)" % (100.0 * correct / test_x.shape[0], test_x.shape[0]), flush=True)
     _log(rank, "Total time: %3.2fs:" % (time.time() - begin))
+    shutdown()
     return 0 if in_sync else 3

@@ -191,12 +191,13 @@ def run(FLAGS, distributed: bool) -> int:
         return -1
     if getattr(FLAGS, "finetune", False):
         from . import finetune
-        rc = finetune.run(FLAGS, image_lists, image_dir, rank, world, device, seed)
+        rc = finetune.run(FLAGS, image_lists, image_dir, rank, world, device, seed, distributed=distributed, server=server)
         if server is not None:
             server.report_done()
         if world > 1:
             import torch.distributed as dist
-            dist.barrier()
+            if rc == 0:
+                dist.barrier()
             dist.destroy_process_group()
         return rc
     index = il.build_image_index(image_lists, image_dir)
@@ -480,26 +481,33 @@ def run(FLAGS, distributed: bool) -> int:
             (steps - start_step) * FLAGS.train_batch_size * world / max(train_time, 1e-9), FLAGS.train_batch_size * world))
 
     if rank == 0:
-        tensors = dict(head.tf_tensors())
-        tensors["_dtf/final_tensor_name"] = np.frombuffer(FLAGS.final_tensor_name.encode(), np.uint8).copy()
-        tensors["_dtf/backbone"] = np.frombuffer(backbone_kind.encode(), np.uint8).copy()
-        tensors["_dtf/backbone_seed"] = np.asarray(seed, np.int64)
-        # the frozen graph holds the whole network (retrain1/retrain.py:470-473: convert_variables_to_constants over the
-        # imported Inception graph + the new layer): the backbone's folded filters and biases travel in the bundle, so
-        # test.py reproduces the features the head was trained on whatever the weights' origin (pretrained .pb, .npz, or
-        # random-init + calibrated batch-norm statistics)
-        if backbone_kind == "inception":
-            tensors.update(net.export_folded())
-        else:
-            tensors["backbone/tiny/proj"] = backbone.proj.detach().cpu().numpy()
-        tensors["_dtf/labels"] = np.frombuffer("\n".join(image_lists.keys()).encode(), np.uint8).copy()
-        ckpt.save_tensors(FLAGS.output_graph, tensors)
-        # the frozen head as a real GraphDef too (reference tensor names), for TensorFlow-side tooling
-        from ..utils.graphdef import write_retrained_graph
         tf_t = head.tf_tensors()
-        write_retrained_graph(os.path.splitext(FLAGS.output_graph)[0] + "_frozen_head.pb",
-                              tf_t["final_training_ops/weights/final_weights"],
-                              tf_t["final_training_ops/biases/final_biases"], FLAGS.final_tensor_name)
+        if backbone_kind == "inception":
+            # retrained_graph.pb is what the reference writes (retrain1/retrain.py:470-473: convert_variables_to_constants
+            # over the imported Inception graph + the new layer): ONE serialized GraphDef with the 2015 graph's node names,
+            # DecodeJpeg/contents ... pool_3/_reshape -> final_training_ops -> final_result.  test.py reads it back without
+            # TensorFlow and reproduces the features the head was trained on, whatever the weights' origin (pretrained .pb,
+            # .npz, or random-init + calibrated batch-norm statistics).
+            from ..utils.graphdef import write_inception_graphdef
+            n_nodes = write_inception_graphdef(FLAGS.output_graph, net.graph, net.params,
+                                               tf_t["final_training_ops/weights/final_weights"],
+                                               tf_t["final_training_ops/biases/final_biases"], FLAGS.final_tensor_name)
+            _log(rank, "frozen graph: %s (%d nodes, %.1f MB)" % (FLAGS.output_graph, n_nodes,
+                                                                  os.path.getsize(FLAGS.output_graph) / 1e6))
+        else:
+            # the CPU stand-in backbone has no TensorFlow graph to name: the native tensor container
+            tensors = dict(tf_t)
+            tensors["_dtf/final_tensor_name"] = np.frombuffer(FLAGS.final_tensor_name.encode(), np.uint8).copy()
+            tensors["_dtf/backbone"] = np.frombuffer(backbone_kind.encode(), np.uint8).copy()
+            tensors["_dtf/backbone_seed"] = np.asarray(seed, np.int64)
+            tensors["backbone/tiny/proj"] = backbone.proj.detach().cpu().numpy()
+            tensors["_dtf/labels"] = np.frombuffer("\n".join(image_lists.keys()).encode(), np.uint8).copy()
+            ckpt.save_tensors(FLAGS.output_graph, tensors)
+            # the frozen head as a GraphDef too (reference tensor names), for TensorFlow-side tooling
+            from ..utils.graphdef import write_retrained_graph
+            write_retrained_graph(os.path.splitext(FLAGS.output_graph)[0] + "_frozen_head.pb",
+                                  tf_t["final_training_ops/weights/final_weights"],
+                                  tf_t["final_training_ops/biases/final_biases"], FLAGS.final_tensor_name)
         with open(FLAGS.output_labels, "w") as f:
             f.write("\n".join(image_lists.keys()) + "\n")
         train_writer.close()

@@ -34,25 +34,33 @@ def run(args) -> List[str]:
 
     lines = open(args.labels).readlines()
     uid_to_human = {uid: line.strip("\n") for uid, line in enumerate(lines)}  # retrain1/test.py:10-16
-    t = ckpt.load_tensors(args.graph)
-    backbone_kind = bytes(t["_dtf/backbone"]).decode()
-    seed = int(t["_dtf/backbone_seed"])
     use_cuda = torch.cuda.is_available() and args.device != "cpu"
     device = torch.device("cuda" if use_cuda else "cpu")
-    C = t["final_training_ops/biases/final_biases"].shape[0]
-    head = RetrainHead(C, device)
-    head.load_tf_tensors(t)
-    if backbone_kind == "inception":
+    from ..utils import graphdef as gd
+    if gd.is_graphdef(args.graph):
+        # the reference's artefact (retrain1/test.py:26-33): a serialized GraphDef holding Inception-v3 + the new layer;
+        # parsed without TensorFlow, fed DecodeJpeg/contents -> final_result
         if not use_cuda:
-            raise RuntimeError("this bundle was trained on the Inception-v3 backbone, which needs the GPU path")
+            raise RuntimeError("this graph holds the Inception-v3 backbone, which needs the GPU path")
+        layers, fw, fb, final_name, ops = gd.read_retrained_graph(args.graph)
         from ..models.inception_v3 import InceptionV3
-        net = InceptionV3(device, seed=seed)
-        if "backbone/conv/folded_weights" not in t:
-            raise RuntimeError("%s carries no backbone (written by an older build): re-run retrain.py" % args.graph)
-        net.load_folded(t)  # the bundle is self-contained, like the reference's frozen graph (retrain1/test.py:26-39)
+        net = InceptionV3(device, seed=0)
+        if sum(1 for _n, o, _i in ops if o == "Conv2D") != len(net.graph.convs) or set(layers) != set(net.graph.convs):
+            raise RuntimeError("%s is not the 2015 Inception-v3 topology (%d conv layers)" % (args.graph, len(layers)))
+        net.load_tf_weights(layers)
+        head = RetrainHead(int(fb.shape[0]), device, final_tensor_name=final_name)
+        head.load_tf_tensors({"final_training_ops/weights/final_weights": fw, "final_training_ops/biases/final_biases": fb})
         backbone = net.forward
     else:
-        backbone = TinyBackbone(device, seed=seed)
+        t = ckpt.load_tensors(args.graph)
+        backbone_kind = bytes(t["_dtf/backbone"]).decode() if "_dtf/backbone" in t else "?"
+        if backbone_kind != "tiny":
+            raise RuntimeError("%s: not a GraphDef and not a stand-in-backbone bundle (written by an older build?): "
+                               "re-run retrain.py" % args.graph)
+        C = t["final_training_ops/biases/final_biases"].shape[0]
+        head = RetrainHead(C, device)
+        head.load_tf_tensors(t)
+        backbone = TinyBackbone(device, seed=int(t["_dtf/backbone_seed"]))
         if "backbone/tiny/proj" in t:
             backbone.proj = torch.from_numpy(np.asarray(t["backbone/tiny/proj"], np.float32)).to(device)
     files = walk_images(args.imgs, (".jpg", ".jpeg"))

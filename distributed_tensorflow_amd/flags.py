@@ -161,6 +161,12 @@ def build_retrain_parser(distributed: bool) -> argparse.ArgumentParser:
     p.add_argument("--finetune_batch_size", type=int, default=32, help="Per-GPU batch of the fine-tune step.")
     p.add_argument("--finetune_optimizer", type=str, default="sgd", choices=["sgd", "adam"])
     p.add_argument("--bucket_mb", type=float, default=25.0, help="Gradient all-reduce bucket size (fine-tune DP).")
+    p.add_argument("--finetune_bn_recalibrate", type=int, default=8,
+                   help="re-estimate the batch-norm moving statistics over this many training batches before the export "
+                        "(0 = keep the running averages, decay 0.9997: right for long runs only)")
+    p.add_argument("--finetune_grad_dtype", type=str, default="fp32", choices=["fp32", "bf16"],
+                   help="wire format of the fine-tune's gradient buckets (bf16: half the xGMI bytes; the optimizer keeps "
+                        "fp32 master weights either way)")
     p.add_argument("--log_dir", type=str, default="./logs",
                    help="Supervisor logdir of retrain2 (retrain2/retrain2.py:424: ./logs/model.ckpt-<global_step>)")
     p.add_argument("--synthetic_classes", type=int, default=5)

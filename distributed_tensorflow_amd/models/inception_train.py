@@ -539,6 +539,32 @@ class InceptionTrainer:
         loss_sum, correct = self._last_metrics.tolist()
         return loss_sum / self.B, correct / self.B
 
+    def evaluate_batch(self, x: torch.Tensor, labels: torch.Tensor, out: torch.Tensor) -> None:
+        """Forward only (batch statistics, moving statistics untouched): the batch's loss sum and correct count are ADDED
+        to ``out`` (fp32 [2] on the device; no host sync).  Call it an even number of times between two training steps:
+        the forward alternates between two sets of statistic accumulators, and a captured step graph assumes the set it
+        was captured with."""
+        from .retrain_head import RetrainHeadParams
+        import ctypes as C
+        self.forward(x, training=False)
+        if not hasattr(self, "_eval_labels"):
+            self._eval_labels = torch.empty(self.B, dtype=torch.int32, device=self.device)
+        self._eval_labels.copy_(labels)
+        p = RetrainHeadParams()
+        p.cache, p.labels_all, p.rows = self.feat.data_ptr(), self._eval_labels.data_ptr(), None
+        p.W = self.param("final_training_ops/weights/final_weights").data_ptr()
+        p.b = self.param("final_training_ops/biases/final_biases").data_ptr()
+        p.B, p.C, p.grad_scale, p.double_softmax, p.training = self.B, self.C, 0.0, int(self.double_softmax), 0
+        p.probs, p.pred, p.dz, p.metrics = None, None, None, out.data_ptr()
+        self.native.check(self.lib.dtf_retrain_head_fwd(C.byref(p), torch.cuda.current_stream().cuda_stream), "head eval")
+
+    def state_tensors(self) -> Dict[str, torch.Tensor]:
+        """Everything a checkpoint of the fine-tune holds: parameters, optimizer slots, moving statistics, step counter."""
+        out = {"P": self.P, "moving_mean": self.moving_mean, "moving_var": self.moving_var, "step": self.step_t}
+        if self.optimizer == "adam":
+            out.update(M=self.M, V=self.V)
+        return out
+
     def flops_per_step(self) -> float:
         from .inception_v3 import graph_flops
         return 3.0 * graph_flops(self.graph) * self.B
@@ -668,6 +694,29 @@ class EagerInceptionTrainer:
 
     def metrics(self) -> Tuple[float, float]:
         return float(self.last_loss), float(self.last_correct) / self.B
+
+    @torch.no_grad()
+    def evaluate_batch(self, x: torch.Tensor, labels: torch.Tensor, out: torch.Tensor) -> None:
+        params = {k: self.layout.view(self.P, k) for k in self.layout.entries}
+        feat = torch_forward_train(self.graph, params, x[..., :3].float().permute(0, 3, 1, 2).contiguous())
+        logits = feat @ params["final_training_ops/weights/final_weights"] + params["final_training_ops/biases/final_biases"]
+        z = torch.softmax(logits, 1) if self.double_softmax else logits
+        out[0] += F.cross_entropy(z, labels.long(), reduction="sum")
+        out[1] += (logits.argmax(1) == labels.long()).float().sum()
+
+    def state_tensors(self) -> Dict[str, torch.Tensor]:
+        return {"P": self.P, "step": self.step_t}
+
+    def export_to(self, model: InceptionV3) -> None:
+        """Weights into an inference network.  This CPU plumbing path keeps no moving statistics (training-mode batch
+        norm only): the exported batch-norm constants are identity statistics."""
+        layers = {}
+        for name, s in self.graph.convs.items():
+            w = self.param(name + "/conv2d_params").detach().cpu()
+            layers[name] = {"weights": w[:, :, :model.params[name]["weights"].shape[2], :].contiguous().numpy(),
+                            "gamma": self.param(name + "/batchnorm/gamma").cpu().numpy(),
+                            "beta": self.param(name + "/batchnorm/beta").cpu().numpy()}
+        model.load_tf_weights(layers)
 
 
 def calibrate_batchnorm(model: InceptionV3, x: torch.Tensor) -> None:

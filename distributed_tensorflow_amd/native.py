@@ -150,6 +150,8 @@ def hip() -> C.CDLL:
         _sig(lib, "dtf_head", I, [C.POINTER(HeadParams), I, P])
         _sig(lib, "dtf_adam_tf", I, [C.POINTER(OptimParams), P])
         _sig(lib, "dtf_sgd", I, [C.POINTER(OptimParams), P])
+        _sig(lib, "dtf_cast_f32_bf16", I, [P, P, C.c_long, P])
+        _sig(lib, "dtf_cast_bf16_f32", I, [P, P, C.c_long, P])
         _sig(lib, "dtf_mnist_fwd_bwd", I, [C.POINTER(MnistEngineStruct), I, P])
         _sig(lib, "dtf_mnist_apply", I, [C.POINTER(MnistEngineStruct), P])
         _sig(lib, "dtf_mnist_apply_part", I, [C.POINTER(MnistEngineStruct), I, P])
@@ -176,6 +178,7 @@ def hip() -> C.CDLL:
         _sig(lib, "dtf_avgpool3x3_same", I, [P, P] + [I] * 6 + [P])
         _sig(lib, "dtf_global_avgpool", I, [P, P, I, I, I, P])
         _sig(lib, "dtf_sample_rows", I, [P, P, I, I, C.c_ulonglong, C.c_ulonglong, P, P])
+        _sig(lib, "dtf_gather_rows", I, [P, P, P, C.c_long, I, P, P, P])
         _sig(lib, "dtf_retrain_head_fwd", I, [P, P])
         _sig(lib, "dtf_retrain_head_bwd", I, [P, P, P, I, I, P, P, P, P, F, P])
         _sig(lib, "dtf_retrain_head_dx", I, [P, P, P, I, I, P, P])

@@ -29,6 +29,7 @@ def _signatures(lib) -> None:
     lib.dtf_rccl_unique_id.argtypes, lib.dtf_rccl_unique_id.restype = [P], I
     lib.dtf_rccl_init.argtypes, lib.dtf_rccl_init.restype = [P, I, I], P
     lib.dtf_rccl_allreduce_f32.argtypes, lib.dtf_rccl_allreduce_f32.restype = [P, P, P, L, I, P], I
+    lib.dtf_rccl_allreduce_bf16.argtypes, lib.dtf_rccl_allreduce_bf16.restype = [P, P, L, P], I
     lib.dtf_rccl_allreduce_f32_multi.argtypes, lib.dtf_rccl_allreduce_f32_multi.restype = [P, P, P, I, P], I
     lib.dtf_rccl_broadcast.argtypes, lib.dtf_rccl_broadcast.restype = [P, P, L, I, P], I
     lib.dtf_rccl_allgather.argtypes, lib.dtf_rccl_allgather.restype = [P, P, P, L, P], I
@@ -131,7 +132,11 @@ class RcclCommunicator:
             raise RcclError("%s failed (%d): %s" % (what, rc, self.lib.dtf_rccl_last_error().decode()))
 
     def all_reduce(self, t: torch.Tensor, stream=None, op: str = "sum") -> None:
-        """In-place fp32 sum (or max) over the ranks."""
+        """In-place fp32 sum (or max), or bf16 sum, over the ranks."""
+        if t.dtype == torch.bfloat16:
+            assert t.is_cuda and t.is_contiguous() and op == "sum"
+            self._check(self.lib.dtf_rccl_allreduce_bf16(self._h, t.data_ptr(), t.numel(), self._st(stream)), "ncclAllReduce")
+            return
         assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
         self._check(self.lib.dtf_rccl_allreduce_f32(self._h, t.data_ptr(), t.data_ptr(), t.numel(), int(op == "max"),
                                                     self._st(stream)), "ncclAllReduce")

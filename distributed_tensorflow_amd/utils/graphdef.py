@@ -314,3 +314,179 @@ def write_retrained_graph(path: str, final_weights: np.ndarray, final_biases: np
         encode_op_node(final_tensor_name, "Softmax", ("final_training_ops/Wx_plus_b/add",)),
     )
     write_graph_consts(path, {w: np.asarray(final_weights, np.float32), b: np.asarray(final_biases, np.float32)}, nodes)
+
+
+# ----------------------------------------------------------------------------- the whole frozen network as a GraphDef
+def _attr(key: str, value_payload: bytes) -> bytes:
+    """One ``map<string, AttrValue>`` entry of a NodeDef (field 5)."""
+    return _enc_field(5, 2, _enc_field(1, 2, key.encode()) + _enc_field(2, 2, value_payload))
+
+
+def attr_type(dt: int) -> bytes: return _enc_field(6, 0, dt)
+def attr_s(s: bytes) -> bytes: return _enc_field(2, 2, s)
+def attr_b(b: bool) -> bytes: return _enc_field(5, 0, 1 if b else 0)
+def attr_i(i: int) -> bytes: return _enc_field(3, 0, i)
+def attr_f(f: float) -> bytes: return _enc_field(4, 5, struct.pack("<f", f))
+def attr_ints(vals) -> bytes: return _enc_field(1, 2, _enc_field(3, 2, b"".join(_enc_varint(int(v)) for v in vals)))  # list { i: [...] }
+
+
+def encode_node(name: str, op: str, inputs=(), attrs: Optional[Dict[str, bytes]] = None) -> bytes:
+    body = _enc_field(1, 2, name.encode()) + _enc_field(2, 2, op.encode())
+    for i in inputs:
+        body += _enc_field(3, 2, i.encode())
+    for k, v in (attrs or {}).items():
+        body += _attr(k, v)
+    return body
+
+
+def attr_list_ints(raw) -> List[int]:
+    """Decode an AttrValue holding ``list { i: ... }`` (strides / ksize)."""
+    out: List[int] = []
+    for fno, _wt, v in _fields(raw):
+        if fno == 1:
+            for f2, w2, v2 in _fields(v):
+                if f2 == 3:
+                    _packed_or_single(out, w2, v2, None, 0)
+    return out
+
+
+HEAD_W = "final_training_ops/weights/final_weights"
+HEAD_B = "final_training_ops/biases/final_biases"
+JPEG_DATA_TENSOR = "DecodeJpeg/contents"          # retrain1/retrain.py:34
+RESIZED_INPUT_TENSOR = "ResizeBilinear"           # :35
+BOTTLENECK_TENSOR = "pool_3/_reshape"             # :30
+
+
+def write_inception_graphdef(path: str, graph, params, head_w: np.ndarray, head_b: np.ndarray,
+                             final_tensor_name: str = "final_result") -> int:
+    """``retrained_graph.pb`` as the reference writes it (``retrain1/retrain.py:470-473``:
+    ``convert_variables_to_constants`` over the imported Inception graph + the new layer): ONE serialized GraphDef that
+    holds the whole network under the 2015 graph's names [ext] —
+
+    * ``DecodeJpeg/contents`` -> DecodeJpeg -> Cast -> ExpandDims -> ``ResizeBilinear`` (299x299) -> Sub 128 -> Mul 1/128;
+    * per conv layer ``<L>/conv2d_params`` (HWIO), ``<L>/Conv2D``, ``<L>/batchnorm/{beta,gamma,moving_mean,
+      moving_variance}``, ``<L>/batchnorm`` (BatchNormWithGlobalNormalization, eps 1e-3), ``<L>`` (Relu);
+    * MaxPool / AvgPool nodes, ``<block>/join`` Concat nodes (channel axis 3), ``pool_3`` (8x8 AvgPool),
+      ``pool_3/_reshape``;
+    * ``final_training_ops/...`` MatMul + add and the Softmax named ``final_tensor_name``.
+
+    ``graph``: ``models.inception_v3.build_graph()``; ``params``: ``{layer: {weights, beta, gamma, moving_mean,
+    moving_variance}}`` (torch tensors or arrays).  Returns the number of nodes written."""
+    F = attr_type(DT_FLOAT)
+    nodes: List[bytes] = []
+
+    def const(name: str, arr) -> str:
+        nodes.append(encode_const_node(name, np.asarray(arr)))
+        return name
+
+    def node(name, op, inputs=(), attrs=None) -> str:
+        nodes.append(encode_node(name, op, inputs, attrs))
+        return name
+
+    # ---- the input pipeline inside the graph (component C41)
+    node(JPEG_DATA_TENSOR, "Placeholder", (), {"dtype": attr_type(DT_STRING)})
+    node("DecodeJpeg", "DecodeJpeg", (JPEG_DATA_TENSOR,), {"channels": attr_i(3)})
+    node("Cast", "Cast", ("DecodeJpeg",), {"SrcT": attr_type(DT_UINT8), "DstT": F})
+    const("ExpandDims/dim", np.asarray(0, np.int32))
+    node("ExpandDims", "ExpandDims", ("Cast", "ExpandDims/dim"), {"T": F})
+    const("ResizeBilinear/size", np.asarray([299, 299], np.int32))
+    node(RESIZED_INPUT_TENSOR, "ResizeBilinear", ("ExpandDims", "ResizeBilinear/size"), {"T": F, "align_corners": attr_b(False)})
+    const("Sub/y", np.asarray(128.0, np.float32))
+    node("Sub", "Sub", (RESIZED_INPUT_TENSOR, "Sub/y"), {"T": F})
+    const("Mul/y", np.asarray(1.0 / 128.0, np.float32))
+    node("Mul", "Mul", ("Sub", "Mul/y"), {"T": F})
+
+    producers: Dict[str, List[Tuple[int, str]]] = {"input": [(0, "Mul")]}
+    joined: Dict[str, str] = {}
+
+    def tensor_of(buf: str) -> str:
+        """The node that holds buffer ``buf``: its single producer, or a Concat over the producers' channel slices."""
+        ps = sorted(producers[buf])
+        if len(ps) == 1:
+            return ps[0][1]
+        if buf not in joined:
+            const(buf + "/join/concat_dim", np.asarray(3, np.int32))
+            joined[buf] = node(buf + "/join", "Concat", [buf + "/join/concat_dim"] + [n for _o, n in ps],
+                               {"T": F, "N": attr_i(len(ps))})
+        return joined[buf]
+
+    def pool_attrs(k: int, stride: int, padding: bytes) -> Dict[str, bytes]:
+        return {"T": F, "ksize": attr_ints([1, k, k, 1]), "strides": attr_ints([1, stride, stride, 1]), "padding": attr_s(padding)}
+
+    for op in graph.ops:
+        src = tensor_of(op.src)
+        if op.kind == "conv":
+            s = op.conv
+            p = params[s.name]
+            as_np = lambda t: np.ascontiguousarray(np.asarray(t.detach().cpu() if hasattr(t, "detach") else t, np.float32))
+            w = const(s.name + "/conv2d_params", as_np(p["weights"]))
+            valid = s.pad == (0, 0) and (s.kh > 1 or s.kw > 1)
+            conv = node(s.name + "/Conv2D", "Conv2D", (src, w),
+                        {"T": F, "strides": attr_ints([1, s.stride, s.stride, 1]), "padding": attr_s(b"VALID" if valid else b"SAME"),
+                         "use_cudnn_on_gpu": attr_b(True)})
+            bn = [const("%s/batchnorm/%s" % (s.name, k), as_np(p[k])) for k in ("moving_mean", "moving_variance", "beta", "gamma")]
+            node(s.name + "/batchnorm", "BatchNormWithGlobalNormalization", [conv] + bn,
+                 {"T": F, "variance_epsilon": attr_f(1e-3), "scale_after_normalization": attr_b(False)})
+            out = node(s.name, "Relu", (s.name + "/batchnorm",), {"T": F})
+        elif op.kind == "maxpool":
+            name = op.dst[:-4] if op.dst.endswith(":out") else op.dst + "/pool"
+            out = node(name, "MaxPool", (src,), pool_attrs(3, op.stride, b"VALID"))
+        elif op.kind == "avgpool":
+            out = node(op.dst[:-4], "AvgPool", (src,), pool_attrs(3, 1, b"SAME"))
+        elif op.kind == "gap":
+            out = node("pool_3", "AvgPool", (src,), pool_attrs(8, 1, b"VALID"))
+        else:
+            raise ValueError("unknown op kind %r" % op.kind)
+        producers.setdefault(op.dst, []).append((op.dst_off, out))
+    const(BOTTLENECK_TENSOR + "/shape", np.asarray([1, 2048], np.int32))
+    node(BOTTLENECK_TENSOR, "Reshape", ("pool_3", BOTTLENECK_TENSOR + "/shape"), {"T": F})
+    # ---- the new layer (retrain1/retrain.py:262-279)
+    const(HEAD_W, np.asarray(head_w, np.float32))
+    const(HEAD_B, np.asarray(head_b, np.float32))
+    node("final_training_ops/Wx_plus_b/MatMul", "MatMul", (BOTTLENECK_TENSOR, HEAD_W),
+         {"T": F, "transpose_a": attr_b(False), "transpose_b": attr_b(False)})
+    node("final_training_ops/Wx_plus_b/add", "Add", ("final_training_ops/Wx_plus_b/MatMul", HEAD_B), {"T": F})
+    node(final_tensor_name, "Softmax", ("final_training_ops/Wx_plus_b/add",), {"T": F})
+    with open(path, "wb") as f:
+        for body in nodes:
+            f.write(_enc_field(1, 2, body))
+    return len(nodes)
+
+
+def is_graphdef(path: str) -> bool:
+    """A serialized GraphDef starts with a NodeDef field (tag 0x0a); the native checkpoint container with its magic."""
+    with open(path, "rb") as f:
+        head = f.read(8)
+    return len(head) > 0 and head[0] == 0x0A and not head.startswith(b"DTFCKPT")
+
+
+def read_retrained_graph(path: str):
+    """What ``retrain1/test.py:26-39`` gets from ``retrained_graph.pb``: the backbone's per-layer weights, the new layer and
+    the name of the output tensor (the Softmax that reads the new layer's ``add``).  Also checks that the file is the network
+    it claims to be: the reference's tensor names exist and every conv layer has its five constants.
+    Returns (layers, final_weights, final_biases, final_tensor_name, ops)."""
+    consts: Dict[str, np.ndarray] = {}
+    ops: List[Tuple[str, str, List[str]]] = []
+    for n in iter_nodes(path):
+        ops.append((n["name"], n["op"], n["input"]))
+        if n["op"] == "Const" and "value" in n["attr"] and attr_value(n["attr"].get("dtype")) == DT_FLOAT:
+            consts[n["name"]] = np.array(attr_value(n["attr"]["value"]))
+    names = {n for n, _o, _i in ops}
+    for need in (JPEG_DATA_TENSOR, RESIZED_INPUT_TENSOR, BOTTLENECK_TENSOR, HEAD_W, HEAD_B):
+        if need not in names:
+            raise ValueError("%s: no node named %r (not a retrained Inception-v3 graph)" % (path, need))
+    final = [n for n, o, i in ops if o == "Softmax" and i and i[0].startswith("final_training_ops/")]
+    if len(final) != 1:
+        raise ValueError("%s: expected one Softmax over the new layer, found %s" % (path, final))
+    layers: Dict[str, Dict[str, np.ndarray]] = {}
+    for name, arr in consts.items():
+        if name.endswith("/conv2d_params"):
+            layers.setdefault(name[:-len("/conv2d_params")], {})["weights"] = arr
+        else:
+            for k in _BN_KEYS:
+                if name.endswith("/batchnorm/" + k):
+                    layers.setdefault(name[:-len("/batchnorm/" + k)], {})[k] = arr
+    bad = [k for k, v in layers.items() if set(v) != {"weights"} | set(_BN_KEYS)]
+    if bad:
+        raise ValueError("%s: incomplete conv layers %s" % (path, bad[:4]))
+    return layers, consts[HEAD_W], consts[HEAD_B], final[0], ops

@@ -343,7 +343,15 @@ x = torch.zeros(B, 299, 299, 8, device="cuda"); x[..., :3] = torch.randn(B, 299,
 y = torch.tensor([0, 1, 2, 1], device="cuda", dtype=torch.int32)
 a = InceptionTrainer(3, B, "cuda", lr=0.01, seed=2)
 b = InceptionTrainer(3, B, "cuda", lr=0.01, seed=2)
-dp = FinetuneDataParallel(a, bucket_mb=20.0, force_collectives=True)
+dp = FinetuneDataParallel(a, bucket_mb=20.0, force_collectives=True, grad_dtype=sys.argv[2])
+# no torch.distributed collective may run inside the step: the buckets go through the framework's own communicator
+calls = {"n": 0}
+_orig = dist.all_reduce
+def _counting(*a_, **k_):
+    calls["n"] += 1
+    return _orig(*a_, **k_)
+dev0 = dp.check_exchange(x, y)           # production exchange vs the host-ordered process-group sum (no step applied)
+dist.all_reduce = _counting
 # Two runs of the same random-init step are not comparable number by number: fp32 atomics (dW split-K, BN statistics)
 # change the rounding, bf16 flips follow, and the 47-layer random-init BatchNorm net amplifies them chaotically
 # (measured: two plain trainers differ by ~100% of the update norm at B=4).  So the RCCL path is checked against the
@@ -355,13 +363,22 @@ for _ in range(6):
     b.train_step(x, y)
     la.append(a.metrics()[0]); lb.append(b.metrics()[0])
 torch.cuda.synchronize()
+in_step = calls["n"]
+dist.all_reduce = _orig
 print(json.dumps({"la": la, "lb": lb, "buckets": len(dp.buckets.ranges), "ncoll": dp.last_num_collectives,
-                  "sync": dp.replicas_in_sync(), "gmax": float(a.G.abs().max()), "steps": int(a.step_t.item())}))
+                  "sync": dp.replicas_in_sync(), "gmax": float(a.G.abs().max()), "steps": int(a.step_t.item()),
+                  "transport": dp.transport, "wire": dp.grad_dtype, "pg_collectives_in_steps": in_step, "dev": dev0,
+                  "async_error": dp.async_error()}))
+dp.close()
 dist.destroy_process_group()
 """
 
 
-def test_finetune_bucketed_allreduce_over_rccl_single_rank(tmp_path):
+@pytest.mark.parametrize("wire", ["fp32", "bf16"])
+def test_finetune_bucketed_allreduce_over_rccl_single_rank(tmp_path, wire):
+    """The fine-tune's gradient buckets travel through the framework's OWN communicator (``csrc/hip/rccl_comm.hip``) on a side
+    stream fed by the readiness hook: zero ``torch.distributed`` collectives inside the step, the exchange verified against
+    the host-ordered sum (reference transport: ``/root/reference/retrain2/retrain2.py:377,411-416``)."""
     import json
     import os
     import subprocess
@@ -369,10 +386,13 @@ def test_finetune_bucketed_allreduce_over_rccl_single_rank(tmp_path):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "rccl_ft.py"
     script.write_text(_RCCL_FT)
-    r = subprocess.run([sys.executable, str(script), repo], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    r = subprocess.run([sys.executable, str(script), repo, wire], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["buckets"] >= 3 and out["ncoll"] == out["buckets"] and out["sync"] is True and out["steps"] == 6
+    assert out["transport"] == "rccl-native" and out["wire"] == wire and out["pg_collectives_in_steps"] == 0, out
+    assert out["dev"] < (2e-2 if wire == "bf16" else 1e-5) and out["async_error"] is None, out
     assert out["gmax"] == 0.0
     assert abs(out["la"][0] - out["lb"][0]) < 0.05  # same weights, same batch: the first loss agrees
     assert out["la"][-1] < out["la"][0] and out["lb"][-1] < out["lb"][0], out
@@ -392,6 +412,38 @@ def test_retrain_cli_finetune_on_gpu(tmp_path):
     r = subprocess.run(cmd, cwd=cwd, env=dict(os.environ, PYTHONPATH=repo), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=500)
     assert r.returncode == 0, r.stdout[-3000:]
-    assert "Fine-tune throughput" in r.stdout and "Final test accuracy" in r.stdout
+    assert "Fine-tune throughput" in r.stdout and "Final test accuracy" in r.stdout and "on the device" in r.stdout
     accs = [float(l.split("Train accuracy = ")[1].split("%")[0]) for l in r.stdout.splitlines() if "Train accuracy" in l]
     assert accs[-1] >= 90.0, r.stdout[-2000:]  # the synthetic classes are trivially separable
+    vacc = [float(l.split("Validation accuracy = ")[1].split("%")[0]) for l in r.stdout.splitlines() if "Validation accuracy" in l]
+    assert vacc and vacc[-1] >= 80.0, r.stdout[-2000:]
+    # the fine-tuned network is exported like the retrained one (a GraphDef) and retrain1/test.py classifies held-out JPEGs
+    # with it (reference: retrain1/test.py:26-58)
+    import numpy as np
+    from distributed_tensorflow_amd.data import image_lists as il
+    held = il.make_synthetic_image_dir(os.path.join(cwd, "held_out"), num_classes=3, images_per_class=10, seed=4242)
+    r2 = subprocess.run([sys.executable, "-u", os.path.join(repo, "retrain1", "test.py"), "--imgs", held, "--graph",
+                         os.path.join(cwd, "ft.pb"), "--labels", os.path.join(cwd, "labels.txt")], cwd=cwd,
+                        env=dict(os.environ, PYTHONPATH=repo), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=200)
+    assert r2.returncode == 0, r2.stdout[-3000:]
+    files = [l for l in r2.stdout.splitlines() if l.endswith(".jpg")]
+    top1 = [l[3:] for l in r2.stdout.splitlines() if l.startswith("=> ")]
+    truth = [os.path.basename(os.path.dirname(f)).replace("_", " ") for f in files]
+    assert len(top1) == 30 and np.mean([a == b for a, b in zip(top1, truth)]) >= 0.9, list(zip(top1, truth))[:8]
+
+
+def test_gather_rows_kernel_and_device_sampler():
+    """The fine-tune's batch is drawn on the device: class-balanced sampler + one gather kernel into static buffers."""
+    from distributed_tensorflow_amd.apps.finetune import DeviceBatchSampler
+    torch.manual_seed(3)
+    n = 90
+    y = torch.tensor([0] * 10 + [1] * 60 + [2] * 20, dtype=torch.int32, device="cuda")
+    x = torch.randn(n, 7, 5, 8, device="cuda").to(BF)        # 560 B rows (a multiple of 16)
+    s = DeviceBatchSampler(x, y, 3, seed=11)
+    xb, yb = torch.empty(600, 7, 5, 8, device="cuda", dtype=BF), torch.empty(600, dtype=torch.int32, device="cuda")
+    s.sample_into(xb, yb)
+    torch.cuda.synchronize()
+    rows = s._rows[600].long()
+    assert torch.equal(xb, x.index_select(0, rows)) and torch.equal(yb, y.index_select(0, rows))
+    frac = torch.bincount(yb.long(), minlength=3).float() / 600
+    assert float((frac - 1 / 3).abs().max()) < 0.08

@@ -82,8 +82,59 @@ def test_retrain_cli_finetune_mode(tmp_path):
            "--output_labels", os.path.join(cwd, "labels.txt"), "--model_dir", os.path.join(cwd, "model"), "--seed", "3"]
     r = subprocess.run(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
-    assert "Step 1: Train accuracy" in r.stdout and "Fine-tune throughput" in r.stdout and "replicas in sync: True" in r.stdout
-    from distributed_tensorflow_amd.utils import checkpoint as ckpt
-    t = ckpt.load_tensors(os.path.join(cwd, "ft.pb"))
-    assert t["conv/conv2d_params"].shape == (3, 3, 8, 32) and t["final_training_ops/weights/final_weights"].shape == (2048, 2)
+    assert "Step 1: Train accuracy" in r.stdout and "Validation accuracy" in r.stdout and "Fine-tune throughput" in r.stdout
+    assert "replicas in sync: True" in r.stdout
+    # the export is the reference's artefact: ONE GraphDef of Inception-v3 + the new layer, which retrain*/test.py reads
+    from distributed_tensorflow_amd.utils import graphdef as gd
+    layers, fw, fb, final_name, ops = gd.read_retrained_graph(os.path.join(cwd, "ft.pb"))
+    assert layers["conv"]["weights"].shape == (3, 3, 3, 32) and fw.shape == (2048, 2) and final_name == "final_result"
+    assert sum(1 for _n, o, _i in ops if o == "Conv2D") == 94
     assert open(os.path.join(cwd, "labels.txt")).read().split("\n")[:2] == ["class 00", "class 01"]
+
+
+def test_device_batch_sampler_cpu_statement():
+    """The class-balanced sampler of the fine-tune (random class, then a random image of that class, with replacement:
+    ``/root/reference/retrain1/retrain.py:322-340``): balanced over classes whatever the class sizes, labels match rows."""
+    from distributed_tensorflow_amd.apps.finetune import DeviceBatchSampler
+    y = torch.tensor([2] * 50 + [0] * 5 + [1] * 200, dtype=torch.int32)   # not label-major: sorted once
+    x = torch.arange(255, dtype=torch.float32).reshape(255, 1, 1, 1).repeat(1, 1, 1, 4).contiguous()
+    s = DeviceBatchSampler(x, y, 3, seed=5)
+    xb, yb = torch.empty(3000, 1, 1, 4), torch.empty(3000, dtype=torch.int32)
+    s.sample_into(xb, yb)
+    frac = torch.bincount(yb.long(), minlength=3).float() / 3000
+    assert float((frac - 1 / 3).abs().max()) < 0.04
+    orig_label = y[xb[:, 0, 0, 0].long()]          # the row's value is its index in the ORIGINAL order
+    assert torch.equal(orig_label, yb)
+    first = xb.clone()
+    s.sample_into(xb, yb)
+    assert not torch.equal(first, xb)               # the draw counter advances
+
+
+def test_retrain2_finetune_stop_relaunch_resume_two_ranks(tmp_path):
+    """``retrain2.py --finetune`` runs under the Supervisor like every distributed script of the reference
+    (``/root/reference/retrain2/retrain2.py:423-431,445,508``): a fault on the last rank stops every rank, the chief saves
+    parameters + step to ./logs/model.ckpt-<step>, the relaunch restores, broadcasts, continues and exports."""
+    import glob
+    import re
+    cwd = str(tmp_path)
+    common = ["--num_gpus", "2", "--backend", "gloo", "--device", "cpu", "--synthetic", "--finetune", "--synthetic_classes", "2",
+              "--synthetic_images_per_class", "16", "--finetune_batch_size", "2", "--eval_step_interval", "2",
+              "--save_model_secs", "0", "--seed", "3", "--bottleneck_dir", os.path.join(cwd, "bn")]
+    env = dict(os.environ, PYTHONPATH=REPO, OMP_NUM_THREADS="3", DTF_HEARTBEAT_PERIOD_S="0.2", MASTER_PORT="29731")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "retrain2", "retrain2.py"), "--training_steps", "5",
+                        "--fault_inject_step", "2"] + common, cwd=cwd, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode != 0, r.stdout[-2000:]
+    assert "injected fault at step 2" in r.stdout and "Supervisor: final checkpoint" in r.stdout, r.stdout[-3000:]
+    saved = glob.glob(os.path.join(cwd, "logs", "model.ckpt-*"))
+    assert saved and not os.path.exists(os.path.join(cwd, "retrained_graph.pb"))
+    step = max(int(p.rsplit("-", 1)[1]) for p in saved)
+    assert 2 <= step < 5
+    env["MASTER_PORT"] = "29732"
+    r2 = subprocess.run([sys.executable, os.path.join(REPO, "retrain2", "retrain2.py"), "--training_steps", "5"] + common,
+                        cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stdout[-3000:]
+    assert "restored" in r2.stdout and ("global_step=%d" % step) in r2.stdout
+    assert min(int(m) for m in re.findall(r"Step (\d+):", r2.stdout)) >= step
+    assert "replicas in sync: True" in r2.stdout and os.path.exists(os.path.join(cwd, "retrained_graph.pb"))
+    assert os.path.exists(os.path.join(cwd, "logs", "model.ckpt-5"))

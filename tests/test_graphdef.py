@@ -1,5 +1,6 @@
 """TF-free GraphDef reader/writer (C26/C28): round trip + cross-check against google.protobuf with a
 dynamically declared subset of tensorflow's graph.proto (TensorFlow itself is not installed)."""
+import os
 import numpy as np
 import pytest
 
@@ -108,3 +109,52 @@ def test_inception_weights_load_into_model(tmp_path):
                        torch.from_numpy(consts["mixed_10/tower_1/mixed/conv_1/batchnorm/moving_variance"]))
     with pytest.raises(KeyError):
         m.load_tf_weights({"nope": {"weights": np.zeros((1, 1, 1, 1), np.float32)}})
+
+
+def test_whole_network_graphdef_round_trip(tmp_path):
+    """``retrained_graph.pb`` is a real GraphDef of Inception-v3 + the new layer (``/root/reference/retrain1/retrain.py:470-473``)
+    under the tensor names the reference's scripts use (``retrain.py:29-35``, ``test.py:33,39``): export -> parse without
+    TensorFlow -> a fresh network holds bit-identical parameters; the topology is the 2015 graph's (94 Conv2D, 11 joins)."""
+    import torch
+    from distributed_tensorflow_amd.models.inception_v3 import InceptionV3
+    from distributed_tensorflow_amd.utils import graphdef as gd
+    net = InceptionV3(device="cpu", seed=11)
+    g = torch.Generator().manual_seed(4)
+    for p in net.params.values():   # non-trivial batch-norm constants
+        c = p["beta"].shape[0]
+        p["beta"], p["gamma"] = torch.randn(c, generator=g) * 0.1, 1.0 + 0.1 * torch.randn(c, generator=g)
+        p["moving_mean"], p["moving_variance"] = torch.randn(c, generator=g) * 0.1, 0.5 + torch.rand(c, generator=g)
+    fw, fb = np.random.RandomState(0).randn(2048, 5).astype(np.float32), np.arange(5, dtype=np.float32)
+    path = str(tmp_path / "retrained_graph.pb")
+    n = gd.write_inception_graphdef(path, net.graph, net.params, fw, fb, "final_result")
+    assert gd.is_graphdef(path) and os.path.getsize(path) > 80e6
+    layers, fw2, fb2, final_name, ops = gd.read_retrained_graph(path)
+    assert final_name == "final_result" and np.array_equal(fw, fw2) and np.array_equal(fb, fb2) and len(ops) == n
+    by_op = {}
+    for _name, op, _inp in ops:
+        by_op[op] = by_op.get(op, 0) + 1
+    assert by_op["Conv2D"] == 94 and by_op["BatchNormWithGlobalNormalization"] == 94 and by_op["Relu"] == 94
+    assert by_op["Concat"] == 11 and by_op["MaxPool"] == 4 and by_op["AvgPool"] == 10 and by_op["Softmax"] == 1
+    names = {n_: (op, inp) for n_, op, inp in ops}
+    assert names["DecodeJpeg"][1] == ["DecodeJpeg/contents"] and names["ResizeBilinear"][0] == "ResizeBilinear"
+    assert names["conv/Conv2D"][1] == ["Mul", "conv/conv2d_params"]
+    assert names["pool_3/_reshape"] == ("Reshape", ["pool_3", "pool_3/_reshape/shape"])
+    assert names["mixed/join"][1] == ["mixed/join/concat_dim", "mixed/conv", "mixed/tower/conv_1", "mixed/tower_1/conv_2",
+                                      "mixed/tower_2/conv"]
+    assert names["mixed_3/join"][1][1:] == ["mixed_3/conv", "mixed_3/tower/conv_2", "mixed_3/pool"]
+    assert names["mixed_10/tower_2/pool"] == ("AvgPool", ["mixed_9/join"]) and names["pool_3"][1] == ["mixed_10/join"]
+    # attributes survive: strides / padding of a strided VALID conv and of a SAME 1x7
+    raw = {n_["name"]: n_ for n_ in gd.iter_nodes(path) if n_["name"] in ("conv/Conv2D", "mixed_4/tower/conv_1/Conv2D", "pool_3")}
+    assert gd.attr_list_ints(raw["conv/Conv2D"]["attr"]["strides"]) == [1, 2, 2, 1]
+    assert gd.attr_value(raw["conv/Conv2D"]["attr"]["padding"]) == b"VALID"
+    assert gd.attr_value(raw["mixed_4/tower/conv_1/Conv2D"]["attr"]["padding"]) == b"SAME"
+    assert gd.attr_list_ints(raw["pool_3"]["attr"]["ksize"]) == [1, 8, 8, 1]
+    # a fresh network loaded from the file is the exporting network, bit for bit
+    fresh = InceptionV3(device="cpu", seed=999)
+    fresh.load_tf_weights(layers)
+    for name in net.graph.convs:
+        for k in ("weights", "beta", "gamma", "moving_mean", "moving_variance"):
+            assert torch.equal(fresh.params[name][k], net.params[name][k].float()), (name, k)
+        assert torch.equal(fresh.folded(name)[0], net.folded(name)[0])
+    # the older importer entry point reads the same file (the first fixture it sees that another function wrote)
+    assert set(gd.inception_weights_from_graphdef(path)) == set(net.graph.convs)
