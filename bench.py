@@ -61,6 +61,12 @@ def parse():
                    help="compute precision of the headline run (the reference trains in fp32)")
     p.add_argument("--extra-dtype", type=str, default="auto", choices=["auto", "none", "fp32", "bf16"],
                    help="also time this precision on one GPU and report it as a labelled extra (auto: the other one)")
+    p.add_argument("--no-extras", action="store_true",
+                   help="skip the labelled extras (the other BASELINE configurations: retrain1, Inception forward, fine-tune)")
+    p.add_argument("--extras-budget", type=float, default=130.0, help="seconds the extras may take in total")
+    p.add_argument("--warmup-seconds", type=float, default=0.05,
+                   help="after the --warmup steps keep warming until this much time has passed (clocks and caches settle by "
+                        "time, not by step count: 5 steps of this model are 0.7 ms)")
     p.add_argument("--ref-steps", type=int, default=10000,
                    help="steps of the reference schedule trained on the t10k split after the timed region (0 = skip)")
     return p.parse_args()
@@ -77,6 +83,18 @@ def _time_blocks(trainer, steps, sync, reduce_max, min_seconds=0.25, max_blocks=
         out.append(reduce_max(time.perf_counter() - t0))  # (the same number on every rank: all take the same decision)
         if out[0] >= min_seconds or len(out) >= max_blocks or sum(out) >= 2 * min_seconds and len(out) % 2 == 1:
             return out
+
+
+def _warm_by_time(trainer, sync, reduce_max, seconds, use_cuda):
+    """Untimed: after the W warm-up steps, further blocks of 64 steps until ``seconds`` have passed on every rank (the same
+    number of blocks everywhere: the decision is taken on the max over ranks).  The driver's --warmup 5 is 0.7 ms of this
+    model; the first timed blocks were 2-5 % slower than the rest."""
+    if not use_cuda or seconds <= 0:
+        return
+    t0 = time.perf_counter()
+    while reduce_max(time.perf_counter() - t0) < seconds:
+        trainer.train_steps(64)
+        sync()
 
 
 def _reference_schedule(eng, trainer, device, rank, world, steps, batch):
@@ -163,6 +181,7 @@ def main():
     trainer.prepare()  # graph capture only: nothing executes
     trainer.train_steps(args.warmup)
     sync()
+    _warm_by_time(trainer, sync, reduce_max, args.warmup_seconds, use_cuda)
     if world > 1:
         trainer.ensure_healthy()  # (IPC waits timed out during warm-up -> every rank switches to RCCL before the clock starts)
     blocks = _time_blocks(trainer, args.steps, sync, reduce_max)
@@ -192,6 +211,8 @@ def main():
         tr2 = DataParallelTrainer(eng2, sync=True)
         tr2.prepare()
         tr2.train_steps(args.warmup)
+        sync()
+        _warm_by_time(tr2, sync, reduce_max, args.warmup_seconds, use_cuda)
         b2 = _time_blocks(tr2, args.steps, sync, reduce_max)
         d2 = sorted(b2)[len(b2) // 2]
         extra = {"dtype": extra_dtype, "value": round(args.steps * args.batch / d2, 1), "unit": "images/s",
@@ -205,6 +226,17 @@ def main():
         ref_acc = _reference_schedule(eng, trainer, device, rank, world, args.ref_steps, args.batch)
         if world > 1 and ref_acc is not None:
             in_sync = in_sync and trainer.replicas_in_sync()
+
+    # the other BASELINE configurations through their product paths, each in a process of its own (labelled extras)
+    extras = {}
+    if world == 1 and use_cuda and args.engine == "native" and not args.no_extras and not args.dp_path:
+        trainer.close()
+        torch.cuda.synchronize()
+        from distributed_tensorflow_amd.apps.bench_extras import run_extras
+        try:
+            extras = run_extras(args.extras_budget)
+        except Exception as e:  # noqa: BLE001 - never lose the headline to an extra
+            extras = {"extras_error": repr(e)}
 
     if rank == 0:
         global_batch = args.batch * world
@@ -251,6 +283,7 @@ def main():
             "ipc_wait_timeouts": timeouts,
             "allreduce_us_at_startup": trainer.transport_us,
         }
+        out.update(extras)
         # ONE write call for the whole line: with unbuffered stdio print() issues the text and the newline separately, and
         # another rank's output on the shared pipe could land between them
         sys.stdout.write(json.dumps(out) + "\n")

@@ -306,6 +306,7 @@ def run(FLAGS, image_lists, image_dir: str, rank: int, world: int, device, seed:
     start_step = i
     rc = 0
     start = time.time()
+    warm_steps, t_warm = min(5, max(1, (steps - i) // 2)), None
     try:
         while i < steps and not (sv is not None and sv.should_stop()):
             if FLAGS.fault_inject_step >= 0 and i == FLAGS.fault_inject_step and rank == world - 1:
@@ -315,6 +316,9 @@ def run(FLAGS, image_lists, image_dir: str, rank: int, world: int, device, seed:
             i += 1
             engine.global_step = i
             st = i - 1
+            if i - start_step == warm_steps and device.type == "cuda":
+                torch.cuda.synchronize()  # (steady-state clock: the first steps hold lazy initialisation and the first log)
+                t_warm = time.time()
             if st % FLAGS.eval_step_interval == 0 or i == steps:
                 loss, acc = dp.mean_metrics()
                 vacc = validation_accuracy()
@@ -362,6 +366,12 @@ def run(FLAGS, image_lists, image_dir: str, rank: int, world: int, device, seed:
         _log(rank, "Fine-tune throughput: %.1f images/sec (global batch %d, %d GPU%s; batch sampling %s)" % (
             (i - start_step) * B * world / max(train_time, 1e-9), B * world, world, "" if world == 1 else "s",
             "on the device" if sampler is not None else "decoded and distorted per step"))
+        if t_warm is not None and i - start_step > warm_steps:
+            t_end = start + train_time
+            _log(rank, "Fine-tune steady state: %.1f images/sec (%d steps after %d warm-up steps, sampling, validation and "
+                       "logging included; last train loss %.4f)" % (
+                (i - start_step - warm_steps) * B * world / max(t_end - t_warm, 1e-9), i - start_step - warm_steps,
+                warm_steps, dp.mean_metrics()[0]))
     in_sync = dp.replicas_in_sync()
     _log(rank, "replicas in sync: %s" % in_sync)
 

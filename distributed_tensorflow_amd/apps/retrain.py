@@ -258,6 +258,24 @@ def run(FLAGS, distributed: bool) -> int:
     if world > 1:
         from ..parallel.ddp import broadcast_
         broadcast_(head.P, src=0)
+        import torch.distributed as dist
+        if device.type == "cuda" and dist.get_backend() == "nccl" and getattr(FLAGS, "comm", "auto") != "ipc":
+            # the head's 41 KB gradient all-reduce goes through the framework's own communicator, enqueued on the step's
+            # stream (reference transport: retrain2/retrain2.py:377,411-416); all ranks or none
+            from ..parallel.rccl_comm import RcclCommunicator
+            ok, comm = 1, None
+            try:
+                comm = RcclCommunicator.create(rank, world, device, key="rccl/head")
+            except Exception as e:  # noqa: BLE001
+                ok = 0
+                _log(0, "rank %d: native RCCL communicator unavailable (%r): process-group all-reduce" % (rank, e))
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()):
+                head.comm = comm
+                _log(rank, "head gradients: native RCCL communicator (%d ranks), enqueued on the step's stream" % world)
+            elif comm is not None:
+                comm.close(abort=True)
 
     distortion = Distortion(FLAGS.flip_left_right, FLAGS.random_crop, FLAGS.random_scale, FLAGS.random_brightness)
     cache = BottleneckCache(index, device)
@@ -450,6 +468,8 @@ def run(FLAGS, distributed: bool) -> int:
         if rank == 0 and train_writer is not None:
             train_writer.close()
             validation_writer.close()
+        if head.comm is not None:
+            head.comm.close(abort=True)  # (a peer is gone or going: do not wait for it)
         if store is not None:
             store.close()
         if store_server is not None:
@@ -513,6 +533,8 @@ def run(FLAGS, distributed: bool) -> int:
         train_writer.close()
         validation_writer.close()
     _log(rank, "Total time: %3.2fs:" % (time.time() - begin_time))
+    if head.comm is not None:
+        head.comm.close()
     if store is not None:
         store.close()
     if store_server is not None:

@@ -54,6 +54,10 @@ class RetrainHead:
         self._step_t = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._ticket = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._dz = None
+        # data parallelism (retrain2): the framework's own communicator (parallel/rccl_comm.py) when one is attached — the
+        # 41 KB gradient all-reduce is then an enqueue on the step's stream, no torch.distributed call and no host sync in
+        # the step; None = the process group (gloo on CPU / several ranks sharing one GPU)
+        self.comm = None
         self._ring = None  # optional [R,4] device ring of per-step metric sums (train ce, train correct, val ce, val correct)
 
     def use_metrics_ring(self, ring: Optional[torch.Tensor]) -> None:
@@ -180,7 +184,7 @@ class RetrainHead:
                                        metrics_ptr=self._ring.data_ptr() + ring_slot * 16 if use_ring else 0, capture=capture)
             st = torch.cuda.current_stream().cuda_stream
             lib = native.hip()
-            if self.world == 1:
+            if self.world == 1 and self.comm is None:
                 native.check(lib.dtf_retrain_head_bwd(cache.data_ptr(), native.ptr(rows), self._dz.data_ptr(), B, self.C,
                                                       self.P.data_ptr(), self.P.data_ptr() + 4 * BOTTLENECK * self.C, 0, 0,
                                                       self.lr, st), "head bwd")
@@ -191,7 +195,10 @@ class RetrainHead:
                 gb = self.G[BOTTLENECK * self.C:]
                 native.check(lib.dtf_retrain_head_bwd(cache.data_ptr(), native.ptr(rows), self._dz.data_ptr(), B, self.C,
                                                       0, 0, gW.data_ptr(), gb.data_ptr(), 0.0, st), "head bwd")
-                all_reduce_(self.G, group=group)
+                if self.comm is not None:
+                    self.comm.all_reduce(self.G)  # (ncclAllReduce on this stream: stream-ordered between bwd and the update)
+                else:
+                    all_reduce_(self.G, group=group)
                 hip_ops.sgd_(self.P, self.G, self._step_t, self._ticket, lr=self.lr, grad_scale=1.0 / self.world)
         else:
             x = cache if rows is None else cache.index_select(0, rows.long())

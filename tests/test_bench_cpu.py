@@ -51,3 +51,24 @@ def test_bench_json_contract_two_ranks_as_the_driver_launches_it():
     d = _line(r.stdout)
     _check(d, 2, 2, 1)
     assert d["replicas_in_sync"] is True
+
+
+def test_extras_records_schema_from_driver_logs():
+    """The labelled extras of bench.py (BASELINE configs 3-5) are parsed from the product drivers' own log lines."""
+    from distributed_tensorflow_amd.apps import bench_extras as be
+    log = ("bottleneck extraction: 2000 images on this rank in 0.21s (9523.8 images/sec/rank, HBM cache 16.4 MB)\n"
+           "2026-01-01: Step 1999: Train accuracy = 100.0% Cross entropy = 0.91 Validation accuracy = 100.0%\n"
+           "Final test accuracy = 99.5% \nTraining time: 0.11s\n"
+           "Head training throughput: 1840000.0 bottleneck-images/sec (global batch 100)\n")
+    p = be.parse_retrain1(log)
+    assert p["extraction_images_per_sec"] == 9523.8 and p["extraction_images"] == 2000 and p["head_images_per_sec"] == 1840000.0
+    assert abs(p["final_test_accuracy"] - 0.995) < 1e-9 and p["training_seconds"] == 0.11
+    log = ("2026: Step 0: Train accuracy = 20.0% Cross entropy = 1.6094 Validation accuracy = 21.0%\n"
+           "Training time: 1.23s\nFine-tune throughput: 5200.0 images/sec (global batch 128, 1 GPU; batch sampling on the device)\n"
+           "Fine-tune steady state: 6100.5 images/sec (40 steps after 5 warm-up steps, sampling, validation and logging included; "
+           "last train loss 0.0123)\nFinal test accuracy = 100.0% (N=60)\n")
+    p = be.parse_finetune(log)
+    assert p["value"] == 6100.5 and p["timed_steps"] == 40 and p["final_train_loss"] == 0.0123 and p["first_train_loss"] == 1.6094
+    assert p["whole_run_images_per_sec"] == 5200.0 and p["final_test_accuracy"] == 1.0
+    # nothing runs without a GPU budget: an empty selection returns no records
+    assert be.run_extras(budget_s=0.0) == {}

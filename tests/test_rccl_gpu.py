@@ -201,3 +201,55 @@ def test_checked_step_validates_the_production_exchange(tmp_path, schedule, dtyp
         assert o["schedule"] == schedule and max(o["dev"]) < 2e-3, o
         assert o["in_sync"] and o["host_step"] == o["device_step"] == 3 + 2 * 18, o
         assert 1.5 < o["loss_last"] < o["loss_first"] + 0.05 < 2.6, o   # (the checked steps did not double-count metrics)
+
+
+_HEAD_RCCL = r"""
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29646", HSA_ENABLE_IPC_MODE_LEGACY="0")
+import torch, torch.distributed as dist
+from distributed_tensorflow_amd.models.retrain_head import RetrainHead
+from distributed_tensorflow_amd.parallel.rccl_comm import RcclCommunicator
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+torch.manual_seed(2)
+N, C, B = 400, 5, 100
+cache = torch.rand(N, 2048, device="cuda"); labels = torch.randint(0, C, (N,), device="cuda", dtype=torch.int32)
+a, b = RetrainHead(C, "cuda", learning_rate=0.05, seed=1), RetrainHead(C, "cuda", learning_rate=0.05, seed=1)
+a.comm = RcclCommunicator.create(0, 1, "cuda:0", key="rccl/headtest")   # the data-parallel path with a 1-rank group
+calls = {"n": 0}
+orig = dist.all_reduce
+def counting(*x, **k):
+    calls["n"] += 1
+    return orig(*x, **k)
+dist.all_reduce = counting
+import time
+for i in range(300):
+    rows = torch.randint(0, N, (B,), device="cuda", dtype=torch.int32)
+    a.train_step(cache, labels, rows); b.train_step(cache, labels, rows)
+torch.cuda.synchronize()
+maxdiff = float((a.P - b.P).abs().max())
+t0 = time.perf_counter()
+for i in range(300):
+    a.train_step(cache, labels, rows)
+torch.cuda.synchronize()
+us = (time.perf_counter() - t0) / 300 * 1e6
+dist.all_reduce = orig
+print(json.dumps({"pg_calls": calls["n"], "maxdiff": maxdiff, "us_per_dp_step": us,
+                  "async_error": a.comm.async_error()}))
+a.comm.close()
+dist.destroy_process_group()
+"""
+
+
+def test_retrain_head_dp_step_uses_the_native_communicator(tmp_path):
+    """retrain2's head step with the framework's communicator attached: forward, backward, ncclAllReduce of the 41 KB
+    gradient and the SGD update are four enqueues on one stream -- no torch.distributed collective, no host sync; same
+    parameters as the fused single-GPU step (``/root/reference/retrain2/retrain2.py:377,411-416``)."""
+    script = tmp_path / "head_rccl.py"
+    script.write_text(_HEAD_RCCL)
+    r = subprocess.run([sys.executable, str(script), REPO], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=200)
+    assert r.returncode == 0, r.stdout[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["pg_calls"] == 0 and out["maxdiff"] < 1e-6 and out["async_error"] is None, out
+    assert out["us_per_dp_step"] < 150.0, out
