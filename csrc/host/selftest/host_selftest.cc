@@ -41,6 +41,14 @@ int dtf_ckpt_count(void*);
 int dtf_ckpt_entry(void*, int, char*, int, int*, int*, uint64_t*, uint64_t*);
 int dtf_ckpt_read(void*, int, void*);
 void dtf_ckpt_close(void*);
+void* dtf_bundle_begin(const char*);
+int dtf_bundle_add(void*, const char*, int, int, const int64_t*, const void*, uint64_t);
+int dtf_bundle_finish(void*);
+void* dtf_bundle_open(const char*);
+int dtf_bundle_count(void*);
+int dtf_bundle_entry(void*, int, char*, int, int*, int*, int64_t*, uint64_t*);
+int dtf_bundle_read(void*, int, void*);
+void dtf_bundle_close(void*);
 int64_t dtf_parse_floats(const char*, uint64_t, float*, uint64_t);
 int64_t dtf_format_floats(const float*, uint64_t, char*, uint64_t);
 }
@@ -225,12 +233,75 @@ static void test_ckpt(const std::string& dir) {
   EXPECT(dtf_format_floats(vals, 5, text, 8) < 0);  // too small a buffer is an error, not an overflow
 }
 
+// TensorFlow tensor bundle: enough entries for several restart runs, a truncated index, a flipped data byte
+static void test_bundle(const std::string& dir) {
+  const std::string prefix = dir + "/selftest_model.ckpt";
+  void* w = dtf_bundle_begin(prefix.c_str());
+  EXPECT(w != nullptr);
+  std::vector<std::vector<float>> vals(40);
+  for (int i = 0; i < 40; ++i) {
+    vals[i].assign(17 + i, (float)i);
+    char name[64];
+    snprintf(name, sizeof name, "tower/layer_%02d/weights", i);
+    const int64_t d[2] = {1, (int64_t)vals[i].size()};
+    EXPECT(dtf_bundle_add(w, name, 1, 2, d, vals[i].data(), vals[i].size() * 4) == 0);
+  }
+  const int32_t step = 77;
+  EXPECT(dtf_bundle_add(w, "Variable", 3, 0, nullptr, &step, 4) == 0);
+  EXPECT(dtf_bundle_finish(w) == 0);
+  void* r = dtf_bundle_open(prefix.c_str());
+  EXPECT(r != nullptr);
+  if (r) {
+    EXPECT(dtf_bundle_count(r) == 41);
+    char name[128];
+    int dt = 0, nd = 0;
+    int64_t dims[8];
+    uint64_t nb = 0;
+    EXPECT(dtf_bundle_entry(r, 0, name, sizeof name, &dt, &nd, dims, &nb) == 0);
+    EXPECT(std::string(name) == "Variable" && dt == 3 && nd == 0 && nb == 4);  // sorted: upper case first
+    int32_t got = 0;
+    EXPECT(dtf_bundle_read(r, 0, &got) == 0 && got == 77);
+    EXPECT(dtf_bundle_entry(r, 40, name, sizeof name, &dt, &nd, dims, &nb) == 0);
+    EXPECT(std::string(name) == "tower/layer_39/weights" && nd == 2 && dims[1] == 56 && nb == 56 * 4);
+    std::vector<float> b(56);
+    EXPECT(dtf_bundle_read(r, 40, b.data()) == 0 && b[55] == 39.0f);
+    EXPECT(dtf_bundle_entry(r, 41, name, sizeof name, &dt, &nd, dims, &nb) != 0);
+    dtf_bundle_close(r);
+  }
+  // a flipped byte in the data file is caught by the tensor's CRC
+  {
+    FILE* f = fopen((prefix + ".data-00000-of-00001").c_str(), "r+b");
+    EXPECT(f != nullptr);
+    if (f) { fseek(f, 2, SEEK_SET); fputc(0x7f, f); fclose(f); }
+    void* r2 = dtf_bundle_open(prefix.c_str());
+    EXPECT(r2 != nullptr);
+    if (r2) {
+      int bad = 0;
+      std::vector<float> b(64);
+      for (int i = 0; i < dtf_bundle_count(r2); ++i) bad += dtf_bundle_read(r2, i, b.data()) != 0;
+      EXPECT(bad == 1);
+      dtf_bundle_close(r2);
+    }
+  }
+  // a truncated index is refused
+  {
+    FILE* f = fopen((prefix + ".index").c_str(), "rb");
+    std::vector<char> all(1 << 16);
+    const size_t n = f ? fread(all.data(), 1, all.size(), f) : 0;
+    if (f) fclose(f);
+    FILE* g = fopen((prefix + "_cut.index").c_str(), "wb");
+    if (g) { fwrite(all.data(), 1, n / 2, g); fclose(g); }
+    EXPECT(dtf_bundle_open((prefix + "_cut").c_str()) == nullptr);
+  }
+}
+
 int main(int argc, char** argv) {
   const std::string dir = argc > 1 ? argv[1] : "/tmp";
   test_crc();
   test_events(dir);
   test_store();
   test_ckpt(dir);
+  test_bundle(dir);
   if (g_fail) {
     fprintf(stderr, "host selftest: %d check(s) failed\n", g_fail);
     return 1;

@@ -237,6 +237,14 @@ def host() -> C.CDLL:
         _sig(lib, "dtf_ckpt_entry", I, [P, I, P, I, P, P, P, P])
         _sig(lib, "dtf_ckpt_read", I, [P, I, P])
         _sig(lib, "dtf_ckpt_close", None, [P])
+        _sig(lib, "dtf_bundle_begin", P, [c_char_p])
+        _sig(lib, "dtf_bundle_add", I, [P, c_char_p, I, I, P, P, c_uint64])
+        _sig(lib, "dtf_bundle_finish", I, [P])
+        _sig(lib, "dtf_bundle_open", P, [c_char_p])
+        _sig(lib, "dtf_bundle_count", I, [P])
+        _sig(lib, "dtf_bundle_entry", I, [P, I, P, I, P, P, P, P])
+        _sig(lib, "dtf_bundle_read", I, [P, I, P])
+        _sig(lib, "dtf_bundle_close", None, [P])
         _sig(lib, "dtf_parse_floats", c_int64, [c_char_p, c_uint64, P, c_uint64])
         _sig(lib, "dtf_format_floats", c_int64, [P, c_uint64, P, c_uint64])
         _host = lib

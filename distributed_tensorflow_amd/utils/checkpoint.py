@@ -100,6 +100,67 @@ def load_tensors(path: str) -> "OrderedDict[str, np.ndarray]":
     return out
 
 
+# ----------------------------------------------------------------------------- TensorFlow tensor bundle (tf.train.Saver's files)
+_TF_DTYPE = {np.dtype(np.float32): 1, np.dtype(np.float64): 2, np.dtype(np.int32): 3, np.dtype(np.uint8): 4,
+             np.dtype(np.int64): 9, np.dtype(np.bool_): 10}
+_NP_OF_TF = {v: k for k, v in _TF_DTYPE.items()}
+
+
+def save_tf_bundle(prefix: str, tensors: Dict[str, object]) -> str:
+    """``<prefix>.index`` + ``<prefix>.data-00000-of-00001``: the checkpoint files ``tf.train.Saver().save(sess, prefix)``
+    writes (``demo1/train.py:144,165``), produced by the native writer (``csrc/host/tensor_bundle.cc``) — an SSTable of
+    ``BundleEntryProto`` records over the raw tensor bytes, CRC32C per block and per tensor.  Keys are the variables' TF
+    names.  Atomic (tmp + rename)."""
+    lib = native.host()
+    os.makedirs(os.path.dirname(os.path.abspath(prefix)) or ".", exist_ok=True)
+    h = lib.dtf_bundle_begin(prefix.encode())
+    if not h:
+        raise CheckpointError("cannot start tensor bundle " + prefix)
+    for name, v in tensors.items():
+        a = np.asarray(_to_numpy(v)[0], order="C")  # (ascontiguousarray would promote a scalar to 1-d)
+        if a.dtype not in _TF_DTYPE:
+            raise CheckpointError("%s: dtype %s has no TensorFlow DataType here" % (name, a.dtype))
+        dims = (C.c_int64 * max(1, a.ndim))(*a.shape)
+        if lib.dtf_bundle_add(h, name.encode(), _TF_DTYPE[a.dtype], a.ndim, dims, a.ctypes.data_as(C.c_void_p), a.nbytes) != 0:
+            raise CheckpointError("tensor bundle: cannot add " + name)
+    if lib.dtf_bundle_finish(h) != 0:
+        raise CheckpointError("tensor bundle: writing %s failed" % prefix)
+    return prefix
+
+
+def load_tf_bundle(prefix: str) -> "OrderedDict[str, np.ndarray]":
+    """Read a tensor bundle (ours or one written by TensorFlow's ``Saver``: any uncompressed single-shard table) without
+    TensorFlow; per-block and per-tensor CRCs are verified."""
+    lib = native.host()
+    h = lib.dtf_bundle_open(prefix.encode())
+    if not h:
+        raise CheckpointError("%s.index: not a readable single-shard tensor bundle" % prefix)
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    try:
+        name = C.create_string_buffer(1024)
+        dtype, ndim, nbytes = C.c_int(), C.c_int(), C.c_uint64()
+        dims = (C.c_int64 * 8)()
+        for i in range(lib.dtf_bundle_count(h)):
+            if lib.dtf_bundle_entry(h, i, name, 1024, C.byref(dtype), C.byref(ndim), dims, C.byref(nbytes)) != 0:
+                raise CheckpointError("tensor bundle: bad entry %d" % i)
+            if dtype.value not in _NP_OF_TF:
+                continue  # (strings / resources: nothing this framework stores)
+            a = np.empty(tuple(dims[d] for d in range(ndim.value)), _NP_OF_TF[dtype.value])
+            if a.nbytes != nbytes.value:
+                raise CheckpointError("%s: %d bytes for shape %s" % (name.value.decode(), nbytes.value, a.shape))
+            rc = lib.dtf_bundle_read(h, i, a.ctypes.data_as(C.c_void_p))
+            if rc != 0:
+                raise CheckpointError("%s: %s" % (name.value.decode(), "CRC mismatch" if rc == -74 else "read error %d" % rc))
+            out[name.value.decode()] = a
+    finally:
+        lib.dtf_bundle_close(h)
+    return out
+
+
+def is_tf_bundle(prefix: str) -> bool:
+    return os.path.exists(prefix + ".index") and os.path.exists(prefix + ".data-00000-of-00001")
+
+
 # ----------------------------------------------------------------------------- TF-name layout (SURVEY §5.4)
 def mnist_tf_names(with_global_step: bool) -> "OrderedDict[str, str]":
     """engine parameter name -> TF variable name."""
@@ -149,10 +210,13 @@ def mnist_state_from_tf(engine, tensors: Dict[str, np.ndarray]) -> int:
 class Saver:
     """``saver.save(sess, path[, global_step])`` / ``saver.restore(sess, path)`` for an engine."""
 
-    def __init__(self, engine, *, with_global_step: bool = True, max_to_keep: int = 5):
+    def __init__(self, engine, *, with_global_step: bool = True, max_to_keep: int = 5, tf_bundle: bool = True):
         self.engine = engine
         self.with_global_step = with_global_step
         self.max_to_keep = max_to_keep
+        # also write what tf.train.Saver writes, <path>.index + <path>.data-00000-of-00001 (TensorFlow can restore it;
+        # restore() reads either form)
+        self.tf_bundle = tf_bundle
         self._kept = []
 
     def save(self, save_path: str, global_step: Optional[int] = None) -> str:
@@ -163,15 +227,23 @@ class Saver:
             global_step = int(np.asarray(tensors.get("Variable", tensors.get("_dtf/step", global_step))).reshape(-1)[0])
         path = save_path if global_step is None else "%s-%d" % (save_path, global_step)
         save_tensors(path, tensors)
+        if self.tf_bundle:
+            # TF has no "_dtf/step": the demo1 graph keeps no global step, so that entry stays in the native container only
+            save_tf_bundle(path, OrderedDict((k, v) for k, v in tensors.items() if not k.startswith("_dtf/")))
         update_checkpoint_state(os.path.dirname(os.path.abspath(path)) or ".", path)
         self._kept.append(path)
         while self.max_to_keep and len(self._kept) > self.max_to_keep:
             old = self._kept.pop(0)
-            if old != path and os.path.exists(old):
-                os.remove(old)
+            for f in (old, old + ".index", old + ".data-00000-of-00001"):
+                if old != path and os.path.exists(f):
+                    os.remove(f)
         return path
 
     def restore(self, path: str) -> int:
+        """``path``: the native container, or the prefix of a TensorFlow tensor bundle (``model/train.ckpt`` as written by
+        ``tf.train.Saver``: ``demo1/test.py:182`` restores exactly that)."""
+        if not os.path.isfile(path) and is_tf_bundle(path):
+            return mnist_state_from_tf(self.engine, load_tf_bundle(path))
         return mnist_state_from_tf(self.engine, load_tensors(path))
 
 

@@ -215,3 +215,138 @@ def test_file_writer_add_summary_is_thread_safe(tmp_path):
         else:
             i = e["step"]
             assert e["scalars"] == {"a/x": float(i), "a/y": float(2 * i), "a/z": float(3 * i)}
+
+
+# ----------------------------------------------------------------------------- TensorFlow tensor bundle (tf.train.Saver's files)
+def _py_varint(b, pos):
+    v = shift = 0
+    while True:
+        x = b[pos]
+        pos += 1
+        v |= (x & 0x7F) << shift
+        if not x & 0x80:
+            return v, pos
+        shift += 7
+
+
+def _py_table_entries(path):
+    """An independent statement of the LevelDB table format in plain Python (footer -> index block -> data blocks, prefix
+    compression, masked CRC32C trailers): the native reader is not only checked against its own writer."""
+    import struct
+    from distributed_tensorflow_amd import native
+    lib = native.host()
+    data = open(path, "rb").read()
+    assert struct.unpack("<Q", data[-8:])[0] == 0xDB4775248B80FB57
+    pos = len(data) - 48
+    _moff, pos = _py_varint(data, pos)
+    _msize, pos = _py_varint(data, pos)
+    ioff, pos = _py_varint(data, pos)
+    isize, pos = _py_varint(data, pos)
+
+    def block(off, size):
+        assert data[off + size] == 0                                          # no compression
+        (crc,) = struct.unpack("<I", data[off + size + 1:off + size + 5])
+        raw = lib.dtf_crc32c(data[off:off + size + 1], size + 1)
+        assert (((raw >> 15) | (raw << 17)) + 0xA282EAD8) & 0xFFFFFFFF == crc  # masked CRC32C of block + type byte
+        (nrestart,) = struct.unpack("<I", data[off + size - 4:off + size])
+        end = off + size - 4 - 4 * nrestart
+        p, key, out = off, b"", []
+        while p < end:
+            shared, p = _py_varint(data, p)
+            non_shared, p = _py_varint(data, p)
+            vlen, p = _py_varint(data, p)
+            key = key[:shared] + data[p:p + non_shared]
+            p += non_shared
+            out.append((key, data[p:p + vlen]))
+            p += vlen
+        return out
+
+    entries = []
+    for _k, handle in block(ioff, isize):
+        boff, q = _py_varint(handle, 0)
+        bsize, q = _py_varint(handle, q)
+        entries += block(boff, bsize)
+    return entries
+
+
+def test_tf_tensor_bundle_round_trip_and_independent_parse(tmp_path):
+    """``<prefix>.index`` + ``<prefix>.data-00000-of-00001`` as ``tf.train.Saver`` writes them
+    (``/root/reference/demo1/train.py:144,165``; restored by ``demo1/test.py:175-182``)."""
+    from distributed_tensorflow_amd.utils import checkpoint as ckpt
+    rng = np.random.RandomState(0)
+    tensors = {"Conv1/Variable": rng.randn(5, 5, 1, 32).astype(np.float32),
+               "Conv1/Variable/Adam": rng.randn(5, 5, 1, 32).astype(np.float32),
+               "Conv1/Variable/Adam_1": rng.rand(5, 5, 1, 32).astype(np.float32),
+               "fc1/Variable": rng.randn(3136, 64).astype(np.float32),
+               "train_step/beta1_power": np.asarray(0.9 ** 7, np.float32),
+               "Variable": np.asarray(1234, np.int32),
+               "counts": np.arange(7, dtype=np.int64)}
+    prefix = str(tmp_path / "model" / "train.ckpt")
+    ckpt.save_tf_bundle(prefix, tensors)
+    assert ckpt.is_tf_bundle(prefix) and not os.path.exists(prefix)
+    assert os.path.getsize(prefix + ".data-00000-of-00001") == sum(v.nbytes for v in tensors.values())
+    back = ckpt.load_tf_bundle(prefix)
+    assert list(back) == sorted(tensors)                                       # keys come back in table (sorted) order
+    for k, v in tensors.items():
+        assert back[k].dtype == v.dtype and back[k].shape == v.shape and np.array_equal(back[k], v), k
+    # the same file through the plain-Python statement of the format: header first, keys sorted and prefix-compressed
+    ent = _py_table_entries(prefix + ".index")
+    assert ent[0][0] == b"" and [k.decode() for k, _v in ent[1:]] == sorted(tensors)
+    raw = open(prefix + ".index", "rb").read()
+    assert raw.count(b"Conv1/Variable") == 1                                   # shared prefixes are stored once per restart run
+    # BundleEntryProto of the scalar: dtype DT_INT32 (3), empty shape, size 4
+    e = dict(ent)[b"Variable"]
+    assert e[:2] == bytes([0x08, 3]) and bytes([0x28, 4]) in e
+    # corruption of one tensor byte is caught by its CRC; corruption of the index by the block CRC
+    with open(prefix + ".data-00000-of-00001", "r+b") as f:
+        f.seek(100)
+        b = f.read(1)
+        f.seek(100)
+        f.write(bytes([b[0] ^ 0x40]))
+    with pytest.raises(ckpt.CheckpointError, match="CRC"):
+        ckpt.load_tf_bundle(prefix)
+    ckpt.save_tf_bundle(prefix, tensors)
+    with open(prefix + ".index", "r+b") as f:
+        f.seek(20)
+        b = f.read(1)
+        f.seek(20)
+        f.write(bytes([b[0] ^ 0x01]))
+    with pytest.raises(ckpt.CheckpointError):
+        ckpt.load_tf_bundle(prefix)
+
+
+def test_tf_tensor_bundle_many_entries_span_blocks(tmp_path):
+    from distributed_tensorflow_amd.utils import checkpoint as ckpt
+    tensors = {"layer_%04d/some/rather/long/variable/name/to/fill/the/index/block/weights" % i:
+               np.full((3,), i, np.float32) for i in range(6000)}
+    prefix = str(tmp_path / "big.ckpt")
+    ckpt.save_tf_bundle(prefix, tensors)
+    assert os.path.getsize(prefix + ".index") > 300 << 10                      # more than one 256 KB block
+    back = ckpt.load_tf_bundle(prefix)
+    assert len(back) == 6000 and all(float(back[k][0]) == float(v[0]) for k, v in tensors.items())
+    ent = _py_table_entries(prefix + ".index")
+    assert len(ent) == 6001
+
+
+def test_saver_writes_what_tf_saver_writes_and_restores_from_it(tmp_path):
+    """``Saver.save`` leaves ``model/train.ckpt.index`` + ``.data-00000-of-00001`` next to the native container;
+    ``restore`` accepts the bundle prefix alone (what a TensorFlow run would have left)."""
+    import torch
+    from distributed_tensorflow_amd.data import mnist
+    from distributed_tensorflow_amd.engine.mnist_engine import EagerMnistEngine
+    from distributed_tensorflow_amd.utils import checkpoint as ckpt
+    imgs, labels = mnist.synthetic_mnist(64, seed=0)
+    ds = mnist.DataSet(mnist._scale_flatten(imgs), mnist.dense_to_one_hot(labels), seed=0)
+    dd = mnist.DeviceDataset(ds, "cpu", seed=0)
+    e = EagerMnistEngine(dd, batch_size=16, seed=1)
+    for _ in range(3):
+        e.train_step()
+    path = ckpt.Saver(e, with_global_step=True).save(str(tmp_path / "logs" / "model.ckpt"), global_step=3)
+    assert path.endswith("model.ckpt-3") and ckpt.is_tf_bundle(path)
+    t = ckpt.load_tf_bundle(path)
+    assert t["Variable"] == 3 and t["Conv1/weights/Variable"].shape == (5, 5, 1, 32) if "Conv1/weights/Variable" in t else True
+    assert any(k.endswith("/Adam_1") for k in t) and "train_step/beta1_power" in t
+    os.remove(path)                                                             # only TensorFlow's files are left
+    e2 = EagerMnistEngine(dd, batch_size=16, seed=99)
+    assert ckpt.Saver(e2).restore(path) == 3
+    assert torch.equal(e2.P, e.P) and torch.equal(e2.M, e.M) and torch.equal(e2.V, e.V)
