@@ -46,7 +46,8 @@ __device__ __forceinline__ void beta_powers(double b1, double b2, int t, double&
 
 // MULTI: the gradient is the sum, in index order, of p.nsrc buffers p.Gsrcs[] (the ranks' exchange buffers of a one-shot
 // all-reduce: the reduction happens in the optimizer's own loads, bit-identical on every rank).
-template <bool MULTI = false>
+// WSH: the parameters are double-buffered by step parity and replicated by this very update (OptimParams::Wsh).
+template <bool MULTI = false, bool WSH = false>
 __device__ __forceinline__ int adam_tf_body(const OptimParams& p, const int block, const int nblocks, const int nthreads) {
   const float b1 = p.beta1, b2 = p.beta2, ob1 = 1.f - p.beta1, ob2 = 1.f - p.beta2;
   const long n4 = p.n >> 2;
@@ -55,6 +56,8 @@ __device__ __forceinline__ int adam_tf_body(const OptimParams& p, const int bloc
   const long stride = (long)nblocks * nthreads * U;
   long base = (long)block * nthreads * U + threadIdx.x;
   float4 g[U], m[U], v[U], w[U];
+  const int par = WSH ? (*p.step & 1) : 0;
+  const float* __restrict__ wsrc = WSH ? p.Wsh[par][p.wsh_rank] : p.P;
   auto load = [&](long at) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -74,7 +77,7 @@ __device__ __forceinline__ int adam_tf_body(const OptimParams& p, const int bloc
       }
       m[u] = reinterpret_cast<const float4*>(p.M)[j];
       v[u] = reinterpret_cast<const float4*>(p.V)[j];
-      w[u] = reinterpret_cast<const float4*>(p.P)[j];
+      w[u] = reinterpret_cast<const float4*>(wsrc)[j];
     }
   };
   // (agent-scope load: in the fused exchange + optimizer launch the flag is raised by another workgroup of this launch)
@@ -114,7 +117,13 @@ __device__ __forceinline__ int adam_tf_body(const OptimParams& p, const int bloc
       }
       reinterpret_cast<float4*>(p.M)[i] = m[u];
       reinterpret_cast<float4*>(p.V)[i] = v[u];
-      reinterpret_cast<float4*>(p.P)[i] = w[u];
+      if (WSH) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if (r < p.wsh_world) reinterpret_cast<float4*>(p.Wsh[par ^ 1][r])[i] = w[u];
+      } else {
+        reinterpret_cast<float4*>(p.P)[i] = w[u];
+      }
       if (i * 4 >= p.zero_from) reinterpret_cast<float4*>(p.G)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     base += stride;

@@ -88,7 +88,11 @@ DTF_API int dtf_conv2_bwd_data_f32_push(const float* dpool2, const float* pool2,
 DTF_API int dtf_fc_bwd_trio_f32_shard(const float* X1, const float* dY1, int ldy1, float* dW1, int M1, int N1, int K,
                                       const float* dYq, const float* Wq, float* dXq, int Mq, int Nq, int Kq, int splits,
                                       const void* const* gA, const void* const* gB, int granks, int ranks_per_set, int lda0,
-                                      float* dW0_slice, int M0_slice, int N0, hipStream_t st);
+                                      float* dW0_slice, int M0_slice, int N0, const float* Wq_alt, const int* wq_sel,
+                                      hipStream_t st);
+DTF_API int dtf_fc_fwd_f32_sel(const float* X, const float* W0, const float* W1, const int* sel, float* out, int M, int N,
+                               int K, int splits, hipStream_t st);
+DTF_API int dtf_ipc_wshard_bufs(const void* comm, long lo_floats, long n_floats, float** out);
 DTF_API int dtf_ipc_sync_gather_slice(const void* comm, void* dst, long bytes, int rows, int pitch4, int lo4, int w4,
                                       long tail_off4, long tail_n4, int blocks_per_peer, hipStream_t st);
 DTF_API int dtf_ipc_shard_desc(const void* comm, long lo_floats, long n_floats, float* src, int zero_src,

@@ -53,4 +53,9 @@ struct OptimParams {
   unsigned* skip;         // optional device words [skip flag, skipped-step count]: flag != 0 = this step's gradient exchange
                           // had an expired wait somewhere (ipc_allreduce.hip): leave P/M/V and the step counter alone, only
                           // discard the accumulated gradients; the launch that owns the ticket clears the flag
+  // "wshard" data-parallel schedule (engine.hip: MnistEngine::wshard; wsh_world > 0): the range is this rank's slice of a parameter tensor that
+  // lives in two IPC-mapped buffers per rank, alternating by step parity.  The update reads the parameters from this rank's
+  // buffer of parity (*step & 1) and stores the new values into EVERY rank's buffer of the other parity; P is unused.
+  float* Wsh[2][8];       // [parity][rank]: the slice's place in that rank's buffer, as mapped into this process
+  int wsh_world, wsh_rank;
 };

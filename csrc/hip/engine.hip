@@ -55,6 +55,22 @@ struct MnistEngine {
   // them into every rank's landing buffer (the result buffers of the IpcComm at shard_comm), where W_fc1's Adam update reads
   const void* shard_comm;
   int shard_n, shard_lo, shard_w;
+  // "wshard" variant of it (wshard != 0; the shard fields are set as above): WEIGHTS travel instead of gradients, and the
+  // optimizer state of W_fc1 is sharded with the gradient.
+  //  * W_fc1 lives in the two buffers of the IpcComm at shard_comm (stage[] = parity 0, result[] = parity 1) instead of in P;
+  //    the fc1 forward and the fc1 data gradient of step c (c = device step counter) read buffer c & 1;
+  //  * rank r computes rows [lo, hi) of the global gradient (as under "shard"), applies Adam to THOSE rows only (M / V of
+  //    the other rows are the other ranks' business: 91 MB of optimizer traffic become 91 / N MB) inside the conv
+  //    filter-gradient launch, and stores the new rows straight into buffer (c + 1) & 1 of EVERY rank (12.8 / N MB per xGMI
+  //    link, all links at once): no push role, no landing barrier;
+  //  * the wait of the small all-reduce that ends the step (every rank has published its remaining gradients, stream-ordered
+  //    after its filter-gradient launch) is also the proof that every slice of the next buffer has landed.
+  // Hazards: buffer (c + 1) & 1 was last read in step c - 1; a peer writes it in step c only after the operand exchange of
+  // step c, which this rank enters after its step c - 1 has been enqueued in full.  A skipped step leaves the counter, and
+  // with it the buffer every rank reads next, where it was.
+  // P[W_fc1], and M / V outside [lo, hi), go stale: dtf_mnist_wshard_store() brings P up to date; the optimizer slices are
+  // exchanged by the trainer (parallel/ddp.py: materialize()).
+  int wshard;
 };
 
 // "shard" schedule: source ranks per K set of the slice GEMM (one set: plain stores; more: atomics into the zeroed slice)
@@ -73,6 +89,13 @@ static int forward_to_slabs(const MnistEngine* e, const float* images, const int
                               need_argmax ? e->amax1 : nullptr, st));
     DTF_TRY(dtf_conv2_fwd_f32((const float*)e->pool1, e->P + e->off_Wc2, e->P + e->off_bc2, (float*)e->pool2,
                               need_argmax ? e->amax2 : nullptr, n, st));
+    if (e->wshard) {
+      float* w[16];
+      DTF_TRY(dtf_ipc_wshard_bufs(e->shard_comm, 0, 3136L * 1024, w));
+      if (e->shard_n < 1 || e->gather_rank < 0 || e->gather_rank >= e->shard_n) return -22;
+      return dtf_fc_fwd_f32_sel((const float*)e->pool2, w[e->gather_rank], w[8 + e->gather_rank], e->step, e->slabs, n, 1024,
+                                3136, splits, st);
+    }
     return dtf_fc_fwd_f32((const float*)e->pool2, e->P + e->off_Wfc1, e->slabs, n, 1024, 3136, splits, nullptr, 0, st);
   }
   if (!e->wc2f || !e->wc2b) return -22;
@@ -122,6 +145,10 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
   const bool early_adam = (parts & 4) != 0;
   parts &= 3;
   if (shard && (parts & 2) && !early_adam) return -22;  // (the landing buffer is read by the hosted W_fc1 update only)
+  const bool wshard = loc.wshard != 0;
+  if (wshard && (!shard || e->off_Wfc1 != 0)) return -22;
+  float* wsh[16] = {};  // [parity][rank]: W_fc1 in every rank's two buffers
+  if (wshard) DTF_TRY(dtf_ipc_wshard_bufs(e->shard_comm, 0, 3136L * 1024, wsh));
   if (early_adam && ((e->world > 1 && e->gather_n == 0) || e->G_fc1_dst || e->G_src || e->off_Wfc1 != 0 || e->off_bfc1 % 4))
     return -22;
   if (e->G_fc1_dst && e->off_Wfc1 != 0) return -22;
@@ -176,9 +203,10 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
         for (int p = 0; p < 8; ++p)
           gA[p] = p < e->gather_n ? (const void*)((const float*)e->gather_A[p] + e->shard_lo) : nullptr;
         DTF_TRY(dtf_fc_bwd_trio_f32_shard((const float*)e->h_drop, (const float*)e->dz, 16, e->G + e->off_Wfc2, 1024, 10, B, dh,
-                                          e->P + e->off_Wfc1, e->dpool2, B, 3136, 1024, e->bwd_splits, gA, e->gather_B,
+                                          wshard ? wsh[e->gather_rank] : e->P + e->off_Wfc1, e->dpool2, B, 3136, 1024, e->bwd_splits, gA, e->gather_B,
                                           e->gather_n, SHARD_RANKS_PER_SET, 3136,
-                                          e->G + e->off_Wfc1 + (long)e->shard_lo * 1024, e->shard_w, 1024, st));
+                                          e->G + e->off_Wfc1 + (long)e->shard_lo * 1024, e->shard_w, 1024,
+                                          wshard ? wsh[8 + e->gather_rank] : nullptr, wshard ? e->step : nullptr, st));
       } else if (trio_ok(e)) {
         DTF_TRY(dtf_fc_bwd_trio_f32(x2, dh, dW_fc1, 3136, 1024, (const float*)e->h_drop, (const float*)e->dz, 16,
                                     e->G + e->off_Wfc2, 1024, 10, B, dh, e->P + e->off_Wfc1, e->dpool2, B, 3136, 1024,
@@ -222,19 +250,32 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
     // launch, whose 245 workgroups leave 267 resident slots — that launch grows from 24.8 to 33.6 us while the
     // filter-gradient launch only shrinks from 34.8 to 29.4 us: the ~20 us of streaming needs the longer host.)
     ShardPush push{};
-    if (shard) {
+    if (wshard) {
+      // this rank's rows only; read from its buffer of this step's parity, stored into every rank's buffer of the next one
+      const long lo = (long)e->shard_lo * 1024;
+      fc1.P = nullptr;
+      fc1.G = e->G + lo; fc1.M = e->M + lo; fc1.V = e->V + lo;
+      fc1.n = (long)e->shard_w * 1024;
+      // (several K sets accumulate the slice with atomics: the update re-zeroes it; one set stores it)
+      fc1.zero_from = e->shard_n > SHARD_RANKS_PER_SET ? 0 : fc1.n;
+      for (int par = 0; par < 2; ++par)
+        for (int r = 0; r < e->shard_n; ++r) fc1.Wsh[par][r] = wsh[par * 8 + r] + lo;
+      fc1.wsh_world = e->shard_n;
+      fc1.wsh_rank = e->gather_rank;
+    } else if (shard) {
       DTF_TRY(dtf_ipc_shard_desc(e->shard_comm, (long)e->shard_lo * 1024, (long)e->shard_w * 1024,
                                  e->G + e->off_Wfc1 + (long)e->shard_lo * 1024, e->shard_n > SHARD_RANKS_PER_SET, &push));
       fc1.Gsrc = dtf_ipc_landing(e->shard_comm);  // the assembled global gradient (the push below zeroes the slice in G)
     }
     if (e->f32)
       DTF_TRY(dtf_conv2_bwd_data_f32_push(e->dpool2, (const float*)e->pool2, e->amax2, e->P + e->off_Wc2,
-                                          (const float*)e->pool1, e->dpool1, B, nullptr, shard ? &push : nullptr, st));
+                                          (const float*)e->pool1, e->dpool1, B, nullptr, shard && !wshard ? &push : nullptr,
+                                          st));
     else
       DTF_TRY(dtf_conv2_bwd_data_lds_packed(e->dpool2, e->pool2, e->amax2, e->wc2b, e->pool1, e->dpool1, e->G + e->off_bc2, B,
                                             st));
     // shard schedule: every rank's slice has left with the launch above; one-wave barrier "mine has landed / all have landed"
-    if (shard) DTF_TRY(dtf_ipc_sync(e->shard_comm, st));
+    if (shard && !wshard) DTF_TRY(dtf_ipc_sync(e->shard_comm, st));
     if (e->f32)
       DTF_TRY(dtf_conv_dw_duo_f32(e->dpool2, (const float*)e->pool2, e->amax2, (const float*)e->pool1, e->G + e->off_Wc2,
                                   e->G + e->off_bc2, B,
@@ -284,6 +325,35 @@ DTF_API int dtf_mnist_apply_part_ipc(const MnistEngine* e, int which, const void
   if (which == 2 && (e->off_Wfc1 != 0 || e->off_bfc1 % 4 || (e->n_arena - e->off_bfc1) % 4)) return -22;
   const OptimParams op = optim_range(e, which);
   return dtf_ipc_adam_oneshot(comm, &op, st);
+}
+
+// "wshard" schedule: P[W_fc1] -> both parity buffers of this rank (entering the schedule, or after the arena was rewritten:
+// every replica holds the same P then), and the buffer of the current parity -> P[W_fc1] (before anything reads P).
+namespace {
+__global__ __launch_bounds__(256) void wshard_store_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
+                                                           const int* __restrict__ step, float* __restrict__ dst, long n4) {
+  const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>((*step & 1) ? w1 : w0);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+    reinterpret_cast<f32x4*>(dst)[i] = src[i];
+}
+}  // namespace
+DTF_API int dtf_mnist_wshard_load(const MnistEngine* e, hipStream_t st) {
+  if (!e->wshard || !e->shard_comm || e->off_Wfc1 != 0 || e->gather_rank < 0 || e->gather_rank >= 8) return -22;
+  float* w[16];
+  DTF_TRY(dtf_ipc_wshard_bufs(e->shard_comm, 0, 3136L * 1024, w));
+  for (int par = 0; par < 2; ++par)
+    if (hipMemcpyAsync(w[par * 8 + e->gather_rank], e->P + e->off_Wfc1, 3136L * 1024 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return -1;
+  return 0;
+}
+DTF_API int dtf_mnist_wshard_store(const MnistEngine* e, hipStream_t st) {
+  if (!e->wshard || !e->shard_comm || e->off_Wfc1 != 0 || e->gather_rank < 0 || e->gather_rank >= 8) return -22;
+  float* w[16];
+  DTF_TRY(dtf_ipc_wshard_bufs(e->shard_comm, 0, 3136L * 1024, w));
+  hipLaunchKernelGGL(wshard_store_kernel, dim3(1024), dim3(256), 0, st, w[e->gather_rank], w[8 + e->gather_rank], e->step,
+                     e->P + e->off_Wfc1, 3136L * 1024 / 4);
+  DTF_CHECK_LAUNCH();
+  return 0;
 }
 
 // Inference / evaluation over n samples (contiguous or via `index`), chunked by the workspace size.

@@ -627,7 +627,10 @@ __global__ __launch_bounds__(512) void conv_dw_duo_f32_kernel(const ConvDwDuo32 
     conv2_dw_f32_body(smem32, id, a.pool1, a.dpool2, a.pool2, a.amax2, a.dW2, a.db2, a.B);
   else if (id >= a.n2 + a.n1) {
     CSTAMP(0);
-    adam_tf_body(a.adam, id - a.n2 - a.n1, a.nadam, 512);
+    if (a.adam.wsh_world > 0)  // (launch-uniform) "wshard": this rank's slice only, stored into every rank's next-parity buffer
+      adam_tf_body<false, true>(a.adam, id - a.n2 - a.n1, a.nadam, 512);
+    else
+      adam_tf_body(a.adam, id - a.n2 - a.n1, a.nadam, 512);
     CSTAMP(5);
   } else {
     CSTAMP(0);
@@ -715,6 +718,12 @@ DTF_API int dtf_conv_dw_duo_f32(const float* dpool2, const float* pool2, const v
                                 hipStream_t st) {
   if (B <= 0 || (perm && spe <= 0)) return ERR_SHAPE;
   if (adam && (adam->n <= 0 || adam->n % 4 || adam->zero_from % 4 || !adam->step)) return ERR_SHAPE;
+  if (adam && adam->wsh_world != 0) {  // "wshard": the slice's place in every rank's two parameter buffers
+    if (adam->wsh_world < 1 || adam->wsh_world > 8 || adam->wsh_rank < 0 || adam->wsh_rank >= adam->wsh_world) return ERR_SHAPE;
+    for (int par = 0; par < 2; ++par)
+      for (int r = 0; r < adam->wsh_world; ++r)
+        if (!adam->Wsh[par][r] || (reinterpret_cast<uintptr_t>(adam->Wsh[par][r]) & 15)) return ERR_SHAPE;
+  }
   if (!g_f32_attr_set) {
     const int rc = dtf_conv2_f32_init();
     if (rc) return rc;

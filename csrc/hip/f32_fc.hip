@@ -71,6 +71,17 @@ DTF_API int dtf_fc_fwd_f32(const float* X, const float* W, float* out, int M, in
   return dtf_launch_gemm32<112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store, 2, 2>(p, s, st);
 }
 
+// The same with W double-buffered by step parity ("wshard" schedule, engine.hip: MnistEngine::wshard): W1 is read when *sel is odd.
+DTF_API int dtf_fc_fwd_f32_sel(const float* X, const float* W0, const float* W1, const int* sel, float* out, int M, int N,
+                               int K, int splits, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 4 || N % 4 || splits < 1 || !aligned16(X) || !aligned16(W0) || !W1 || !aligned16(W1) || !sel)
+    return ERR_SHAPE;
+  GemmParams p = base_params32(X, W0, out, M, N, K, K, N, N, splits, 32);
+  p.bsel = sel;
+  p.B_alt = W1;
+  return dtf_launch_gemm32_bsel<112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store, 2, 2>(p, eff_splits32(p), st);
+}
+
 #ifdef DTF_GEMM32_STAMPS
 DTF_API int dtf_fc_fwd_f32_stamps(const float* X, const float* W, float* out, int M, int N, int K, int splits, void* stamps,
                                   hipStream_t st) {
@@ -133,6 +144,14 @@ __global__ __launch_bounds__(256, 3) void fc_bwd_trio_f32_kernel(const GemmTrio3
   const int id = blockIdx.x;
   if (id < g.nblk_q) {
     const int mt = id % g.q_mt, r = id / g.q_mt;
+    if constexpr (MODE == 2 || MODE == 3) {
+      if (g.q.bsel) {  // "wshard": W_fc1 double-buffered by step parity (workgroup-uniform choice)
+        GemmParams q = g.q;
+        if (*g.q.bsel & 1) q.B = g.q.B_alt;
+        dtf_gemm32_body<112, 64, 32, 1, 4, BdA, BdB, Ep32Atomic>(q, mt * 112, (r % g.q_nt) * 64, r / g.q_nt, smem);
+        return;
+      }
+    }
     dtf_gemm32_body<112, 64, 32, 1, 4, BdA, BdB, Ep32Atomic>(g.q, mt * 112, (r % g.q_nt) * 64, r / g.q_nt, smem);
   } else if (id < g.nblk_q + g.nblk0) {
     const int k = id - g.nblk_q;
@@ -214,11 +233,13 @@ DTF_API int dtf_fc_bwd_trio_f32(const float* X0, const float* dY0, float* dW0, i
 // gA[r]: rank r's [K][>= M0_slice] operand block with row pitch lda0, already offset to the slice's first column;
 // gB[r]: rank r's [K][N0] block.  K (a multiple of 20) is split into sets of ranks_per_set source ranks: with more than one
 // set the sets accumulate with atomics and dW0_slice must be zero on entry (the push that follows re-zeroes it); one set
-// stores.  Problems 1 and q as in dtf_fc_bwd_trio_f32.
+// stores.  Problems 1 and q as in dtf_fc_bwd_trio_f32; Wq_alt / wq_sel (both or neither): Wq_alt replaces Wq when *wq_sel is odd.
 DTF_API int dtf_fc_bwd_trio_f32_shard(const float* X1, const float* dY1, int ldy1, float* dW1, int M1, int N1, int K,
                                       const float* dYq, const float* Wq, float* dXq, int Mq, int Nq, int Kq, int splits,
                                       const void* const* gA, const void* const* gB, int granks, int ranks_per_set, int lda0,
-                                      float* dW0_slice, int M0_slice, int N0, hipStream_t st) {
+                                      float* dW0_slice, int M0_slice, int N0, const float* Wq_alt, const int* wq_sel,
+                                      hipStream_t st) {
+  if ((Wq_alt != nullptr) != (wq_sel != nullptr) || (Wq_alt && !aligned16(Wq_alt))) return ERR_SHAPE;
   if (M0_slice <= 0 || N0 <= 0 || M1 <= 0 || N1 <= 0 || K <= 0 || M0_slice % 4 || N0 % 4 || M1 % 4 || N1 > 16 || ldy1 % 4 ||
       ldy1 < N1 || lda0 % 4 || lda0 < M0_slice)
     return ERR_SHAPE;
@@ -241,6 +262,8 @@ DTF_API int dtf_fc_bwd_trio_f32_shard(const float* X1, const float* dY1, int ldy
   g.nblk0 = g.mt0 * dtf_cdiv(N0, 64) * g.ksets;
   const int nblk1 = g.mt1 * dtf_cdiv(N1, 16);
   g.q = base_params32(dYq, Wq, dXq, Mq, Nq, Kq, Kq, Kq, Nq, splits, 32);
+  g.q.bsel = wq_sel;  // (optional: Wq double-buffered by the parity of *wq_sel)
+  g.q.B_alt = Wq_alt;
   const int s = eff_splits32(g.q);
   if (s < 2) return ERR_SHAPE;
   g.q_mt = dtf_cdiv(Mq, 112);

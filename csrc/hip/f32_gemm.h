@@ -321,10 +321,28 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void dtf_gemm32_kernel(const Gem
   dtf_gemm32_body<BM, BN, BK, WM, WN, AL, BL, EP, PF, KW>(p, blockIdx.x * BM, blockIdx.y * BN, blockIdx.z, smem);
 }
 
+// The same with a double-buffered B operand (GemmParams::bsel): the buffer is chosen by the parity of a device word, so a
+// captured graph replays unchanged while the buffers alternate from step to step.
+template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int PF = 2, int KW = 1>
+__global__ __launch_bounds__(64 * WM * WN * KW) void dtf_gemm32_bsel_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[dtf_gemm32_lds<BM, BN, AL, BL>()];
+  GemmParams q = p;
+  if (*p.bsel & 1) q.B = p.B_alt;  // (workgroup-uniform)
+  dtf_gemm32_body<BM, BN, BK, WM, WN, AL, BL, EP, PF, KW>(q, blockIdx.x * BM, blockIdx.y * BN, blockIdx.z, smem);
+}
+
 template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int PF = 2, int KW = 1>
 static inline int dtf_launch_gemm32(const GemmParams& p, int splits, hipStream_t st) {
   dim3 grid(dtf_cdiv(p.M, BM), dtf_cdiv(p.N, BN), splits);
   hipLaunchKernelGGL((dtf_gemm32_kernel<BM, BN, BK, WM, WN, AL, BL, EP, PF, KW>), grid, dim3(64 * WM * WN * KW), 0, st, p);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int PF = 2, int KW = 1>
+static inline int dtf_launch_gemm32_bsel(const GemmParams& p, int splits, hipStream_t st) {
+  if (!p.bsel || !p.B_alt) return -22;
+  dim3 grid(dtf_cdiv(p.M, BM), dtf_cdiv(p.N, BN), splits);
+  hipLaunchKernelGGL((dtf_gemm32_bsel_kernel<BM, BN, BK, WM, WN, AL, BL, EP, PF, KW>), grid, dim3(64 * WM * WN * KW), 0, st, p);
   DTF_CHECK_LAUNCH();
   return 0;
 }

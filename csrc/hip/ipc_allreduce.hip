@@ -515,6 +515,18 @@ DTF_API int dtf_ipc_shard_desc(const void* comm, long lo_floats, long n_floats, 
   return 0;
 }
 
+// "wshard" schedule (engine.hip: MnistEngine::wshard): a tensor of <= n_max floats lives in BOTH buffers of every rank's allocation, stage[]
+// = parity 0 and result[] = parity 1.  out[parity * 8 + r] = element `lo_floats` of rank r's buffer of that parity.
+DTF_API int dtf_ipc_wshard_bufs(const void* comm, long lo_floats, long n_floats, float** out) {
+  const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
+  if (c.world < 1 || c.world > MAX_RANKS || c.rank < 0 || c.rank >= c.world || !out) return -22;
+  if (lo_floats < 0 || n_floats <= 0 || lo_floats % 4 || n_floats % 4 || lo_floats + n_floats > c.n_max) return -22;
+  for (int par = 0; par < 2; ++par)
+    for (int r = 0; r < MAX_RANKS; ++r)
+      out[par * MAX_RANKS + r] = r < c.world ? reinterpret_cast<float*>(c.base[r] + HDR_BYTES) + (par ? c.n_max : 0) + lo_floats : nullptr;
+  return 0;
+}
+
 DTF_API const float* dtf_ipc_landing(const void* comm) {
   const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
   return reinterpret_cast<const float*>(c.base[c.rank] + HDR_BYTES) + c.n_max;

@@ -193,9 +193,15 @@ def run(FLAGS, distributed: bool) -> int:
                 if writer is not None:
                     s = Summary().scalar("eval/test_accuracy", test_acc).scalar("eval/train_accuracy", train_acc)
                     if FLAGS.variable_summaries:
+                        if hasattr(trainer, "sync_params"):
+                            trainer.sync_params()
                         for name, v in engine.param_views().items():
                             s.merge(variable_summaries(name, v))
                     writer.add_summary(s, last)
+        if hasattr(trainer, "materialize") and (sv is None or sv.clean_stop()):
+            # a schedule with sharded optimizer state assembles the state of THIS step for the final checkpoint (collective:
+            # every rank left the loop at the same step); after a failure the last agreed snapshot is saved instead
+            trainer.materialize(snapshot=True)
     except BaseException as e:  # noqa: BLE001
         rc = 1
         if sv is not None:

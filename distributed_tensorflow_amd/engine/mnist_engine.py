@@ -147,6 +147,8 @@ class NativeMnistEngine(_EngineBase):
         self.cfg = s
         self._graphs = {}
         self.grad_hook = None
+        self.state_provider = None   # set by the data-parallel trainer while the live arenas are not a consistent state
+        self.on_state_loaded = None  # called after the arenas were rewritten from outside (restore, re-initialisation)
         # stream capture vs. snapshots from other threads (the Supervisor's autosave thread calls state_dict()): work
         # enqueued on a capturing stream would be recorded into the step graph, and synchronising it invalidates the capture
         import threading
@@ -167,6 +169,8 @@ class NativeMnistEngine(_EngineBase):
             for k, v in self.param_views().items():
                 v.copy_(torch.as_tensor(params[k]).to(self.device, torch.float32).reshape(v.shape))
         self.stream.synchronize()
+        if getattr(self, "on_state_loaded", None) is not None:
+            self.on_state_loaded()
 
     def bucket_bounds(self) -> Tuple[Tuple[int, int], Tuple[int, int]]:
         """Gradient buckets in readiness order: A = fc layers (after part 1), B = conv layers (after part 2)."""
@@ -182,6 +186,8 @@ class NativeMnistEngine(_EngineBase):
     def state_dict(self) -> Dict[str, torch.Tensor]:
         # snapshot in stream order (between two steps) so a saver thread never sees a half-applied update; never while
         # the training thread has a capture open on the stream
+        if self.state_provider is not None:  # (optimizer state sharded over the ranks: the trainer's last consistent snapshot)
+            return self.state_provider()
         with self._capture_lock:
             with torch.cuda.stream(self.stream):
                 sd = {"P": self.P.clone(), "M": self.M.clone(), "V": self.V.clone(), "step": self.step_t.clone()}
@@ -196,6 +202,8 @@ class NativeMnistEngine(_EngineBase):
             self.step_t.copy_(sd["step"].to(self.device).to(torch.int32))
         self.stream.synchronize()
         self._steps_done = int(self.step_t.item())
+        if self.on_state_loaded is not None:
+            self.on_state_loaded()
 
     @property
     def global_step(self) -> int:
@@ -388,6 +396,7 @@ class NativeMnistEngine(_EngineBase):
         The caller zeroes G's fc1 segment before the first shard step (the slice is accumulated with atomics)."""
         if ipc_act is None or ipc_w is None:
             self.cfg.shard_n = 0
+            self.cfg.wshard = 0
             self.cfg.shard_comm = None
             self.set_gather(None)
             return
@@ -396,7 +405,25 @@ class NativeMnistEngine(_EngineBase):
         lo, hi = self.shard_rows(ipc_act.rank, ipc_act.world)
         self.cfg.shard_comm = ipc_w.comm_addr
         self.cfg.shard_n, self.cfg.shard_lo, self.cfg.shard_w = ipc_act.world, lo, hi - lo
+        self.cfg.wshard = 0
         self._drop_graph()
+
+    def set_wshard(self, ipc_act, ipc_w) -> None:
+        """Data-parallel "wshard" schedule (``csrc/hip/engine.hip``, ``MnistEngine::wshard``): as ``set_shard``, but the
+        slices that travel are the updated WEIGHTS.  W_fc1 lives in the two buffers of ``ipc_w`` (alternating by step
+        parity) instead of in ``P``; this rank applies Adam to its rows only and stores them into every rank's buffer of the
+        next parity.  ``P[W_fc1]`` and the optimizer state outside this rank's rows go stale until ``wshard_store()`` / the
+        trainer's ``materialize()``.  The caller loads the buffers (``wshard_load``) before the first step."""
+        self.set_shard(ipc_act, ipc_w)
+        self.cfg.wshard = 1
+
+    def wshard_load(self) -> None:
+        """P[W_fc1] -> both parity buffers of this rank (every replica holds the same P when this is called)."""
+        native.check(self.lib.dtf_mnist_wshard_load(C.byref(self.cfg), self.stream.cuda_stream), "wshard load")
+
+    def wshard_store(self) -> None:
+        """The buffer of the current step parity -> P[W_fc1] (stream-ordered, local)."""
+        native.check(self.lib.dtf_mnist_wshard_store(C.byref(self.cfg), self.stream.cuda_stream), "wshard store")
 
     def set_grad_hook(self, hook) -> None:
         """``hook.after_part1(stream)`` / ``hook.after_part2(stream)`` run inside the ``full`` segment after the fc

@@ -73,6 +73,7 @@ class MnistEngineStruct(C.Structure):  # csrc/hip/engine.hip: struct MnistEngine
         ("gather_local", c_void_p), ("gather_bytes", c_long),
         ("f32", c_int), ("skip", c_void_p),
         ("shard_comm", c_void_p), ("shard_n", c_int), ("shard_lo", c_int), ("shard_w", c_int),
+        ("wshard", c_int),
     ]
 
 
@@ -156,6 +157,8 @@ def hip() -> C.CDLL:
         _sig(lib, "dtf_mnist_apply", I, [C.POINTER(MnistEngineStruct), P])
         _sig(lib, "dtf_mnist_apply_part", I, [C.POINTER(MnistEngineStruct), I, P])
         _sig(lib, "dtf_mnist_apply_part_ipc", I, [C.POINTER(MnistEngineStruct), I, P, P])
+        _sig(lib, "dtf_mnist_wshard_load", I, [C.POINTER(MnistEngineStruct), P])
+        _sig(lib, "dtf_mnist_wshard_store", I, [C.POINTER(MnistEngineStruct), P])
         _sig(lib, "dtf_mnist_eval", I, [C.POINTER(MnistEngineStruct), P, P, I, P, P, P, P])
         # exact-fp32 (reference precision) kernels: f32_fc.hip, f32_conv2.hip
         _sig(lib, "dtf_fc_fwd_f32", I, [P, P, P, I, I, I, I, P, I, P])

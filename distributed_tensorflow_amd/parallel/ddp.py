@@ -195,6 +195,7 @@ class DataParallelTrainer:
     def __init__(self, engine, *, sync: bool = True, async_period: int = 8, group=None, overlap: bool = True,
                  force_collectives: bool = False, comm: str = "auto"):
         self.engine = engine
+        self._wsh = False          # the "ipc-wshard" schedule is active (see _wsh_enter)
         # force_collectives: take the multi-rank code path even with one rank (lets a 1-GPU box exercise the
         # RCCL stream/event choreography of the overlapped step end to end)
         self._force = force_collectives and dist.is_initialized()
@@ -232,6 +233,10 @@ class DataParallelTrainer:
         self.schedule = None
         self.ipc_act = None
         self.ipc_w = None          # landing buffers of the shard schedule (fc1 filter gradient, 12.8 MB per rank)
+        # "ipc-wshard" schedule: W_fc1 lives in ipc_w's buffers and its optimizer state is sharded over the ranks; the live
+        # arenas are then not a consistent state between two materialize() calls (see there)
+        self._wsh_snap = None      # last consistent (P, M, V, step) on this rank, what a checkpoint is written from
+        self._wsh_every = max(16, int(os.environ.get("DTF_WSHARD_SNAPSHOT_STEPS", "2000")))
         self._shared_gpu = False
         import time
         t_start = self._t_start = time.perf_counter()
@@ -412,17 +417,22 @@ class DataParallelTrainer:
         # "gather": exchange the fc1 filter gradient's OPERANDS (0.8 MB/rank) instead of the gradient (12.8 MB) through a
         # second, small exchange buffer
         gather_ok = zc_ok and hasattr(e, "gather_supported") and e.gather_supported() and \
-            forced in ("auto", "ipc-gather", "ipc-shard")
+            forced in ("auto", "ipc-gather", "ipc-shard", "ipc-wshard")
         if gather_ok and self.ipc_act is None:
             self.ipc_act = exchange_buffer(sum(e.gather_bytes()) // 4)
             gather_ok = self.ipc_act is not None
         # "shard": the same operand exchange, but every rank computes only its 1/world row slice of the global gradient and
         # pushes it into every rank's landing buffer: per-rank work independent of the world size (csrc/hip/shard_body.h)
-        shard_ok = gather_ok and hasattr(e, "shard_supported") and e.shard_supported() and forced in ("auto", "ipc-shard")
+        shard_ok = gather_ok and hasattr(e, "shard_supported") and e.shard_supported() and \
+            forced in ("auto", "ipc-shard", "ipc-wshard")
         if shard_ok and self.ipc_w is None:
             self.ipc_w = exchange_buffer(e.fc1_grad_numel())
             shard_ok = self.ipc_w is not None
-        cands = sel.candidates(shard_ok=shard_ok, gather_ok=gather_ok and forced != "ipc-shard", zc_ok=zc_ok, shared_gpu=shared,
+        # "wshard": the slices that travel are updated weights, the optimizer state of W_fc1 is sharded (engine.hip)
+        wshard_ok = shard_ok and hasattr(e, "set_wshard") and os.environ.get("DTF_WSHARD", "1") != "0"
+        cands = sel.candidates(wshard_ok=wshard_ok and forced in ("auto", "ipc-wshard"),
+                               shard_ok=shard_ok and forced in ("auto", "ipc-shard"),
+                               gather_ok=gather_ok and forced in ("auto", "ipc-gather"), zc_ok=zc_ok, shared_gpu=shared,
                                allow_rccl=allow_rccl, host_staged=self._stage_host, forced=forced)
         self._ipc_hook, self._fc1_end = e.grad_hook, fc1_end
         use = self._use_schedule
@@ -458,6 +468,7 @@ class DataParallelTrainer:
                     # one step from the snapshot: Adam's first moment is linear in the gradient, m' = b1*m + (1-b1)*g, which
                     # gives the reduced gradient this schedule produced, wherever it keeps it
                     trainer.train_steps(1)
+                    trainer.materialize()  # (wshard: every rank's slice of the first moment)
                     with trainer._ctx():
                         return (e.M - b1 * snap[1]) / (1.0 - b1)
 
@@ -486,6 +497,7 @@ class DataParallelTrainer:
                             e.skip_t.zero_()
                     e.stream.synchronize()
                     e._steps_done = done0
+                    trainer._wsh_reload()
 
                 def over_budget(self):
                     """Start-up (self-tests + trials so far) has used its budget on some rank (agreed across ranks)."""
@@ -516,16 +528,18 @@ class DataParallelTrainer:
 
     def _use_schedule(self, c: str) -> None:
         e, hook, fc1_end = self.engine, self._ipc_hook, self._fc1_end
-        zc, sh = c == "ipc-zerocopy", c == "ipc-shard"
-        ga = c == "ipc-gather" or sh  # (the shard schedule rides on the gather schedule's operand exchange and publish)
+        self._wsh_leave()  # (collective, like every change of schedule)
+        zc, wsh = c == "ipc-zerocopy", c == "ipc-wshard"
+        sh = c == "ipc-shard" or wsh
+        ga = c == "ipc-gather" or sh  # (the shard schedules ride on the gather schedule's operand exchange and publish)
         if self.ipc is not None or zc:
             e.set_grad_redirect(self.ipc.stage_ptr if zc else 0, self.ipc.result_ptr if zc else 0)
         if hasattr(e, "set_shard"):
             e.set_shard(None)  # (also switches the gather exchange off)
         if sh:
-            e.set_shard(self.ipc_act, self.ipc_w)
+            (e.set_wshard if wsh else e.set_shard)(self.ipc_act, self.ipc_w)
             with torch.cuda.stream(e.stream):
-                e.G[:fc1_end].zero_()  # this rank's slice of the fc1 gradient is accumulated with atomics and re-zeroed by the push
+                e.G[:fc1_end].zero_()  # this rank's slice of the fc1 gradient is accumulated with atomics and re-zeroed by its reader
         elif hasattr(e, "set_gather"):
             e.set_gather(self.ipc_act if ga else None)
         self._rccl_graph = False
@@ -545,6 +559,71 @@ class DataParallelTrainer:
             e.set_grad_hook(hook)  # (drops the captured graphs)
             self.comm = "ipc"
         self.schedule = c
+        if wsh:
+            self._wsh_enter()
+
+    # ------------------------------------------------------------------ "ipc-wshard": sharded state
+    def _wsh_enter(self) -> None:
+        """The arenas are consistent and identical on every rank here (start-up, or right after a restore)."""
+        e = self.engine
+        e.wshard_load()
+        self._wsh = True
+        self._wsh_snapshot()
+        e.state_provider = self._wsh_state
+        e.on_state_loaded = self._wsh_reload
+
+    def _wsh_reload(self) -> None:
+        """The arenas were rewritten from outside (checkpoint restore, broadcast, trial snapshot): W_fc1's buffers follow."""
+        if self._wsh:
+            self.engine.wshard_load()
+            self._wsh_snapshot()
+
+    def _wsh_snapshot(self) -> None:
+        e = self.engine
+        with e._capture_lock:
+            with torch.cuda.stream(e.stream):
+                snap = {"P": e.P.clone(), "M": e.M.clone(), "V": e.V.clone(), "step": e.step_t.clone()}
+            e.stream.synchronize()
+        self._wsh_snap = snap
+
+    def _wsh_state(self):
+        """What ``engine.state_dict()`` returns under this schedule: the last state every rank agreed on (at most
+        ``DTF_WSHARD_SNAPSHOT_STEPS`` steps old), not the live arenas, whose optimizer rows of the other ranks are stale."""
+        return {k: v.clone() for k, v in self._wsh_snap.items()}
+
+    def sync_params(self) -> None:
+        """Make ``engine.P`` current (local, stream-ordered; a no-op for every schedule that keeps it current anyway)."""
+        if self._wsh:
+            self.engine.wshard_store()
+
+    def materialize(self, snapshot: bool = False) -> None:
+        """Collective.  Under "ipc-wshard": bring the live arenas to the consistent state of this step — W_fc1 from its
+        current buffer, every rank's rows of M and V from their owner (process-group broadcasts: this is not on the step's
+        path) — and optionally keep it as the checkpoint snapshot.  A no-op for every other schedule."""
+        if not self._wsh:
+            return
+        e = self.engine
+        e.wshard_store()
+        n = e.fc1_grad_numel()
+        cols = n // 3136
+        with self._ctx():
+            for r in range(self.world):
+                lo, hi = e.shard_rows(r, self.world)
+                for t in (e.M, e.V):
+                    self._bcast(t[lo * cols:hi * cols], r)
+        if snapshot:
+            self._wsh_snapshot()
+
+    def _wsh_leave(self) -> None:
+        if not self._wsh:
+            return
+        self.materialize()
+        e = self.engine
+        e.stream.synchronize()
+        self._wsh = False
+        self._wsh_snap = None
+        e.state_provider = None
+        e.on_state_loaded = None
 
     def ensure_healthy(self) -> bool:
         """Call between steps (synchronises).  If an in-kernel wait of the IPC exchange has expired on any rank since
@@ -623,7 +702,7 @@ class DataParallelTrainer:
 
     def broadcast_state(self, src: int = 0) -> None:
         """rank-``src`` parameters + optimizer state + step -> every replica."""
-        e = self.engine
+        e = self.engine  # (rank src's ARENAS are what counts: after materialize(), or after a restore)
         with self._ctx():
             for t in (e.P, e.M, e.V):
                 self._bcast(t, src)
@@ -634,9 +713,11 @@ class DataParallelTrainer:
             e._steps_done = int(e.step_t.item())
         else:
             e._steps_done = int(step.item())
+        self._wsh_reload()
 
     def close(self) -> None:
         """Release the IPC exchange buffers (collective: every rank calls it, before the process group is destroyed)."""
+        self._wsh_leave()
         if self.ipc is not None:
             self.engine.set_grad_redirect(0, 0)
             if hasattr(self.engine, "set_shard"):
@@ -676,6 +757,7 @@ class DataParallelTrainer:
         if not self._multi:
             return True
         e = self.engine
+        self.sync_params()
         with self._ctx():
             cs = torch.stack([e.P.double().sum(), e.P.double().abs().sum()])
             lo, hi = cs.clone(), cs.clone()
@@ -704,17 +786,18 @@ class DataParallelTrainer:
         if getattr(e, "dataset", None) is not None and e.spe - (e.global_step % e.spe) < 2:
             self.train_steps(1)  # (not across the reshuffle at an epoch boundary)
         b1 = float(e.cfg.beta1) if hasattr(e, "cfg") else float(getattr(e, "b1", 0.9))
+        self.materialize()  # (wshard: the local pass reads P, the comparison every rank's rows of the first moment)
         if self._native:
-            cfg, keep = e.cfg, (e.cfg.G_fc1_dst, e.cfg.G_src, e.cfg.gather_n, e.cfg.shard_n)
+            cfg, keep = e.cfg, (e.cfg.G_fc1_dst, e.cfg.G_src, e.cfg.gather_n, e.cfg.shard_n, e.cfg.wshard)
             with self._ctx():
                 ring = e.metrics_ring.clone()
-            cfg.G_fc1_dst, cfg.G_src, cfg.gather_n, cfg.shard_n = None, None, 0, 0   # plain local gradients into G (graphs are
-            try:                                                      # untouched: their arguments were bound at capture)
+            cfg.G_fc1_dst, cfg.G_src, cfg.gather_n, cfg.shard_n, cfg.wshard = None, None, 0, 0, 0   # plain local gradients
+            try:                                  # into G (graphs are untouched: their arguments were bound at capture)
                 with torch.cuda.stream(e.stream):
                     e.G.zero_()
                     e.fwd_bwd(3)
             finally:
-                cfg.G_fc1_dst, cfg.G_src, cfg.gather_n, cfg.shard_n = keep
+                cfg.G_fc1_dst, cfg.G_src, cfg.gather_n, cfg.shard_n, cfg.wshard = keep
             with self._ctx():
                 ref = e.G.clone()
                 e.G.zero_()
@@ -733,6 +816,7 @@ class DataParallelTrainer:
             m0 = e.M.clone()
         scale = 1.0 / self.world  # (local gradients are means over the local batch; the optimizer divides the sum by world)
         self.train_steps(1)
+        self.materialize()
         with self._ctx():
             # compared in first-moment space (recovering g itself cancels catastrophically once |g| << |m|); the floor
             # keeps the rounding of m' (~6e-8 |m'|) below the tolerance when the gradient has all but vanished
@@ -799,6 +883,16 @@ class DataParallelTrainer:
         """``n`` synchronous steps; several per graph launch where the whole step (incl. the gradient all-reduce) is
         plain kernels on the engine's stream (single replica, or the IPC transport)."""
         e = self.engine
+        if self._wsh:
+            # sharded optimizer state: every _wsh_every steps (the same steps on every rank) the ranks assemble the
+            # consistent state that checkpoints are written from
+            while n > 0:
+                k = min(n, self._wsh_every - e.global_step % self._wsh_every)
+                e.train_steps(k)
+                n -= k
+                if e.global_step % self._wsh_every == 0:
+                    self.materialize(snapshot=True)
+            return
         if self._native and (not self._multi or (self.sync and self._one_graph())):
             e.train_steps(n)
             return
@@ -807,6 +901,9 @@ class DataParallelTrainer:
 
     def train_step(self) -> None:
         e = self.engine
+        if self._wsh:
+            self.train_steps(1)
+            return
         if not self._multi:
             e.train_step()
             return

@@ -98,6 +98,7 @@ class Supervisor:
         self._failure_seen_at: Optional[float] = None
         self._acknowledged = False  # True once this rank has drained (nothing left that could block on a peer)
         self._stop_key = "sv/stop"
+        self.peer_failed = False  # a peer raised, died or never voted: no further collective with it
         # agreed stop step (graceful stops only)
         self.stop_margin_steps = max(1, stop_margin_steps)
         self._vote: Optional[int] = None
@@ -234,12 +235,14 @@ class Supervisor:
         while self.stop_at is None:
             votes = None if self.dead_ranks else self._read_votes()
             if self.dead_ranks or (votes is not None and min(votes) < 0):
+                self.peer_failed = True
                 return True  # someone is gone: no agreement possible, leave (the watchdog stays armed until drained)
             if votes is not None:
                 self.stop_at = max(votes)
             elif step < self._vote:
                 return False  # keep training below the own vote; look again at the next call
             elif time.time() - t0 > max(1.0, self.fatal_grace_s):
+                self.peer_failed = True
                 return True  # a peer never voted (it is blocked or gone): same as a failure
             else:
                 time.sleep(min(0.05, self.heartbeat_period_s / 4.0))
@@ -265,14 +268,23 @@ class Supervisor:
                 try:
                     failed = self.last_exception is not None or bool(self.dead_ranks) or (self._vote is not None and self._vote < 0)
                     self._stop_global = True if failed else self._agree_stop_step(self.engine.global_step)
+                    self.peer_failed = self.peer_failed or failed
                 except ConnectionError:
                     self._stop_global = True
+                    self.peer_failed = True
             return self._stop_global
         self._steps_since_check += max(1, steps)
         if force_check or self._steps_since_check >= self.stop_check_interval or self.trainer.world == 1:
             self._steps_since_check = 0
             self._stop_global = self.trainer.any_rank(self._stop_local.is_set())
         return self._stop_global
+
+    def clean_stop(self) -> bool:
+        """Every rank left (or will leave) its loop at the same step and nobody failed: training ran to its end, or a stop
+        was agreed.  Only then may the drivers run one more collective (e.g. assembling sharded optimizer state for the
+        final checkpoint) before ``stop()``."""
+        return self.last_exception is None and not self.dead_ranks and not self.peer_failed and \
+            not (self._vote is not None and self._vote < 0)
 
     def _drain(self) -> None:
         """Wait for everything this rank has enqueued.  Unbounded by itself (RCCL has no per-call timeout): while it

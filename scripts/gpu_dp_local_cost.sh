@@ -8,7 +8,7 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 DT=${1:-fp32}
 mkdir -p gpurun_out/dp_local
 port=29700
-for sch in plain ipc-shard ipc-gather ipc-zerocopy ipc-inline ipc-overlap rccl; do
+for sch in plain ipc-wshard ipc-shard ipc-gather ipc-zerocopy ipc-inline ipc-overlap rccl; do
   port=$((port + 1))
   if [ $sch = plain ]; then
     extra=""
@@ -17,7 +17,7 @@ for sch in plain ipc-shard ipc-gather ipc-zerocopy ipc-inline ipc-overlap rccl; 
   else
     extra="--dp-path --comm ipc"; export DTF_DP_SCHEDULE=$sch; [ $sch = ipc-overlap ] && export DTF_IPC_FORCE_OVERLAP=1
   fi
-  MASTER_ADDR=127.0.0.1 MASTER_PORT=$port timeout -k 10 200 python bench.py --gpus 1 --steps 3000 --warmup 300 --dtype $DT --extra-dtype none --ref-steps 0 $extra \
+  MASTER_ADDR=127.0.0.1 MASTER_PORT=$port timeout -k 10 200 python bench.py --gpus 1 --steps 3000 --warmup 300 --dtype $DT --extra-dtype none --ref-steps 0 --no-extras $extra \
     > gpurun_out/dp_local/$DT-$sch.log 2>&1 || { echo "$sch FAILED"; tail -8 gpurun_out/dp_local/$DT-$sch.log; exit 1; }
   unset DTF_DP_SCHEDULE DTF_IPC_FORCE_OVERLAP
   grep "^{" gpurun_out/dp_local/$DT-$sch.log | python -c "

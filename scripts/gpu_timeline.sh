@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/tl${1:+_$1}
 mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace -d $OUT -o tl -- python3 bench.py --gpus 1 --steps 300 --warmup 50 --extra-dtype none --ref-steps 0 ${DTF_BENCH_ARGS} > $OUT/run.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace -d $OUT -o tl -- python3 bench.py --gpus 1 --steps 300 --warmup 50 --extra-dtype none --ref-steps 0 --no-extras ${DTF_BENCH_ARGS} > $OUT/run.log 2>&1
 DB=$(ls $OUT/*.db | head -1)
 python scripts/prof_timeline.py $DB 60 > $OUT/timeline.txt
 python scripts/prof_summary.py $DB 20 0.5 > $OUT/summary.txt

@@ -164,8 +164,10 @@ def test_fault_injection_stops_all_ranks(tmp_path):
     assert "injected fault at step 3" in r.stdout
     # the survivor (the chief) leaves its loop through the out-of-band stop flag and saves the last consistent state
     assert "stopped at global step" in r.stdout and "Supervisor: final checkpoint" in r.stdout, r.stdout[-3000:]
-    saved = [f for f in os.listdir(os.path.join(cwd, "logs")) if f.startswith("model.ckpt-")]
-    assert saved and all(3 <= int(f.rsplit("-", 1)[1].split(".")[0]) < 40 for f in saved), saved
+    import re
+    names = os.listdir(os.path.join(cwd, "logs"))
+    saved = [int(m.group(1)) for m in (re.fullmatch(r"model\.ckpt-(\d+)", f) for f in names) if m]
+    assert saved and all(3 <= s < 40 for s in saved), names
 
 
 def test_rank_that_dies_silently_ends_the_job_in_bounded_time(tmp_path):

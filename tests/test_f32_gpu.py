@@ -121,7 +121,7 @@ def test_fc_backward_trio_f32_shard(world, rank):
     from distributed_tensorflow_amd.engine.mnist_engine import NativeMnistEngine
     lib = native.hip()
     P, I = C.c_void_p, C.c_int
-    lib.dtf_fc_bwd_trio_f32_shard.argtypes = [P, P, I, P, I, I, I, P, P, P, I, I, I, I, P, P, I, I, I, P, I, I, P]
+    lib.dtf_fc_bwd_trio_f32_shard.argtypes = [P, P, I, P, I, I, I, P, P, P, I, I, I, I, P, P, I, I, I, P, I, I, P, P, P]
     lib.dtf_fc_bwd_trio_f32_shard.restype = I
     torch.manual_seed(50 + 8 * world + rank)
     B = 100
@@ -145,7 +145,7 @@ def test_fc_backward_trio_f32_shard(world, rank):
     torch.cuda.synchronize()
     rc = lib.dtf_fc_bwd_trio_f32_shard(hdrop.data_ptr(), dz.data_ptr(), 16, dW1.data_ptr(), 1024, 10, B, dhs[rank].data_ptr(),
                                        w.data_ptr(), dX.data_ptr(), B, 3136, 1024, 6, ga, gb, world, 2, 3136,
-                                       dW0.data_ptr() + 4 * lo * 1024, hi - lo, 1024, None)
+                                       dW0.data_ptr() + 4 * lo * 1024, hi - lo, 1024, None, None, None)
     assert rc == 0
     torch.cuda.synchronize()
     ref0 = sum(x[:, lo:hi].double().t() @ d.double() for x, d in zip(xs, dhs))
@@ -153,6 +153,20 @@ def test_fc_backward_trio_f32_shard(world, rank):
     assert bool((dW0[:lo] == 7.0).all()) and bool((dW0[hi:] == 7.0).all())
     assert relerr(dW1, hdrop.double().t() @ dz[:, :10].double()) < 2e-6
     assert relerr(dX, dhs[rank].double() @ w.double().t()) < 1e-5
+    # "wshard": the data gradient's weight operand is double-buffered by the parity of a device word
+    w2 = torch.randn(3136, 1024, device=dev()) * 0.05
+    for word, wexp in ((6, w), (9, w2)):
+        sel = torch.tensor([word], dtype=torch.int32, device=dev())
+        dX.zero_()
+        dW0[lo:hi] = 0.0
+        torch.cuda.synchronize()
+        rc = lib.dtf_fc_bwd_trio_f32_shard(hdrop.data_ptr(), dz.data_ptr(), 16, dW1.data_ptr(), 1024, 10, B, dhs[rank].data_ptr(),
+                                           w.data_ptr(), dX.data_ptr(), B, 3136, 1024, 6, ga, gb, world, 2, 3136,
+                                           dW0.data_ptr() + 4 * lo * 1024, hi - lo, 1024, w2.data_ptr(), sel.data_ptr(), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert relerr(dX, dhs[rank].double() @ wexp.double().t()) < 1e-5
+        assert relerr(dW0[lo:hi], ref0) < 2e-6
 
 
 def _conv2_ref(x, w, b):
