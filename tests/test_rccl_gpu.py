@@ -6,6 +6,7 @@ sharing the GPU over the IPC exchange.  Reference behaviour being replaced: ``/r
 """
 import json
 import os
+import re
 import subprocess
 import sys
 
@@ -357,3 +358,26 @@ def test_retrain_head_dp_step_uses_the_native_communicator(tmp_path):
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["pg_calls"] == 0 and out["maxdiff"] < 1e-6 and out["async_error"] is None, out
     assert out["us_per_dp_step"] < 150.0, out
+
+
+def test_demo2_two_ranks_weight_sharded_schedule_final_checkpoint_and_resume(tmp_path):
+    """demo2 with two ranks sharing the GPU under "ipc-wshard" (sharded optimizer state): the checked steps pass, the final
+    checkpoint is the state of the LAST step (assembled collectively at the clean end of training, not the last snapshot),
+    and a relaunch restores it, re-loads W_fc1's buffers and trains on (``/root/reference/demo2/train.py:166-184``)."""
+    cwd = str(tmp_path)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DTF_DP_SCHEDULE="ipc-wshard", DTF_WSHARD_SNAPSHOT_STEPS="64",
+               PYTHONPATH=REPO)
+    common = ["--num_gpus", "2", "--backend", "gloo", "--synthetic", "true", "--eval_step_interval", "100", "--eval_train_set",
+              "false", "--seed", "3", "--save_model_secs", "0", "--check_replicas"]
+    r = subprocess.run([sys.executable, os.path.join(REPO, "demo2", "train.py"), "--training_steps", "301"] + common, cwd=cwd, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "schedule ipc-wshard" in r.stdout and r.stdout.count("checked step") >= 2, r.stdout[-3000:]
+    assert os.path.exists(os.path.join(cwd, "logs", "model.ckpt-301")), os.listdir(os.path.join(cwd, "logs"))
+    acc1 = [float(m) for m in re.findall(r"test_acc: ([0-9.]+)", r.stdout)]
+    r2 = subprocess.run([sys.executable, os.path.join(REPO, "demo2", "train.py"), "--training_steps", "402"] + common, cwd=cwd, env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stdout[-3000:]
+    assert "restored" in r2.stdout and "global_step=301" in r2.stdout, r2.stdout[-3000:]
+    acc2 = [float(m) for m in re.findall(r"test_acc: ([0-9.]+)", r2.stdout)]
+    assert acc1[-1] > 0.6 and acc2 and acc2[-1] >= acc1[-1] - 0.05, (acc1, acc2)   # (it continued: a fresh start is at 0.1)

@@ -204,3 +204,26 @@ def test_chief_does_not_checkpoint_after_its_own_consistency_error(tmp_path):
     sv.request_stop(ConnectionError("peer went away"))
     sv.stop(final_save=True)
     assert len(saved) == 1
+
+
+def test_clean_stop_is_false_after_any_failure():
+    """``clean_stop()`` gates the one extra collective a driver may run before ``stop()`` (assembling sharded optimizer
+    state for the final checkpoint): true after a normal end or an agreed stop, false once anybody failed."""
+    from distributed_tensorflow_amd.parallel.supervisor import Supervisor
+
+    class _T:
+        world, rank = 1, 0
+        engine = type("E", (), {"global_step": 0})()
+
+        def any_rank(self, f):
+            return f
+
+    sv = Supervisor(_T(), is_chief=True, logdir=None, save_model_secs=0)
+    assert sv.clean_stop()
+    sv.request_stop()            # a stop nobody failed for
+    assert sv.clean_stop()
+    sv.peer_failed = True
+    assert not sv.clean_stop()
+    sv2 = Supervisor(_T(), is_chief=True, logdir=None, save_model_secs=0)
+    sv2.request_stop(RuntimeError("boom"))
+    assert not sv2.clean_stop()
