@@ -42,7 +42,12 @@ DTF_API int dtf_dbg_set_conv_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP
 namespace {
 constexpr int ERR_SHAPE = -22;
 constexpr int XP = 36;                  // floats per input halo pixel (32 ch + 4 pad)
-constexpr int XIMG = 18 * 18 * XP;      // 11 664 floats
+// Row pitch of the halo'd input image in the forward kernel.  Its A fragments are ds_read_b64 (banks mod 64, conflicts
+// within 32-lane halves); a half reads the 16 pixels of 4 pooling windows = 8 columns x 2 rows.  With 9 four-bank units
+// per pixel the 8 columns cover 8 different units (9 is odd) and the second row must add 8 units: 672 / 4 = 168 = 8 mod 16
+// (18 * 36 = 648 gives 2: two-way conflicts on 6 of 16 pixels).  Windows that wrap to the next window row still collide.
+constexpr int XROW = 672;
+constexpr int XIMG = 18 * XROW;         // 12 096 floats
 constexpr int DP = 68;                  // floats per dY halo pixel (64 ch + 4 pad)
 constexpr int DIMG = 18 * 18 * DP;      // 22 032 floats
 }  // namespace
@@ -109,7 +114,8 @@ __global__ __launch_bounds__(512) void conv2_fwd_f32_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const int c = tid + 512 * i;
-      if (c < 2592) *reinterpret_cast<f32x4*>(img + s * XIMG + (c >> 3) * XP + (c & 7) * 4) = iv[s][i];
+      const int pix = c >> 3, hy = pix / 18, hx = pix - hy * 18;
+      if (c < 2592) *reinterpret_cast<f32x4*>(img + s * XIMG + hy * XROW + hx * XP + (c & 7) * 4) = iv[s][i];
     }
   }
   __syncthreads();
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(512) void conv2_fwd_f32_kernel(const float* __restr
     gw = gw < nwin ? gw : nwin - 1;  // padding windows of the last workgroup; their results are discarded
     const int slot = gw / 49 - b0, win = gw - (b0 + slot) * 49, sub = r & 3;
     const int py = win / 7, px = win - py * 7;
-    abase[mt] = slot * XIMG + ((2 * py + (sub >> 1)) * 18 + 2 * px + (sub & 1)) * XP + c0 + 2 * q;
+    abase[mt] = slot * XIMG + (2 * py + (sub >> 1)) * XROW + (2 * px + (sub & 1)) * XP + c0 + 2 * q;
   }
   f32x4 acc[FWD_MT][2];
 #pragma unroll
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(512) void conv2_fwd_f32_kernel(const float* __restr
 #pragma unroll
     for (int dx = 0; dx < 5; ++dx) {
       // next tap in (dy, dx) order; after the last one the read is a harmless repeat of tap (4, 4)
-      const int toffn = dx < 4 ? (dy * 18 + dx + 1) * XP : ((dy < 4 ? dy + 1 : 4) * 18 + (dy < 4 ? 0 : 4)) * XP;
+      const int toffn = dx < 4 ? dy * XROW + (dx + 1) * XP : (dy < 4 ? dy + 1 : 4) * XROW + (dy < 4 ? 0 : 4) * XP;
 #pragma unroll
       for (int mt = 0; mt < FWD_MT; ++mt) afn[mt] = *reinterpret_cast<const float2*>(img + abase[mt] + toffn);
       __builtin_amdgcn_sched_barrier(0);
@@ -251,7 +257,11 @@ struct UnpoolTask32 {
 namespace {
 constexpr int BD_POS = 80, BD_MT = BD_POS / 16;
 constexpr int BD_ROWS = 15;
-constexpr int BD_IMG = BD_ROWS * 18 * DP;        // 18 360 floats
+// Row pitch of the un-pooled dY halo image: the A fragments are ds_read_b64 of 16 consecutive positions (17 four-bank units
+// per pixel: consecutive pixels take consecutive units); a tile that runs over a row end continues 4 halo pixels further,
+// which the row pitch must turn into "the next unit": (pitch / 4) mod 16 = 14 * 17 mod 16 = 14 -> 1272 (18 * 68 = 1224 gives 2).
+constexpr int BD_ROWP = 1272;
+constexpr int BD_IMG = BD_ROWS * BD_ROWP;        // 19 080 floats
 constexpr int BD_RED = 8 * BD_MT * 2 * 256;      // [wave][tile][lane][4]: 20 480 floats
 constexpr int BD_LDS = (BD_IMG > BD_RED ? BD_IMG : BD_RED) * 4;
 }  // namespace
@@ -308,7 +318,7 @@ __device__ __forceinline__ void conv2_bwd_data_f32_body(float* __restrict__ smem
   }
   CSTAMP(5);
   {
-    const int n4 = (nrow0 + nrow1) * (18 * DP / 4);
+    const int n4 = (nrow0 + nrow1) * (BD_ROWP / 4);
     for (int c = tid; c < n4; c += 512) *reinterpret_cast<f32x4*>(dimg + c * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();
@@ -328,7 +338,7 @@ __device__ __forceinline__ void conv2_bwd_data_f32_body(float* __restrict__ smem
           f32x4 o;
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = ((ut[i].av >> (8 * j)) & 0xffu) == (uint32_t)sp ? ut[i].g[j] : 0.f;
-          *reinterpret_cast<f32x4*>(dst + ((rbase + hy) * 18 + 2 * tcol[i] + (sp & 1) + 2) * DP) = o;
+          *reinterpret_cast<f32x4*>(dst + (rbase + hy) * BD_ROWP + (2 * tcol[i] + (sp & 1) + 2) * DP) = o;
         }
       }
     }
@@ -342,7 +352,7 @@ __device__ __forceinline__ void conv2_bwd_data_f32_body(float* __restrict__ smem
     const int slot = p >= (b0 + 1) * 196 ? 1 : 0;
     const int pos = p - (b0 + slot) * 196;
     const int y = pos / 14, xx = pos - y * 14;
-    abase[mt] = (((slot ? nrow0 : -ylo0) + y) * 18 + xx) * DP + k0 + 2 * q;
+    abase[mt] = ((slot ? nrow0 : -ylo0) + y) * BD_ROWP + xx * DP + k0 + 2 * q;
   }
   // ReLU mask of the layer below for the (at most two) tiles this wave finalises, fetched ahead of the k loop
   float pm[2][4];
@@ -383,7 +393,7 @@ __device__ __forceinline__ void conv2_bwd_data_f32_body(float* __restrict__ smem
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int dx = 0; dx < 5; ++dx) {
-      const int toffn = dx < 4 ? (dy * 18 + dx + 1) * DP : ((dy < 4 ? dy + 1 : 4) * 18 + (dy < 4 ? 0 : 4)) * DP;
+      const int toffn = dx < 4 ? dy * BD_ROWP + (dx + 1) * DP : (dy < 4 ? dy + 1 : 4) * BD_ROWP + (dy < 4 ? 0 : 4) * DP;
 #pragma unroll
       for (int mt = 0; mt < BD_MT; ++mt) afn[mt] = *reinterpret_cast<const float2*>(dimg + abase[mt] + toffn);
       __builtin_amdgcn_sched_barrier(0);
@@ -468,8 +478,12 @@ __global__ __launch_bounds__(512) void conv2_bwd_data_f32_kernel(const ConvBwdDa
 // block -> (image quad g, output-channel half c, filter row dy); 512 threads.
 // pool1 fp32 [B,196,32] (the conv input); dW fp32 [25][32][64] accumulated with atomics.
 namespace {
-constexpr int DW_XROWS = 14 * 18 * XP;   // the 14 halo rows a filter row touches: 9072 floats
-constexpr int DW_DY = 196 * XP;          // dY of one channel half, position-major, 36-float pitch: 7056 floats
+// LDS layouts chosen for ds_read_b32, whose banks are (address / 4) mod 32 and whose lanes conflict within 32-lane halves: a
+// half holds two consecutive positions x 16 channels, so the two positions must land on different 16-bank halves.
+constexpr int DW_XP = 48;                 // floats per input halo pixel (32 ch + 16 pad): consecutive pixels alternate halves
+constexpr int DW_XROWS = 14 * 18 * DW_XP; // the 14 halo rows a filter row touches: 12 096 floats
+constexpr int DW_DYP = 32;                // dY of one channel half, position-major, unpadded; the 16-channel half h of
+constexpr int DW_DY = 196 * DW_DYP;       // position p is stored at slot h ^ (p & 1): 6272 floats
 constexpr int DW_RED = 8 * 10 * 256;     // [wave][tile][lane][4]: 20 480 floats
 constexpr int DW_LDS = (DW_XROWS + DW_DY > DW_RED ? DW_XROWS + DW_DY : DW_RED) * 4;
 
@@ -510,12 +524,20 @@ __device__ __forceinline__ void conv2_dw_f32_body(float* __restrict__ smem, cons
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int ch = tid + 512 * i;
-      if (ch < 2016) *reinterpret_cast<f32x4*>(ximg + (ch >> 3) * XP + (ch & 7) * 4) = xv[i];
+      if (ch < 2016) *reinterpret_cast<f32x4*>(ximg + (ch >> 3) * DW_XP + (ch & 7) * 4) = xv[i];
     }
     if (tid < 392) {
       ut.mask();
       const int win = tid >> 3, py = win / 7, px = win - py * 7;
-      ut.store(dyi + (tid & 7) * 4, py, px, 14, XP, 0, 0);
+      const int coff = (tid & 7) * 4;
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {  // sub-position (sy, sx) of the window: position parity = sx
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = ((ut.av >> (8 * j)) & 0xffu) == (uint32_t)sp ? ut.g[j] : 0.f;
+        const int pos = (2 * py + (sp >> 1)) * 14 + 2 * px + (sp & 1);
+        *reinterpret_cast<f32x4*>(dyi + pos * DW_DYP + (coff ^ ((sp & 1) << 4))) = o;
+      }
       if (bias_role) { gsum[0] += ut.g[0]; gsum[1] += ut.g[1]; gsum[2] += ut.g[2]; gsum[3] += ut.g[3]; }
     }
   };
@@ -540,12 +562,12 @@ __device__ __forceinline__ void conv2_dw_f32_body(float* __restrict__ smem, cons
     for (int s = (kq - im) & 3; s < 49; s += 4) {
       const int pos = 4 * s + q;
       const int y = pos / 14, xx = pos - y * 14;
-      const float* xa = ximg + (y * 18 + xx) * XP + mt * 16 + r;  // tap (dy, dx): staged row y, halo column xx + dx
-      const float* da = dyi + pos * XP + r;
-      const float b0f = da[0], b1f = da[16];
+      const float* xa = ximg + (y * 18 + xx) * DW_XP + mt * 16 + r;  // tap (dy, dx): staged row y, halo column xx + dx
+      const float* da = dyi + pos * DW_DYP + r;                      // (position parity = q & 1: pos = 4 s + q)
+      const float b0f = da[(q & 1) << 4], b1f = da[((q & 1) ^ 1) << 4];
       float a[5];
 #pragma unroll
-      for (int dx = 0; dx < 5; ++dx) a[dx] = xa[dx * XP];
+      for (int dx = 0; dx < 5; ++dx) a[dx] = xa[dx * DW_XP];
 #pragma unroll
       for (int dx = 0; dx < 5; ++dx) {
         acc[dx][0] = mfma16f32(a[dx], b0f, acc[dx][0]);
