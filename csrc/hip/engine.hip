@@ -73,6 +73,14 @@ struct MnistEngine {
   int wshard;
 };
 
+// sizeof of the structs that distributed_tensorflow_amd/native.py mirrors with ctypes (checked when the library is loaded:
+// a mirror that is shorter than the struct makes every by-value kernel argument read past the caller's buffer)
+DTF_API void dtf_struct_sizes(int* out) {
+  out[0] = (int)sizeof(HeadParams);
+  out[1] = (int)sizeof(OptimParams);
+  out[2] = (int)sizeof(MnistEngine);
+}
+
 // "shard" schedule: source ranks per K set of the slice GEMM (one set: plain stores; more: atomics into the zeroed slice)
 static constexpr int SHARD_RANKS_PER_SET = 2;
 

@@ -198,6 +198,36 @@ __global__ __launch_bounds__(256) void sample_rows_kernel(const long* __restrict
   rows[i] = (int)(offsets[c] + (long)((r.y & 0x7FFFFFFu) % (unsigned long)cnt));
 }
 
+DTF_API int dtf_sizeof_retrain_head_params() { return (int)sizeof(RetrainHeadParams); }
+
+// The same with the draw counter in device memory (a captured step graph replays unchanged): draw = *counter + 1, and the
+// counter is advanced by a one-thread kernel behind the sampler (every block of the sampler has read it by then).
+__global__ __launch_bounds__(256) void sample_rows_dev_kernel(const long* __restrict__ offsets, const long* __restrict__ counts,
+                                                              int C, int n, unsigned long long seed,
+                                                              const unsigned long long* __restrict__ counter,
+                                                              int* __restrict__ rows) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long draw = *counter + 1ull;
+  const uint4 r = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)draw, (uint32_t)(draw >> 32), 0x72747261u),
+                                make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+  int c = (int)(r.x % (uint32_t)C);
+  for (int tries = 0; tries < C && counts[c] == 0; ++tries) c = (c + 1) % C;
+  const long cnt = counts[c] > 0 ? counts[c] : 1;
+  rows[i] = (int)(offsets[c] + (long)((r.y & 0x7FFFFFFu) % (unsigned long)cnt));
+}
+__global__ void bump_counter_kernel(unsigned long long* counter) { *counter += 1ull; }
+
+DTF_API int dtf_sample_rows_dev(const long* offsets, const long* counts, int C, int n, unsigned long long seed,
+                                unsigned long long* counter, int* rows, hipStream_t st) {
+  if (C <= 0 || n <= 0 || !counter) return ERR_SHAPE;
+  hipLaunchKernelGGL(sample_rows_dev_kernel, dim3(dtf_cdiv(n, 256)), dim3(256), 0, st, offsets, counts, C, n, seed, counter, rows);
+  DTF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(1), 0, st, counter);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
 DTF_API int dtf_sample_rows(const long* offsets, const long* counts, int C, int n, unsigned long long seed,
                             unsigned long long draw, int* rows, hipStream_t st) {
   if (C <= 0 || n <= 0) return ERR_SHAPE;

@@ -62,7 +62,8 @@ class DeviceBatchSampler:
     """``get_random_cached_bottlenecks`` (``retrain1/retrain.py:322-340``: random class, then random image of that class,
     with replacement) over an HBM-resident image split, entirely on the device: ``dtf_sample_rows`` draws the rows
     (counter-based RNG keyed by (seed, draw)), ``dtf_gather_rows`` copies the picked images and labels into the caller's
-    static batch buffers.  No per-step host list, no Python loop, no host->device copy.  CPU: the same draw with torch ops."""
+    static batch buffers.  No per-step host list, no Python loop, no host->device copy; the draw counter itself lives in
+    device memory, so the sampler can be part of a captured step graph.  CPU: the same draw with torch ops."""
 
     def __init__(self, x, y, num_classes: int, seed: int):
         import torch
@@ -78,6 +79,7 @@ class DeviceBatchSampler:
         self.offsets = torch.as_tensor(np.concatenate(([0], np.cumsum(counts)[:-1])).astype(np.int64), device=self.device)
         self.row_bytes = x[0].numel() * x.element_size()
         self._rows = {}
+        self._draw_t = torch.zeros(1, dtype=torch.int64, device=self.device) if self.device.type == "cuda" else None
 
     def sample_into(self, out_x, out_y) -> None:
         import torch
@@ -90,8 +92,8 @@ class DeviceBatchSampler:
                 self._rows[B] = torch.empty(B, dtype=torch.int32, device=self.device)
             rows = self._rows[B]
             st = torch.cuda.current_stream(self.device).cuda_stream
-            native.check(lib.dtf_sample_rows(self.offsets.data_ptr(), self.counts.data_ptr(), self.C, B, self.seed, self.draws,
-                                             rows.data_ptr(), st), "sample_rows")
+            native.check(lib.dtf_sample_rows_dev(self.offsets.data_ptr(), self.counts.data_ptr(), self.C, B, self.seed,
+                                                 self._draw_t.data_ptr(), rows.data_ptr(), st), "sample_rows")
             native.check(lib.dtf_gather_rows(self.x.data_ptr(), rows.data_ptr(), out_x.data_ptr(), self.row_bytes, B,
                                              self.y.data_ptr(), out_y.data_ptr(), st), "gather_rows")
             return
@@ -104,18 +106,67 @@ class DeviceBatchSampler:
         out_y.copy_(self.y.index_select(0, rows))
 
 
+class StepPairGraph:
+    """Two consecutive training steps — batch sampling, forward, loss, backward, gradient exchange, optimizer — as ONE
+    hipGraph replay.  Two, because the step alternates between two sets of batch-norm statistic
+    accumulators and two metric slots (``inception_train.py``): after a pair everything is back where it started, so the
+    captured pair replays unchanged.  One graph per starting parity, captured on first use after the eager warm-up steps
+    (autotuning, lazy allocations).  Capture errors disable the graph for the rest of the run; the step then stays eager.
+
+    ``lock`` is held while a capture is open: the Supervisor's saver thread synchronises the device in ``state_dict()``,
+    which is not allowed while a stream of the process is capturing."""
+
+    def __init__(self, step_fn, parity_fn, device, lock, log=lambda m: None):
+        self.step_fn, self.parity_fn, self.device, self.lock, self.log = step_fn, parity_fn, device, lock, log
+        self.graphs = {}
+        self.enabled = True
+        self.replays = 0
+
+    def run(self) -> bool:
+        """Run two steps through the graph; False (and nothing enqueued) when the graph is not available."""
+        import torch
+        if not self.enabled:
+            return False
+        par = self.parity_fn()
+        g = self.graphs.get(par)
+        if g is None:
+            with self.lock:
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                try:
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self.step_fn()
+                        self.step_fn()
+                except Exception as e:  # noqa: BLE001
+                    self.enabled = False
+                    self.log("step graph: capture failed (%r); the step stays eager" % (e,))
+                    torch.cuda.synchronize(self.device)
+                    return False
+            if self.parity_fn() != par:
+                self.enabled = False
+                self.log("step graph: parity did not return to its start after two steps; the step stays eager")
+                return False
+            self.graphs[par] = g
+        g.replay()
+        self.replays += 1
+        return True
+
+
 class FinetuneEngine:
     """What the Supervisor and its saver see of the fine-tune: a global step and a state to snapshot / restore."""
 
     def __init__(self, trainer):
+        import threading
         self.trainer = trainer
         self.global_step = 0
+        self.capture_lock = threading.RLock()
 
     def state_dict(self):
         import torch
-        if self.trainer.P.is_cuda:
-            torch.cuda.synchronize(self.trainer.P.device)
-        return {k: v.detach().cpu().numpy().copy() for k, v in self.trainer.state_tensors().items()}
+        with self.capture_lock:  # (never while the training thread has a graph capture open)
+            if self.trainer.P.is_cuda:
+                torch.cuda.synchronize(self.trainer.P.device)
+            return {k: v.detach().cpu().numpy().copy() for k, v in self.trainer.state_tensors().items()}
 
     def load_state_dict(self, sd) -> None:
         import torch
@@ -307,12 +358,37 @@ def run(FLAGS, image_lists, image_dir: str, rank: int, world: int, device, seed:
     rc = 0
     start = time.time()
     warm_steps, t_warm = min(5, max(1, (steps - i) // 2)), None
+
+    def one_step():
+        x, y = next_batch()
+        dp.train_step(x, y)
+
+    # pairs of steps as one hipGraph replay wherever the host has nothing to do in between (no logging point, no fault
+    # injection, no agreed stop step inside the pair); everything else, and the warm-up, runs eagerly
+    pair = None
+    if native_ok and sampler is not None and getattr(FLAGS, "finetune_graph", True) and dp.graph_capable():
+        pair = StepPairGraph(one_step, lambda: trainer._fwd_parity, device, engine.capture_lock, log=lambda m: _log(rank, m))
+
+    def pair_ok(at: int) -> bool:
+        if pair is None or not pair.enabled or at - start_step < max(2, warm_steps) or at + 2 > steps - 1:
+            return False
+        if at % FLAGS.eval_step_interval == 0 or (at + 1) % FLAGS.eval_step_interval == 0:
+            return False  # (a logging point reads the metrics of exactly that step)
+        if FLAGS.fault_inject_step in (at, at + 1):
+            return False
+        return sv is None or sv.steps_allowed(at, 2) >= 2
+
     try:
         while i < steps and not (sv is not None and sv.should_stop()):
             if FLAGS.fault_inject_step >= 0 and i == FLAGS.fault_inject_step and rank == world - 1:
                 raise RuntimeError("injected fault at step %d" % i)
-            x, y = next_batch()
-            dp.train_step(x, y)
+            if pair_ok(i) and pair.run():
+                i += 2
+                engine.global_step = i
+                if hasattr(trainer, "_steps_host"):
+                    trainer._steps_host += 2
+                continue
+            one_step()
             i += 1
             engine.global_step = i
             st = i - 1
@@ -372,6 +448,9 @@ def run(FLAGS, image_lists, image_dir: str, rank: int, world: int, device, seed:
                        "logging included; last train loss %.4f)" % (
                 (i - start_step - warm_steps) * B * world / max(t_end - t_warm, 1e-9), i - start_step - warm_steps,
                 warm_steps, dp.mean_metrics()[0]))
+    if pair is not None:
+        _log(rank, "step graph: %d of %d steps ran as two-step hipGraph replays (%d graph%s captured)" % (
+            2 * pair.replays, i - start_step, len(pair.graphs), "" if len(pair.graphs) == 1 else "s"))
     in_sync = dp.replicas_in_sync()
     _log(rank, "replicas in sync: %s" % in_sync)
 

@@ -164,6 +164,9 @@ def build_retrain_parser(distributed: bool) -> argparse.ArgumentParser:
     p.add_argument("--finetune_bn_recalibrate", type=int, default=8,
                    help="re-estimate the batch-norm moving statistics over this many training batches before the export "
                         "(0 = keep the running averages, decay 0.9997: right for long runs only)")
+    p.add_argument("--finetune_graph", type="bool", nargs="?", const=True, default=True,
+                   help="replay pairs of fine-tune steps (sampling, forward, backward, exchange, optimizer) as one hipGraph "
+                        "wherever the host has nothing to do in between")
     p.add_argument("--finetune_grad_dtype", type=str, default="fp32", choices=["fp32", "bf16"],
                    help="wire format of the fine-tune's gradient buckets (bf16: half the xGMI bytes; the optimizer keeps "
                         "fp32 master weights either way)")

@@ -35,6 +35,10 @@ class RetrainHead:
                  seed: Optional[int] = None, final_tensor_name: str = "final_result"):
         self.C = class_count
         self.device = torch.device(device)
+        if self.device.type == "cuda":
+            n = native.hip().dtf_sizeof_retrain_head_params()
+            if n != C.sizeof(RetrainHeadParams):
+                raise native.NativeError("RetrainHeadParams mirror is %d bytes, the library's struct %d" % (C.sizeof(RetrainHeadParams), n))
         self.lr = learning_rate
         self.double_softmax = double_softmax
         self.final_tensor_name = final_tensor_name

@@ -49,6 +49,7 @@ class OptimParams(C.Structure):
         ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("grad_scale", c_float),
         ("step", c_void_p), ("ticket", c_void_p), ("metrics_ring", c_void_p), ("ring", c_int),
         ("Gsrc", c_void_p), ("Gsrcs", c_void_p * 8), ("nsrc", c_int), ("skip", c_void_p),
+        ("Wsh", c_void_p * 16), ("wsh_world", c_int), ("wsh_rank", c_int),  # ("wshard" schedule: set by engine.hip only)
     ]
 
 
@@ -181,13 +182,22 @@ def hip() -> C.CDLL:
         _sig(lib, "dtf_avgpool3x3_same", I, [P, P] + [I] * 6 + [P])
         _sig(lib, "dtf_global_avgpool", I, [P, P, I, I, I, P])
         _sig(lib, "dtf_sample_rows", I, [P, P, I, I, C.c_ulonglong, C.c_ulonglong, P, P])
+        _sig(lib, "dtf_sample_rows_dev", I, [P, P, I, I, C.c_ulonglong, P, P, P])
         _sig(lib, "dtf_gather_rows", I, [P, P, P, C.c_long, I, P, P, P])
+        _sig(lib, "dtf_sizeof_retrain_head_params", I, [])
         _sig(lib, "dtf_retrain_head_fwd", I, [P, P])
         _sig(lib, "dtf_retrain_head_bwd", I, [P, P, P, I, I, P, P, P, P, F, P])
         _sig(lib, "dtf_retrain_head_dx", I, [P, P, P, I, I, P, P])
         for extra in _HIP_EXTRA_SIGS:
             if hasattr(lib, extra[0]):
                 _sig(lib, *extra)
+        # the ctypes mirrors must be exactly as large as the structs the kernels take by value
+        sizes = (C.c_int * 3)()
+        _sig(lib, "dtf_struct_sizes", None, [P])(sizes)
+        for mirror, native_size in zip((HeadParams, OptimParams, MnistEngineStruct), sizes):
+            if C.sizeof(mirror) != native_size:
+                raise NativeError("native.%s is %d bytes, the library's struct %d: the ctypes mirror is out of date" % (
+                    mirror.__name__, C.sizeof(mirror), native_size))
         _hip = lib
         return lib
 

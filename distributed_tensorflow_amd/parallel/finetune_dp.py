@@ -177,6 +177,12 @@ class FinetuneDataParallel:
             w.wait()
         self.last_num_collectives = cursor[0]
 
+    def graph_capable(self) -> bool:
+        """The whole step is kernels and stream-ordered communicator calls (capturable into a hipGraph): the native trainer
+        on one GPU, or with the framework's RCCL communicator.  The process-group path waits for work handles on the host."""
+        tr = self.trainer
+        return bool(tr.P.is_cuda and hasattr(tr, "_fwd_parity") and (not self._multi or self.rccl is not None))
+
     def train_step(self, x: torch.Tensor, labels: torch.Tensor) -> None:
         tr = self.trainer
         if not self._multi:

@@ -363,9 +363,16 @@ for _ in range(6):
     b.train_step(x, y)
     la.append(a.metrics()[0]); lb.append(b.metrics()[0])
 torch.cuda.synchronize()
+# two steps, exchange included, as one hipGraph replay (the communicator's calls on the side stream are captured with them)
+import threading
+from distributed_tensorflow_amd.apps.finetune import StepPairGraph
+pg = StepPairGraph(lambda: dp.train_step(x, y), lambda: a._fwd_parity, torch.device("cuda:0"), threading.RLock(), log=print)
+graph_ok = pg.run() and pg.run()
+torch.cuda.synchronize()
+graph_loss = a.metrics()[0]
 in_step = calls["n"]
 dist.all_reduce = _orig
-print(json.dumps({"la": la, "lb": lb, "buckets": len(dp.buckets.ranges), "ncoll": dp.last_num_collectives,
+print(json.dumps({"graph_ok": bool(graph_ok), "graph_loss": graph_loss, "graph_replays": pg.replays, "la": la, "lb": lb, "buckets": len(dp.buckets.ranges), "ncoll": dp.last_num_collectives,
                   "sync": dp.replicas_in_sync(), "gmax": float(a.G.abs().max()), "steps": int(a.step_t.item()),
                   "transport": dp.transport, "wire": dp.grad_dtype, "pg_collectives_in_steps": in_step, "dev": dev0,
                   "async_error": dp.async_error()}))
@@ -390,7 +397,9 @@ def test_finetune_bucketed_allreduce_over_rccl_single_rank(tmp_path, wire):
                        timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert out["buckets"] >= 3 and out["ncoll"] == out["buckets"] and out["sync"] is True and out["steps"] == 6
+    assert out["buckets"] >= 3 and out["ncoll"] == out["buckets"] and out["sync"] is True
+    # 6 eager steps + 2 graph replays of 2 steps each, the loss still falling
+    assert out["graph_ok"] and out["graph_replays"] == 2 and out["steps"] == 10 and out["graph_loss"] < out["la"][0], out
     assert out["transport"] == "rccl-native" and out["wire"] == wire and out["pg_collectives_in_steps"] == 0, out
     assert out["dev"] < (2e-2 if wire == "bf16" else 1e-5) and out["async_error"] is None, out
     assert out["gmax"] == 0.0
@@ -413,6 +422,9 @@ def test_retrain_cli_finetune_on_gpu(tmp_path):
                        text=True, timeout=500)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "Fine-tune throughput" in r.stdout and "Final test accuracy" in r.stdout and "on the device" in r.stdout
+    import re
+    m = re.search(r"step graph: (\d+) of 40 steps ran as two-step hipGraph replays", r.stdout)
+    assert m and int(m.group(1)) >= 20, r.stdout[-2000:]   # (everything but the warm-up and the logging points)
     accs = [float(l.split("Train accuracy = ")[1].split("%")[0]) for l in r.stdout.splitlines() if "Train accuracy" in l]
     assert accs[-1] >= 90.0, r.stdout[-2000:]  # the synthetic classes are trivially separable
     vacc = [float(l.split("Validation accuracy = ")[1].split("%")[0]) for l in r.stdout.splitlines() if "Validation accuracy" in l]
