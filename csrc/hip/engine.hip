@@ -71,6 +71,11 @@ struct MnistEngine {
   // P[W_fc1], and M / V outside [lo, hi), go stale: dtf_mnist_wshard_store() brings P up to date; the optimizer slices are
   // exchanged by the trainer (parallel/ddp.py: materialize()).
   int wshard;
+  // wshard_rows_a > 0: the first wshard_rows_a of this rank's rows are updated (and stored to every rank) from spare
+  // workgroups of the conv2 DATA-gradient launch, the rest from the filter-gradient launch as above: the stores of 12.8 / N
+  // MB per xGMI link then have two launches (~52 us) to drain instead of one (~29 us), which is what 2 and 4 GPUs need.  On
+  // one GPU, or with 8, it only costs (the data-gradient launch is MFMA-bound on every CU); the start-up trial decides.
+  int wshard_rows_a;
 };
 
 // sizeof of the structs that distributed_tensorflow_amd/native.py mirrors with ctypes (checked when the library is loaded:
@@ -270,15 +275,30 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
         for (int r = 0; r < e->shard_n; ++r) fc1.Wsh[par][r] = wsh[par * 8 + r] + lo;
       fc1.wsh_world = e->shard_n;
       fc1.wsh_rank = e->gather_rank;
-    } else if (shard) {
+    }
+    OptimParams fc1a{};  // "wshard": the share of the rows that rides in the data-gradient launch
+    const int rows_a = wshard ? e->wshard_rows_a : 0;
+    if (rows_a < 0 || rows_a % 4 || (wshard && rows_a >= e->shard_w)) return -22;
+    if (rows_a > 0) {
+      const long na = (long)rows_a * 1024;
+      fc1a = fc1;
+      fc1a.n = na;
+      fc1a.zero_from = fc1.zero_from == 0 ? 0 : na;
+      fc1.G += na; fc1.M += na; fc1.V += na;
+      fc1.n -= na;
+      fc1.zero_from = fc1.zero_from == 0 ? 0 : fc1.n;
+      for (int par = 0; par < 2; ++par)
+        for (int r = 0; r < e->shard_n; ++r) fc1.Wsh[par][r] += na;
+    }
+    if (shard && !wshard) {
       DTF_TRY(dtf_ipc_shard_desc(e->shard_comm, (long)e->shard_lo * 1024, (long)e->shard_w * 1024,
                                  e->G + e->off_Wfc1 + (long)e->shard_lo * 1024, e->shard_n > SHARD_RANKS_PER_SET, &push));
       fc1.Gsrc = dtf_ipc_landing(e->shard_comm);  // the assembled global gradient (the push below zeroes the slice in G)
     }
     if (e->f32)
       DTF_TRY(dtf_conv2_bwd_data_f32_push(e->dpool2, (const float*)e->pool2, e->amax2, e->P + e->off_Wc2,
-                                          (const float*)e->pool1, e->dpool1, B, nullptr, shard && !wshard ? &push : nullptr,
-                                          st));
+                                          (const float*)e->pool1, e->dpool1, B, rows_a > 0 ? &fc1a : nullptr,
+                                          shard && !wshard ? &push : nullptr, st));
     else
       DTF_TRY(dtf_conv2_bwd_data_lds_packed(e->dpool2, e->pool2, e->amax2, e->wc2b, e->pool1, e->dpool1, e->G + e->off_bc2, B,
                                             st));

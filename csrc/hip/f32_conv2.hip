@@ -468,9 +468,12 @@ __global__ __launch_bounds__(512) void conv2_bwd_data_f32_kernel(const ConvBwdDa
   const int id = blockIdx.x;
   if (id < a.nbd)
     conv2_bwd_data_f32_body(smem32, id, a.dpool2, a.pool2, a.amax2, a.W, a.pool1, a.dpool1, a.B);
-  else if (id < a.nbd + a.nadam)
-    adam_tf_body(a.adam, id - a.nbd, a.nadam, 512);
-  else
+  else if (id < a.nbd + a.nadam) {
+    if (a.adam.wsh_world > 0)  // (launch-uniform) "wshard": a share of this rank's rows, stored into every rank's next buffer
+      adam_tf_body<false, true>(a.adam, id - a.nbd, a.nadam, 512);
+    else
+      adam_tf_body(a.adam, id - a.nbd, a.nadam, 512);
+  } else
     shard_push_body(a.push, id - a.nbd - a.nadam, a.npush, 512);
 }
 
@@ -661,6 +664,16 @@ __global__ __launch_bounds__(512) void conv_dw_duo_f32_kernel(const ConvDwDuo32 
   }
 }
 
+// "wshard" fields of a hosted optimizer range: the slice's place in every rank's two parameter buffers
+static bool wsh_fields_ok(const OptimParams* adam) {
+  if (!adam || adam->wsh_world == 0) return true;
+  if (adam->wsh_world < 1 || adam->wsh_world > 8 || adam->wsh_rank < 0 || adam->wsh_rank >= adam->wsh_world) return false;
+  for (int par = 0; par < 2; ++par)
+    for (int r = 0; r < adam->wsh_world; ++r)
+      if (!adam->Wsh[par][r] || (reinterpret_cast<uintptr_t>(adam->Wsh[par][r]) & 15)) return false;
+  return true;
+}
+
 static bool g_f32_attr_set = false;
 DTF_API int dtf_conv2_f32_init() {
   if (g_f32_attr_set) return 0;
@@ -699,6 +712,7 @@ DTF_API int dtf_conv2_bwd_data_f32_push(const float* dpool2, const float* pool2,
                                         const ShardPush* push, hipStream_t st) {
   if (B <= 0) return ERR_SHAPE;
   if (adam && (adam->n <= 0 || adam->n % 4 || adam->zero_from % 4 || !adam->step)) return ERR_SHAPE;
+  if (!wsh_fields_ok(adam)) return ERR_SHAPE;
   if (push && (push->n4 <= 0 || !push->src || push->world < 1 || push->world > 8 || push->rank < 0 || push->rank >= push->world))
     return ERR_SHAPE;
   if (!g_f32_attr_set) {
@@ -740,12 +754,7 @@ DTF_API int dtf_conv_dw_duo_f32(const float* dpool2, const float* pool2, const v
                                 hipStream_t st) {
   if (B <= 0 || (perm && spe <= 0)) return ERR_SHAPE;
   if (adam && (adam->n <= 0 || adam->n % 4 || adam->zero_from % 4 || !adam->step)) return ERR_SHAPE;
-  if (adam && adam->wsh_world != 0) {  // "wshard": the slice's place in every rank's two parameter buffers
-    if (adam->wsh_world < 1 || adam->wsh_world > 8 || adam->wsh_rank < 0 || adam->wsh_rank >= adam->wsh_world) return ERR_SHAPE;
-    for (int par = 0; par < 2; ++par)
-      for (int r = 0; r < adam->wsh_world; ++r)
-        if (!adam->Wsh[par][r] || (reinterpret_cast<uintptr_t>(adam->Wsh[par][r]) & 15)) return ERR_SHAPE;
-  }
+  if (!wsh_fields_ok(adam)) return ERR_SHAPE;
   if (!g_f32_attr_set) {
     const int rc = dtf_conv2_f32_init();
     if (rc) return rc;

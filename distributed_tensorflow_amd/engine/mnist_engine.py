@@ -397,6 +397,7 @@ class NativeMnistEngine(_EngineBase):
         if ipc_act is None or ipc_w is None:
             self.cfg.shard_n = 0
             self.cfg.wshard = 0
+            self.cfg.wshard_rows_a = 0
             self.cfg.shard_comm = None
             self.set_gather(None)
             return
@@ -406,16 +407,20 @@ class NativeMnistEngine(_EngineBase):
         self.cfg.shard_comm = ipc_w.comm_addr
         self.cfg.shard_n, self.cfg.shard_lo, self.cfg.shard_w = ipc_act.world, lo, hi - lo
         self.cfg.wshard = 0
+        self.cfg.wshard_rows_a = 0
         self._drop_graph()
 
-    def set_wshard(self, ipc_act, ipc_w) -> None:
+    def set_wshard(self, ipc_act, ipc_w, split: float = 0.0) -> None:
         """Data-parallel "wshard" schedule (``csrc/hip/engine.hip``, ``MnistEngine::wshard``): as ``set_shard``, but the
         slices that travel are the updated WEIGHTS.  W_fc1 lives in the two buffers of ``ipc_w`` (alternating by step
         parity) instead of in ``P``; this rank applies Adam to its rows only and stores them into every rank's buffer of the
         next parity.  ``P[W_fc1]`` and the optimizer state outside this rank's rows go stale until ``wshard_store()`` / the
-        trainer's ``materialize()``.  The caller loads the buffers (``wshard_load``) before the first step."""
+        trainer's ``materialize()``.  The caller loads the buffers (``wshard_load``) before the first step.
+        ``split``: fraction of this rank's rows whose update (and stores to the peers) rides in the conv2 data-gradient
+        launch instead of the filter-gradient launch, so that the stores have two launches to drain (2 and 4 GPUs)."""
         self.set_shard(ipc_act, ipc_w)
         self.cfg.wshard = 1
+        self.cfg.wshard_rows_a = min(self.cfg.shard_w - 4, max(0, int(self.cfg.shard_w * split) // 4 * 4))
 
     def wshard_load(self) -> None:
         """P[W_fc1] -> both parity buffers of this rank (every replica holds the same P when this is called)."""

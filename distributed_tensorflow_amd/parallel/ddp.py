@@ -244,9 +244,13 @@ class DataParallelTrainer:
         if self._multi and self._native and sync and not self._stage_host and comm in ("auto", "rccl"):
             self._try_rccl()
         if self._multi and self._native and sync and comm in ("auto", "ipc"):
+            t_a = time.perf_counter()
             self._try_ipc(required=(comm == "ipc"))
+            t_b = time.perf_counter()
             if self.comm == "ipc":
                 self._tune_schedule(allow_rccl=(comm == "auto"))
+            self._note("start-up phases: RCCL communicator %.2f s, IPC mapping + self-test + transport timing %.2f s, "
+                       "exchange buffers + schedule trials %.2f s" % (t_a - t_start, t_b - t_a, time.perf_counter() - t_b))
         if self._multi and self._native and sync and self.comm != "ipc" and self.rccl is not None:
             self._ipc_hook, self._fc1_end = None, 0
             self._use_schedule("rccl")
@@ -408,7 +412,8 @@ class DataParallelTrainer:
             """A further IPC exchange buffer (collective set-up: every rank decides it from the same facts)."""
             from .ipc_comm import IpcAllReduce
             c = IpcAllReduce(n_floats, e.device, group=self.group, skip_ptr=skip_ptr)
-            if c.self_test():
+            # (mapping and protocol are what can fail here; the arena-sized reduction was verified on the first buffer)
+            if c.self_test(n=1 << 18, rounds=2):
                 c.set_timeout(op_timeout)
                 return c
             c.close()
@@ -417,20 +422,22 @@ class DataParallelTrainer:
         # "gather": exchange the fc1 filter gradient's OPERANDS (0.8 MB/rank) instead of the gradient (12.8 MB) through a
         # second, small exchange buffer
         gather_ok = zc_ok and hasattr(e, "gather_supported") and e.gather_supported() and \
-            forced in ("auto", "ipc-gather", "ipc-shard", "ipc-wshard")
+            forced in ("auto", "ipc-gather", "ipc-shard", "ipc-wshard", "ipc-wshard2")
         if gather_ok and self.ipc_act is None:
             self.ipc_act = exchange_buffer(sum(e.gather_bytes()) // 4)
             gather_ok = self.ipc_act is not None
         # "shard": the same operand exchange, but every rank computes only its 1/world row slice of the global gradient and
         # pushes it into every rank's landing buffer: per-rank work independent of the world size (csrc/hip/shard_body.h)
         shard_ok = gather_ok and hasattr(e, "shard_supported") and e.shard_supported() and \
-            forced in ("auto", "ipc-shard", "ipc-wshard")
+            forced in ("auto", "ipc-shard", "ipc-wshard", "ipc-wshard2")
         if shard_ok and self.ipc_w is None:
             self.ipc_w = exchange_buffer(e.fc1_grad_numel())
             shard_ok = self.ipc_w is not None
         # "wshard": the slices that travel are updated weights, the optimizer state of W_fc1 is sharded (engine.hip)
         wshard_ok = shard_ok and hasattr(e, "set_wshard") and os.environ.get("DTF_WSHARD", "1") != "0"
-        cands = sel.candidates(wshard_ok=wshard_ok and forced in ("auto", "ipc-wshard"),
+        # ("ipc-wshard2": a share of each rank's rows is updated and sent from the data-gradient launch, the rest from the
+        # filter-gradient launch -- two launches for the stores to drain; which of the two is faster depends on the links)
+        cands = sel.candidates(wshard_ok=wshard_ok and forced in ("auto", "ipc-wshard", "ipc-wshard2"),
                                shard_ok=shard_ok and forced in ("auto", "ipc-shard"),
                                gather_ok=gather_ok and forced in ("auto", "ipc-gather"), zc_ok=zc_ok, shared_gpu=shared,
                                allow_rccl=allow_rccl, host_staged=self._stage_host, forced=forced)
@@ -529,7 +536,7 @@ class DataParallelTrainer:
     def _use_schedule(self, c: str) -> None:
         e, hook, fc1_end = self.engine, self._ipc_hook, self._fc1_end
         self._wsh_leave()  # (collective, like every change of schedule)
-        zc, wsh = c == "ipc-zerocopy", c == "ipc-wshard"
+        zc, wsh = c == "ipc-zerocopy", c in ("ipc-wshard", "ipc-wshard2")
         sh = c == "ipc-shard" or wsh
         ga = c == "ipc-gather" or sh  # (the shard schedules ride on the gather schedule's operand exchange and publish)
         if self.ipc is not None or zc:
@@ -537,7 +544,11 @@ class DataParallelTrainer:
         if hasattr(e, "set_shard"):
             e.set_shard(None)  # (also switches the gather exchange off)
         if sh:
-            (e.set_wshard if wsh else e.set_shard)(self.ipc_act, self.ipc_w)
+            if wsh:
+                e.set_wshard(self.ipc_act, self.ipc_w,
+                             split=float(os.environ.get("DTF_WSHARD_SPLIT", "0.45")) if c == "ipc-wshard2" else 0.0)
+            else:
+                e.set_shard(self.ipc_act, self.ipc_w)
             with torch.cuda.stream(e.stream):
                 e.G[:fc1_end].zero_()  # this rank's slice of the fc1 gradient is accumulated with atomics and re-zeroed by its reader
         elif hasattr(e, "set_gather"):
@@ -568,6 +579,7 @@ class DataParallelTrainer:
         e = self.engine
         e.wshard_load()
         self._wsh = True
+        self._wsh_dirty = False  # (the arenas ARE the state until the next step runs)
         self._wsh_snapshot()
         e.state_provider = self._wsh_state
         e.on_state_loaded = self._wsh_reload
@@ -576,6 +588,7 @@ class DataParallelTrainer:
         """The arenas were rewritten from outside (checkpoint restore, broadcast, trial snapshot): W_fc1's buffers follow."""
         if self._wsh:
             self.engine.wshard_load()
+            self._wsh_dirty = False
             self._wsh_snapshot()
 
     def _wsh_snapshot(self) -> None:
@@ -602,6 +615,10 @@ class DataParallelTrainer:
         path) — and optionally keep it as the checkpoint snapshot.  A no-op for every other schedule."""
         if not self._wsh:
             return
+        if not self._wsh_dirty:  # (no step since the arenas were last made whole: same verdict on every rank)
+            if snapshot:
+                self._wsh_snapshot()
+            return
         e = self.engine
         e.wshard_store()
         n = e.fc1_grad_numel()
@@ -611,6 +628,7 @@ class DataParallelTrainer:
                 lo, hi = e.shard_rows(r, self.world)
                 for t in (e.M, e.V):
                     self._bcast(t[lo * cols:hi * cols], r)
+        self._wsh_dirty = False
         if snapshot:
             self._wsh_snapshot()
 
@@ -888,6 +906,7 @@ class DataParallelTrainer:
             # consistent state that checkpoints are written from
             while n > 0:
                 k = min(n, self._wsh_every - e.global_step % self._wsh_every)
+                self._wsh_dirty = True
                 e.train_steps(k)
                 n -= k
                 if e.global_step % self._wsh_every == 0:

@@ -191,6 +191,7 @@ dist.destroy_process_group()
 @pytest.mark.parametrize("schedule,dtype,nproc", [("ipc-inline", "fp32", 2), ("ipc-zerocopy", "fp32", 2), ("ipc-gather", "fp32", 2),
                                                   ("ipc-shard", "fp32", 2), ("ipc-shard", "fp32", 3),
                                                   ("ipc-wshard", "fp32", 2), ("ipc-wshard", "fp32", 3),
+                                                  ("ipc-wshard2", "fp32", 2), ("ipc-wshard2", "fp32", 3),
                                                   ("ipc-gather", "bf16", 2), ("ipc-inline", "bf16", 2)])
 def test_checked_step_validates_the_production_exchange(tmp_path, schedule, dtype, nproc):
     """``check_exchange`` (the ``--check_replicas`` assertion): the gradient the optimizer consumed under the production
