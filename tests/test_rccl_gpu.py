@@ -192,7 +192,10 @@ dist.destroy_process_group()
                                                   ("ipc-shard", "fp32", 2), ("ipc-shard", "fp32", 3),
                                                   ("ipc-wshard", "fp32", 2), ("ipc-wshard", "fp32", 3),
                                                   ("ipc-wshard2", "fp32", 2), ("ipc-wshard2", "fp32", 3),
-                                                  ("ipc-gather", "bf16", 2), ("ipc-inline", "bf16", 2)])
+                                                  ("ipc-gather", "bf16", 2), ("ipc-inline", "bf16", 2)] +
+                         # (eight ranks on the one GPU -- four K sets in the slice GEMM, 392-row slices: slow, on request)
+                         ([("ipc-wshard", "fp32", 8), ("ipc-wshard2", "fp32", 8), ("ipc-shard", "fp32", 8)]
+                          if os.environ.get("DTF_TEST_DP_WORLD8") == "1" else []))
 def test_checked_step_validates_the_production_exchange(tmp_path, schedule, dtype, nproc):
     """``check_exchange`` (the ``--check_replicas`` assertion): the gradient the optimizer consumed under the production
     schedule equals the host-ordered sum of the ranks' local gradients; the checked step leaves counters, metrics and
