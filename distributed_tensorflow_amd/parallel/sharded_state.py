@@ -1,0 +1,80 @@
+"""State handling of the "ipc-wshard" data-parallel schedules (``csrc/hip/engine.hip``: ``MnistEngine::wshard``), where W_fc1
+lives in IPC buffers and its optimizer state is sharded over the ranks: the live arenas of a rank are then not a whole
+state.  This mixin of ``DataParallelTrainer`` assembles it (``materialize``: collective), keeps the last state every rank
+agreed on for checkpoints (``engine.state_dict()`` is redirected to it) and follows rewrites of the arenas from outside
+(restore, broadcast, trial snapshots).  Reference behaviour being replaced: the variables live whole on the parameter
+server and ``tf.train.Saver`` reads them there (``/root/reference/demo2/train.py:27-29,166-172``)."""
+from __future__ import annotations
+
+import torch
+
+
+class ShardedStateMixin:
+    def _wsh_enter(self) -> None:
+        """The arenas are consistent and identical on every rank here (start-up, or right after a restore)."""
+        e = self.engine
+        e.wshard_load()
+        self._wsh = True
+        self._wsh_dirty = False  # (the arenas ARE the state until the next step runs)
+        self._wsh_snapshot()
+        e.state_provider = self._wsh_state
+        e.on_state_loaded = self._wsh_reload
+
+    def _wsh_reload(self) -> None:
+        """The arenas were rewritten from outside (checkpoint restore, broadcast, trial snapshot): W_fc1's buffers follow."""
+        if self._wsh:
+            self.engine.wshard_load()
+            self._wsh_dirty = False
+            self._wsh_snapshot()
+
+    def _wsh_snapshot(self) -> None:
+        e = self.engine
+        with e._capture_lock:
+            with torch.cuda.stream(e.stream):
+                snap = {"P": e.P.clone(), "M": e.M.clone(), "V": e.V.clone(), "step": e.step_t.clone()}
+            e.stream.synchronize()
+        self._wsh_snap = snap
+
+    def _wsh_state(self):
+        """What ``engine.state_dict()`` returns under this schedule: the last state every rank agreed on (at most
+        ``DTF_WSHARD_SNAPSHOT_STEPS`` steps old), not the live arenas, whose optimizer rows of the other ranks are stale."""
+        return {k: v.clone() for k, v in self._wsh_snap.items()}
+
+    def sync_params(self) -> None:
+        """Make ``engine.P`` current (local, stream-ordered; a no-op for every schedule that keeps it current anyway)."""
+        if self._wsh:
+            self.engine.wshard_store()
+
+    def materialize(self, snapshot: bool = False) -> None:
+        """Collective.  Under "ipc-wshard": bring the live arenas to the consistent state of this step — W_fc1 from its
+        current buffer, every rank's rows of M and V from their owner (process-group broadcasts: this is not on the step's
+        path) — and optionally keep it as the checkpoint snapshot.  A no-op for every other schedule."""
+        if not self._wsh:
+            return
+        if not self._wsh_dirty:  # (no step since the arenas were last made whole: same verdict on every rank)
+            if snapshot:
+                self._wsh_snapshot()
+            return
+        e = self.engine
+        e.wshard_store()
+        n = e.fc1_grad_numel()
+        cols = n // 3136
+        with self._ctx():
+            for r in range(self.world):
+                lo, hi = e.shard_rows(r, self.world)
+                for t in (e.M, e.V):
+                    self._bcast(t[lo * cols:hi * cols], r)
+        self._wsh_dirty = False
+        if snapshot:
+            self._wsh_snapshot()
+
+    def _wsh_leave(self) -> None:
+        if not self._wsh:
+            return
+        self.materialize()
+        e = self.engine
+        e.stream.synchronize()
+        self._wsh = False
+        self._wsh_snap = None
+        e.state_provider = None
+        e.on_state_loaded = None
