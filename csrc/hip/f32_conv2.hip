@@ -481,12 +481,12 @@ __global__ __launch_bounds__(512) void conv2_bwd_data_f32_kernel(const ConvBwdDa
 // block -> (image quad g, output-channel half c, filter row dy); 512 threads.
 // pool1 fp32 [B,196,32] (the conv input); dW fp32 [25][32][64] accumulated with atomics.
 namespace {
-// LDS layouts chosen for ds_read_b32, whose banks are (address / 4) mod 32 and whose lanes conflict within 32-lane halves: a
-// half holds two consecutive positions x 16 channels, so the two positions must land on different 16-bank halves.
-constexpr int DW_XP = 48;                 // floats per input halo pixel (32 ch + 16 pad): consecutive pixels alternate halves
-constexpr int DW_XROWS = 14 * 18 * DW_XP; // the 14 halo rows a filter row touches: 12 096 floats
-constexpr int DW_DYP = 32;                // dY of one channel half, position-major, unpadded; the 16-channel half h of
-constexpr int DW_DY = 196 * DW_DYP;       // position p is stored at slot h ^ (p & 1): 6272 floats
+// (Round 3 measured a conflict-free layout here -- 48-float pixels and parity-swizzled dY halves for ds_read_b32's 32 banks:
+// bank-conflict share 40.7 -> 15.3 %, launch 35.1 -> 36.5 us, step +1.4 us on the same box.  The 36-float pitch stays.)
+constexpr int DW_XP = XP;
+constexpr int DW_XROWS = 14 * 18 * DW_XP; // the 14 halo rows a filter row touches: 9072 floats
+constexpr int DW_DYP = XP;                // dY of one channel half, position-major, 36-float pitch
+constexpr int DW_DY = 196 * DW_DYP;       // 7056 floats
 constexpr int DW_RED = 8 * 10 * 256;     // [wave][tile][lane][4]: 20 480 floats
 constexpr int DW_LDS = (DW_XROWS + DW_DY > DW_RED ? DW_XROWS + DW_DY : DW_RED) * 4;
 
@@ -532,15 +532,7 @@ __device__ __forceinline__ void conv2_dw_f32_body(float* __restrict__ smem, cons
     if (tid < 392) {
       ut.mask();
       const int win = tid >> 3, py = win / 7, px = win - py * 7;
-      const int coff = (tid & 7) * 4;
-#pragma unroll
-      for (int sp = 0; sp < 4; ++sp) {  // sub-position (sy, sx) of the window: position parity = sx
-        f32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = ((ut.av >> (8 * j)) & 0xffu) == (uint32_t)sp ? ut.g[j] : 0.f;
-        const int pos = (2 * py + (sp >> 1)) * 14 + 2 * px + (sp & 1);
-        *reinterpret_cast<f32x4*>(dyi + pos * DW_DYP + (coff ^ ((sp & 1) << 4))) = o;
-      }
+      ut.store(dyi + (tid & 7) * 4, py, px, 14, DW_DYP, 0, 0);
       if (bias_role) { gsum[0] += ut.g[0]; gsum[1] += ut.g[1]; gsum[2] += ut.g[2]; gsum[3] += ut.g[3]; }
     }
   };
@@ -566,8 +558,8 @@ __device__ __forceinline__ void conv2_dw_f32_body(float* __restrict__ smem, cons
       const int pos = 4 * s + q;
       const int y = pos / 14, xx = pos - y * 14;
       const float* xa = ximg + (y * 18 + xx) * DW_XP + mt * 16 + r;  // tap (dy, dx): staged row y, halo column xx + dx
-      const float* da = dyi + pos * DW_DYP + r;                      // (position parity = q & 1: pos = 4 s + q)
-      const float b0f = da[(q & 1) << 4], b1f = da[((q & 1) ^ 1) << 4];
+      const float* da = dyi + pos * DW_DYP + r;
+      const float b0f = da[0], b1f = da[16];
       float a[5];
 #pragma unroll
       for (int dx = 0; dx < 5; ++dx) a[dx] = xa[dx * DW_XP];
