@@ -37,8 +37,16 @@ class ShardedStateMixin:
 
     def _wsh_state(self):
         """What ``engine.state_dict()`` returns under this schedule: the last state every rank agreed on (at most
-        ``DTF_WSHARD_SNAPSHOT_STEPS`` steps old), not the live arenas, whose optimizer rows of the other ranks are stale."""
-        return {k: v.clone() for k, v in self._wsh_snap.items()}
+        ``DTF_WSHARD_SNAPSHOT_STEPS`` steps old), not the live arenas, whose optimizer rows of the other ranks are stale.
+        Called from the Supervisor's saver thread as well: like ``engine.state_dict()`` it works on the engine's stream and
+        never while the training thread has a graph capture open."""
+        e = self.engine
+        with e._capture_lock:
+            snap = self._wsh_snap  # (replaced as a whole by _wsh_snapshot, never modified in place)
+            with torch.cuda.stream(e.stream):
+                out = {k: v.clone() for k, v in snap.items()}
+            e.stream.synchronize()
+        return out
 
     def sync_params(self) -> None:
         """Make ``engine.P`` current (local, stream-ordered; a no-op for every schedule that keeps it current anyway)."""

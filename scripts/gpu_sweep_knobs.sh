@@ -6,11 +6,11 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/sweep
 run() {  # name, env assignments...
   local name=$1; shift
-  env "$@" timeout -k 10 120 python bench.py --steps 3000 --warmup 300 > gpurun_out/sweep/$name.log 2>&1 || { echo "$name FAILED"; tail -5 gpurun_out/sweep/$name.log; return 1; }
+  env "$@" timeout -k 10 120 python bench.py --steps 3000 --warmup 300 --no-extras --extra-dtype none --ref-steps 0 > gpurun_out/sweep/$name.log 2>&1 || { echo "$name FAILED"; tail -5 gpurun_out/sweep/$name.log; return 1; }
   grep "^{" gpurun_out/sweep/$name.log | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
-print('%-44s %.2f us/step  acc %.3f loss %.4f' % ('$name', 1000 * d['ms_per_step'], d['final_test_accuracy'], d['final_train_loss']))"
+print('%-44s %.2f us/step  loss %.4f' % ('$name', 1000 * d['ms_per_step'], d['final_train_loss']))"
 }
 run base DTF_X=0 || exit 1
 for cfg in "$@"; do
