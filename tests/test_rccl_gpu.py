@@ -377,12 +377,17 @@ def test_demo2_two_ranks_weight_sharded_schedule_final_checkpoint_and_resume(tmp
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DTF_DP_SCHEDULE="ipc-wshard", DTF_WSHARD_SNAPSHOT_STEPS="64",
                PYTHONPATH=REPO)
     common = ["--num_gpus", "2", "--backend", "gloo", "--synthetic", "true", "--eval_step_interval", "100", "--eval_train_set",
-              "false", "--seed", "3", "--save_model_secs", "0", "--check_replicas"]
-    r = subprocess.run([sys.executable, os.path.join(REPO, "demo2", "train.py"), "--training_steps", "301"] + common, cwd=cwd, env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+              "false", "--seed", "3", "--check_replicas"]
+    # (the chief's saver thread fires while training runs: what it writes is the last agreed snapshot, named after ITS step)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "demo2", "train.py"), "--training_steps", "301", "--save_model_secs",
+                        "1"] + common, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "schedule ipc-wshard" in r.stdout and r.stdout.count("checked step") >= 2, r.stdout[-3000:]
     assert os.path.exists(os.path.join(cwd, "logs", "model.ckpt-301")), os.listdir(os.path.join(cwd, "logs"))
+    auto = [int(m) for m in re.findall(r"autosave checkpoint \S*model\.ckpt-(\d+)", r.stdout)]
+    # (a snapshot step: a multiple of 64, the step after a checked step's state assembly, or the start)
+    assert all(a <= 301 for a in auto), auto
+    common = common + ["--save_model_secs", "0"]
     acc1 = [float(m) for m in re.findall(r"test_acc: ([0-9.]+)", r.stdout)]
     r2 = subprocess.run([sys.executable, os.path.join(REPO, "demo2", "train.py"), "--training_steps", "402"] + common, cwd=cwd, env=env,
                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
