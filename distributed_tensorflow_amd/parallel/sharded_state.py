@@ -6,10 +6,22 @@ agreed on for checkpoints (``engine.state_dict()`` is redirected to it) and foll
 server and ``tf.train.Saver`` reads them there (``/root/reference/demo2/train.py:27-29,166-172``)."""
 from __future__ import annotations
 
+import contextlib
+
 import torch
 
 
 class ShardedStateMixin:
+    def _wsh_on_stream(self):
+        """Context in which the engine's tensors are read: its stream, under its capture lock (a CPU stand-in has neither)."""
+        e = self.engine
+        stack = contextlib.ExitStack()
+        stack.enter_context(getattr(e, "_capture_lock", contextlib.nullcontext()))
+        if hasattr(e, "stream"):
+            stack.enter_context(torch.cuda.stream(e.stream))
+            stack.callback(e.stream.synchronize)  # (runs first on exit: the copies have landed before the lock is released)
+        return stack
+
     def _wsh_enter(self) -> None:
         """The arenas are consistent and identical on every rank here (start-up, or right after a restore)."""
         e = self.engine
@@ -29,10 +41,8 @@ class ShardedStateMixin:
 
     def _wsh_snapshot(self) -> None:
         e = self.engine
-        with e._capture_lock:
-            with torch.cuda.stream(e.stream):
-                snap = {"P": e.P.clone(), "M": e.M.clone(), "V": e.V.clone(), "step": e.step_t.clone()}
-            e.stream.synchronize()
+        with self._wsh_on_stream():
+            snap = {"P": e.P.clone(), "M": e.M.clone(), "V": e.V.clone(), "step": e.step_t.clone()}
         self._wsh_snap = snap
 
     def _wsh_state(self):
@@ -40,12 +50,9 @@ class ShardedStateMixin:
         ``DTF_WSHARD_SNAPSHOT_STEPS`` steps old), not the live arenas, whose optimizer rows of the other ranks are stale.
         Called from the Supervisor's saver thread as well: like ``engine.state_dict()`` it works on the engine's stream and
         never while the training thread has a graph capture open."""
-        e = self.engine
-        with e._capture_lock:
+        with self._wsh_on_stream():
             snap = self._wsh_snap  # (replaced as a whole by _wsh_snapshot, never modified in place)
-            with torch.cuda.stream(e.stream):
-                out = {k: v.clone() for k, v in snap.items()}
-            e.stream.synchronize()
+            out = {k: v.clone() for k, v in snap.items()}
         return out
 
     def sync_params(self) -> None:
@@ -65,8 +72,7 @@ class ShardedStateMixin:
             return
         e = self.engine
         e.wshard_store()
-        n = e.fc1_grad_numel()
-        cols = n // 3136
+        cols = e.fc1_grad_numel() // e.shard_rows(self.world - 1, self.world)[1]  # (the last rank's slice ends at the last row)
         with self._ctx():
             for r in range(self.world):
                 lo, hi = e.shard_rows(r, self.world)
@@ -81,7 +87,8 @@ class ShardedStateMixin:
             return
         self.materialize()
         e = self.engine
-        e.stream.synchronize()
+        if hasattr(e, "stream"):
+            e.stream.synchronize()
         self._wsh = False
         self._wsh_snap = None
         e.state_provider = None
