@@ -93,6 +93,12 @@ DTF_API int dtf_fc_bwd_trio_f32_shard(const float* X1, const float* dY1, int ldy
 DTF_API int dtf_fc_fwd_f32_sel(const float* X, const float* W0, const float* W1, const int* sel, float* out, int M, int N,
                                int K, int splits, hipStream_t st);
 DTF_API int dtf_ipc_wshard_bufs(const void* comm, long lo_floats, long n_floats, float** out);
+// ---- "early push" operand exchange (ipc-gather2)
+DTF_API int dtf_ipc_sync_gather_pushed(const void* comm, void* dst, long bytes, int rows, int pitch4, long tail_off4,
+                                       long tail_n4, int blocks_per_peer, hipStream_t st);
+DTF_API int dtf_ipc_push_desc(const void* comm, float* src, long n_floats, struct ShardPush* push);
+DTF_API int dtf_fc_fwd_f32_push(const float* X, const float* W, float* out, int M, int N, int K, int splits,
+                                const struct ShardPush* push, hipStream_t st);
 DTF_API int dtf_ipc_sync_gather_slice(const void* comm, void* dst, long bytes, int rows, int pitch4, int lo4, int w4,
                                       long tail_off4, long tail_n4, int blocks_per_peer, hipStream_t st);
 DTF_API int dtf_ipc_shard_desc(const void* comm, long lo_floats, long n_floats, float* src, int zero_src,

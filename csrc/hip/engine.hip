@@ -76,6 +76,10 @@ struct MnistEngine {
   // MB per xGMI link then have two launches (~52 us) to drain instead of one (~29 us), which is what 2 and 4 GPUs need.  On
   // one GPU, or with 8, it only costs (the data-gradient launch is MFMA-bound on every CU); the start-up trial decides.
   int wshard_rows_a;
+  // "ipc-gather2" (early_push != 0, plain gather schedule only, fp32): this rank's pool2 is stored into every peer's landing
+  // block from spare workgroups of the fc1 forward launch, so it travels while the fc1 forward and the loss head run; the
+  // exchange after the head then moves dh only (ipc_allreduce.hip: dtf_ipc_sync_gather_pushed).
+  int early_push;
 };
 
 // sizeof of the structs that distributed_tensorflow_amd/native.py mirrors with ctypes (checked when the library is loaded:
@@ -96,7 +100,7 @@ static constexpr int SHARD_RANKS_PER_SET = 2;
   } while (0)
 
 static int forward_to_slabs(const MnistEngine* e, const float* images, const int* perm, const int* step, int n,
-                            int splits, bool need_argmax, hipStream_t st) {
+                            int splits, bool need_argmax, hipStream_t st, const ShardPush* push = nullptr) {
   if (e->f32) {
     DTF_TRY(dtf_conv1_fwd_f32(images, perm, step, e->spe, n, e->P + e->off_Wc1, e->P + e->off_bc1, (float*)e->pool1,
                               need_argmax ? e->amax1 : nullptr, st));
@@ -109,6 +113,8 @@ static int forward_to_slabs(const MnistEngine* e, const float* images, const int
       return dtf_fc_fwd_f32_sel((const float*)e->pool2, w[e->gather_rank], w[8 + e->gather_rank], e->step, e->slabs, n, 1024,
                                 3136, splits, st);
     }
+    if (push)
+      return dtf_fc_fwd_f32_push((const float*)e->pool2, e->P + e->off_Wfc1, e->slabs, n, 1024, 3136, splits, push, st);
     return dtf_fc_fwd_f32((const float*)e->pool2, e->P + e->off_Wfc1, e->slabs, n, 1024, 3136, splits, nullptr, 0, st);
   }
   if (!e->wc2f || !e->wc2b) return -22;
@@ -166,8 +172,13 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
     return -22;
   if (e->G_fc1_dst && e->off_Wfc1 != 0) return -22;
   float* const dW_fc1 = e->G_fc1_dst ? e->G_fc1_dst : e->G + e->off_Wfc1;
+  const bool early_push = loc.early_push != 0 && loc.gather_n > 0;
+  if (early_push && (shard || !loc.f32)) return -22;
   if (parts & 1) {
-    DTF_TRY(forward_to_slabs(e, e->images, e->perm, e->step, B, e->fc1_splits, true, st));
+    ShardPush opush{};
+    if (early_push)  // (pool2 of this step is written into this rank's stage buffer by the conv2 forward just before)
+      DTF_TRY(dtf_ipc_push_desc(e->gather_comm, (float*)e->pool2, (long)B * 3136, &opush));
+    DTF_TRY(forward_to_slabs(e, e->images, e->perm, e->step, B, e->fc1_splits, true, st, early_push ? &opush : nullptr));
     HeadParams hp{};
     hp.slabs = e->slabs;
     hp.nslab = effective_splits(3136, e->fc1_splits, e->f32 ? 32 : 64);
@@ -206,6 +217,9 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
       if (shard)  // only the columns of pool2 this rank's gradient slice needs, and dh
         DTF_TRY(dtf_ipc_sync_gather_slice(e->gather_comm, e->gather_local, e->gather_bytes, B, 3136 / 4, e->shard_lo / 4,
                                           e->shard_w / 4, (long)B * 784, (long)B * 256, 16, st));
+      else if (early_push)
+        DTF_TRY(dtf_ipc_sync_gather_pushed(e->gather_comm, e->gather_local, e->gather_bytes, B, 3136 / 4, (long)B * 784,
+                                           (long)B * 256, 16, st));
       else
         DTF_TRY(dtf_ipc_sync_gather(e->gather_comm, e->gather_local, e->gather_bytes, 16, st));
     }

@@ -2,6 +2,7 @@
 // (demo1/train.py:94-120: tf.matmul on float32).  Same roles and the same horizontal fusion as the bf16 launchers in
 // gemm_api.hip; operands and results are fp32 everywhere.
 #include "f32_gemm.h"
+#include "shard_body.h"
 
 namespace {
 constexpr int ERR_SHAPE = -22;
@@ -80,6 +81,39 @@ DTF_API int dtf_fc_fwd_f32_sel(const float* X, const float* W0, const float* W1,
   p.bsel = sel;
   p.B_alt = W1;
   return dtf_launch_gemm32_bsel<112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store, 2, 2>(p, eff_splits32(p), st);
+}
+
+// The fc1 forward with a copy role riding in spare workgroups ("ipc-gather2", ipc_allreduce.hip: dtf_ipc_push_desc): X (this
+// rank's pool2, complete since the previous launch) is stored into every rank's landing block while the GEMM runs, so the
+// operand exchange that follows the loss head only has dh left to move.  z planes [splits, splits + PUSH_PLANES) push.
+namespace {
+constexpr int PUSH_PLANES = 2;
+template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int PF, int KW>
+__global__ __launch_bounds__(64 * WM * WN * KW) void dtf_gemm32_push_kernel(const GemmParams p, const int splits, const ShardPush push) {
+  __shared__ __attribute__((aligned(16))) float smem[dtf_gemm32_lds<BM, BN, AL, BL>()];
+  if ((int)blockIdx.z >= splits) {  // (workgroup-uniform)
+    const int per = gridDim.x * gridDim.y;
+    shard_push_body(push, ((int)blockIdx.z - splits) * per + blockIdx.y * gridDim.x + blockIdx.x, PUSH_PLANES * per,
+                    64 * WM * WN * KW);
+    return;
+  }
+  dtf_gemm32_body<BM, BN, BK, WM, WN, AL, BL, EP, PF, KW>(p, blockIdx.x * BM, blockIdx.y * BN, blockIdx.z, smem);
+}
+}  // namespace
+
+DTF_API int dtf_fc_fwd_f32_push(const float* X, const float* W, float* out, int M, int N, int K, int splits,
+                                const ShardPush* push, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 4 || N % 4 || splits < 1 || !aligned16(X) || !aligned16(W)) return ERR_SHAPE;
+  if (!push || push->n4 <= 0 || !push->src || push->world < 1 || push->world > 8 || push->rank < 0 || push->rank >= push->world)
+    return ERR_SHAPE;
+  for (int r = 0; r < push->world; ++r)
+    if (!push->dst[r] || !aligned16(push->dst[r])) return ERR_SHAPE;
+  GemmParams p = base_params32(X, W, out, M, N, K, K, N, N, splits, 32);
+  const int s = eff_splits32(p);
+  dim3 grid(dtf_cdiv(p.M, 112), dtf_cdiv(p.N, 64), s + PUSH_PLANES);
+  hipLaunchKernelGGL((dtf_gemm32_push_kernel<112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store, 2, 2>), grid, dim3(512), 0, st, p, s, *push);
+  DTF_CHECK_LAUNCH();
+  return 0;
 }
 
 #ifdef DTF_GEMM32_STAMPS

@@ -269,7 +269,10 @@ __global__ __launch_bounds__(256) void ipc_gather_copy_kernel(const IpcComm c, f
 // SLICE ("shard" schedule, shard_body.h): of a peer's stage buffer only `rows` row pieces of w4 float4 (at lo4 inside
 // rows of pitch4 float4: the columns of pool2 this rank's gradient slice needs) and a contiguous tail (dh) are pulled, to the
 // same offsets of the local copy; n4 is unused.
-struct GatherSlice { int rows, pitch4, lo4, w4; long tail_off4, tail_n4; };
+// land_stride4 > 0 ("early push", dtf_ipc_push_desc): the row pieces are NOT pulled from the peer: the peer has pushed its rows
+// into this rank's own result buffer (block p of land_stride4 float4, same row layout) during an earlier launch; they are
+// copied from there (local traffic) and only the tail crosses the link here.
+struct GatherSlice { int rows, pitch4, lo4, w4; long tail_off4, tail_n4; long land_stride4; };
 template <bool SLICE>
 __global__ __launch_bounds__(256) void ipc_sync_gather_kernel(const IpcComm c, f32x4* __restrict__ dst, long n4,
                                                              int blocks_per_peer, const GatherSlice gs) {
@@ -286,6 +289,9 @@ __global__ __launch_bounds__(256) void ipc_sync_gather_kernel(const IpcComm c, f
     }
     __syncthreads();
     const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(stage_of(c.base[p]));
+    const f32x4* __restrict__ land = SLICE && gs.land_stride4 > 0
+        ? reinterpret_cast<const f32x4*>(result_of(c.base[c.rank], c.n_max)) + (long)p * gs.land_stride4 : nullptr;
+    const long body_units = SLICE ? (long)gs.rows * gs.w4 : 0;
     const long total = SLICE ? (long)gs.rows * gs.w4 + gs.tail_n4 : n4;
     f32x4* __restrict__ d = dst + (long)p * (SLICE ? gs.tail_off4 + gs.tail_n4 : n4);
     // unit i of the pull -> float4 offset inside the (identically laid out) source and destination buffers
@@ -299,7 +305,8 @@ __global__ __launch_bounds__(256) void ipc_sync_gather_kernel(const IpcComm c, f
 #pragma unroll
       for (int u = 0; u < COPY_U; ++u) {
         const long i = base + u * 256;
-        v[u] = src[at(i < total ? i : base)];
+        const long j = i < total ? i : base;
+        v[u] = (land && j < body_units) ? land[at(j)] : src[at(j)];
       }
 #pragma unroll
       for (int u = 0; u < COPY_U; ++u) {
@@ -490,10 +497,51 @@ DTF_API int dtf_ipc_sync_gather_slice(const void* comm, void* dst, long bytes, i
   if (blocks_per_peer < 1) blocks_per_peer = 16;
   if (blocks_per_peer > 64) blocks_per_peer = 64;
   const int grid = c.world > 1 ? (c.world - 1) * blocks_per_peer : 1;
-  const GatherSlice gs{rows, pitch4, lo4, w4, tail_off4, tail_n4};
+  const GatherSlice gs{rows, pitch4, lo4, w4, tail_off4, tail_n4, 0L};
   hipLaunchKernelGGL(ipc_sync_gather_kernel<true>, dim3(grid), dim3(256), 0, st, c, reinterpret_cast<f32x4*>(dst), 0L,
                      blocks_per_peer, gs);
   DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// "Early push" form of the operand exchange ("ipc-gather2"): every rank has already stored its [rows][pitch4] block (pool2)
+// into block `rank` of every peer's RESULT buffer (dtf_ipc_push_desc + shard_push_body, from spare workgroups of the fc1
+// forward launch, i.e. while the fc1 forward and the loss head ran).  Here: barrier, pull only the tail (dh) from the peers'
+// stage buffers, and copy the pushed rows from this rank's own result buffer into dst[p] (same layout as the stage buffer).
+DTF_API int dtf_ipc_sync_gather_pushed(const void* comm, void* dst, long bytes, int rows, int pitch4, long tail_off4,
+                                       long tail_n4, int blocks_per_peer, hipStream_t st) {
+  const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
+  if (!dst || bytes <= 0 || bytes % 16 || bytes / 4 > c.n_max || c.world < 1 || c.world > MAX_RANKS || c.rank < 0 ||
+      c.rank >= c.world || c.error != c.epoch + 1)
+    return -22;
+  const long land4 = (long)rows * pitch4;
+  if (rows <= 0 || pitch4 <= 0 || tail_n4 < 0 || tail_off4 < land4 || (tail_off4 + tail_n4) * 16 != bytes ||
+      (long)c.world * land4 * 4 > c.n_max)
+    return -22;
+  if (blocks_per_peer < 1) blocks_per_peer = 16;
+  if (blocks_per_peer > 64) blocks_per_peer = 64;
+  const int grid = c.world > 1 ? (c.world - 1) * blocks_per_peer : 1;
+  const GatherSlice gs{rows, pitch4, 0, pitch4, tail_off4, tail_n4, land4};
+  hipLaunchKernelGGL(ipc_sync_gather_kernel<true>, dim3(grid), dim3(256), 0, st, c, reinterpret_cast<f32x4*>(dst), 0L,
+                     blocks_per_peer, gs);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// Descriptor of that push: `src` (n_floats, this rank's pool2 in its own stage buffer) goes to block `rank` of every rank's
+// result buffer.
+DTF_API int dtf_ipc_push_desc(const void* comm, float* src, long n_floats, ShardPush* push) {
+  const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
+  if (c.world < 1 || c.world > MAX_RANKS || c.rank < 0 || c.rank >= c.world || !push || !src) return -22;
+  if (n_floats <= 0 || n_floats % 4 || (long)c.world * n_floats > c.n_max) return -22;
+  *push = ShardPush{};
+  push->src = src;
+  push->n4 = n_floats / 4;
+  for (int p = 0; p < c.world; ++p)
+    push->dst[p] = reinterpret_cast<float*>(c.base[p] + HDR_BYTES) + c.n_max + (long)c.rank * n_floats;
+  push->world = c.world;
+  push->rank = c.rank;
+  push->zero_src = 0;
   return 0;
 }
 

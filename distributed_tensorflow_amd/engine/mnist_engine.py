@@ -349,11 +349,12 @@ class NativeMnistEngine(_EngineBase):
         es = 4 if self.dtype == "fp32" else 2
         return self.batch_size * 3136 * es, self.batch_size * 1024 * es
 
-    def set_gather(self, ipc=None) -> None:
+    def set_gather(self, ipc=None, early_push: bool = False) -> None:
         """Data-parallel "gather" schedule: a training step keeps its pool2 / dh in this rank's stage buffer of ``ipc``
         (an IpcAllReduce whose stage buffers are at least gather_bytes() large), ranks meet after the loss head, and the
         fc1 filter gradient is computed over ALL ranks' operands, read in place from the peers' buffers; ``None``
         switches it off.  Drops the captured graphs."""
+        self.cfg.early_push = 0
         if ipc is None:
             self.cfg.gather_n = 0
             self.cfg.gather_comm = None
@@ -374,6 +375,11 @@ class NativeMnistEngine(_EngineBase):
             self.cfg.gather_comm = ipc.comm_addr
             self.cfg.gather_n = ipc.world
             self.cfg.gather_rank = ipc.rank
+            if early_push:
+                # "ipc-gather2": every rank stores its pool2 into block `rank` of every peer's result buffer during the fc1
+                # forward launch; the exchange after the loss head then only moves dh (csrc/hip/engine.hip: early_push)
+                assert self.dtype == "fp32" and ipc.n_max >= ipc.world * (b0 // 4), "exchange buffer too small for the early push"
+                self.cfg.early_push = 1
         self._drop_graph()
 
     @staticmethod

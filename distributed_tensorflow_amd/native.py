@@ -74,7 +74,7 @@ class MnistEngineStruct(C.Structure):  # csrc/hip/engine.hip: struct MnistEngine
         ("gather_local", c_void_p), ("gather_bytes", c_long),
         ("f32", c_int), ("skip", c_void_p),
         ("shard_comm", c_void_p), ("shard_n", c_int), ("shard_lo", c_int), ("shard_w", c_int),
-        ("wshard", c_int), ("wshard_rows_a", c_int),
+        ("wshard", c_int), ("wshard_rows_a", c_int), ("early_push", c_int),
     ]
 
 

@@ -168,10 +168,18 @@ class StartupMixin:
         # "gather": exchange the fc1 filter gradient's OPERANDS (0.8 MB/rank) instead of the gradient (12.8 MB) through a
         # second, small exchange buffer
         gather_ok = zc_ok and hasattr(e, "gather_supported") and e.gather_supported() and \
-            forced in ("auto", "ipc-gather", "ipc-shard", "ipc-wshard", "ipc-wshard2")
+            forced in ("auto", "ipc-gather", "ipc-gather2", "ipc-shard", "ipc-wshard", "ipc-wshard2")
+        # "ipc-gather2" (fp32 engine): pool2 is PUSHED to the peers during the fc1 forward launch, only dh is exchanged after
+        # the loss head; the exchange buffer then also holds one landing block per rank
+        gather2_ok = gather_ok and getattr(e, "dtype", "") == "fp32" and os.environ.get("DTF_EARLY_PUSH", "1") != "0" and \
+            forced in ("auto", "ipc-gather2")
         if gather_ok and self.ipc_act is None:
-            self.ipc_act = exchange_buffer(sum(e.gather_bytes()) // 4)
+            n_act = sum(e.gather_bytes()) // 4
+            if gather2_ok:
+                n_act = max(n_act, self.world * (e.gather_bytes()[0] // 4))
+            self.ipc_act = exchange_buffer(n_act)
             gather_ok = self.ipc_act is not None
+        gather2_ok = gather2_ok and gather_ok
         # "shard": the same operand exchange, but every rank computes only its 1/world row slice of the global gradient and
         # pushes it into every rank's landing buffer: per-rank work independent of the world size (csrc/hip/shard_body.h)
         shard_ok = gather_ok and hasattr(e, "shard_supported") and e.shard_supported() and \
@@ -185,7 +193,8 @@ class StartupMixin:
         # filter-gradient launch -- two launches for the stores to drain; which of the two is faster depends on the links)
         cands = sel.candidates(wshard_ok=wshard_ok and forced in ("auto", "ipc-wshard", "ipc-wshard2"),
                                shard_ok=shard_ok and forced in ("auto", "ipc-shard"),
-                               gather_ok=gather_ok and forced in ("auto", "ipc-gather"), zc_ok=zc_ok, shared_gpu=shared,
+                               gather_ok=gather_ok and forced in ("auto", "ipc-gather"), gather2_ok=gather2_ok,
+                               zc_ok=zc_ok, shared_gpu=shared,
                                allow_rccl=allow_rccl, host_staged=self._stage_host, forced=forced)
         self._ipc_hook, self._fc1_end = e.grad_hook, fc1_end
         use = self._use_schedule
@@ -284,7 +293,7 @@ class StartupMixin:
         self._wsh_leave()  # (collective, like every change of schedule)
         zc, wsh = c == "ipc-zerocopy", c in ("ipc-wshard", "ipc-wshard2")
         sh = c == "ipc-shard" or wsh
-        ga = c == "ipc-gather" or sh  # (the shard schedules ride on the gather schedule's operand exchange and publish)
+        ga = c in ("ipc-gather", "ipc-gather2") or sh  # (the shard schedules ride on the gather schedule's exchange and publish)
         if self.ipc is not None or zc:
             e.set_grad_redirect(self.ipc.stage_ptr if zc else 0, self.ipc.result_ptr if zc else 0)
         if hasattr(e, "set_shard"):
@@ -298,7 +307,10 @@ class StartupMixin:
             with torch.cuda.stream(e.stream):
                 e.G[:fc1_end].zero_()  # this rank's slice of the fc1 gradient is accumulated with atomics and re-zeroed by its reader
         elif hasattr(e, "set_gather"):
-            e.set_gather(self.ipc_act if ga else None)
+            if c == "ipc-gather2":
+                e.set_gather(self.ipc_act, early_push=True)
+            else:
+                e.set_gather(self.ipc_act if ga else None)
         self._rccl_graph = False
         if c == "rccl":
             if self.rccl is not None:  # native communicator: the collectives are part of the step graph

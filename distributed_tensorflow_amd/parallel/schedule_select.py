@@ -23,14 +23,15 @@ REFERENCE = "ipc-inline"   # the staged in-stream all-reduce: what the start-up 
 TOLERANCE = 0.02           # relative deviation of a schedule's reduced gradient from the reference schedule's
 
 # order of preference when nothing is timed
-ORDER = ("ipc-wshard", "ipc-wshard2", "ipc-shard", "ipc-gather", "ipc-zerocopy", "ipc-overlap", "ipc-inline", "rccl")
+ORDER = ("ipc-wshard", "ipc-wshard2", "ipc-shard", "ipc-gather2", "ipc-gather", "ipc-zerocopy", "ipc-overlap", "ipc-inline", "rccl")
 
 
 def candidates(*, shard_ok: bool, gather_ok: bool, zc_ok: bool, shared_gpu: bool, allow_rccl: bool, host_staged: bool,
-               forced: str = "auto", wshard_ok: bool = False) -> List[str]:
+               forced: str = "auto", wshard_ok: bool = False, gather2_ok: bool = False) -> List[str]:
     """Schedules worth trying here, in order of preference.  ``forced`` (``DTF_DP_SCHEDULE``) narrows the list to one
     (``ValueError`` if that one is not available)."""
-    cands = (["ipc-wshard", "ipc-wshard2"] if wshard_ok else []) + (["ipc-shard"] if shard_ok else []) + (["ipc-gather"] if gather_ok else []) + \
+    cands = (["ipc-wshard", "ipc-wshard2"] if wshard_ok else []) + (["ipc-shard"] if shard_ok else []) + \
+            (["ipc-gather2"] if gather2_ok else []) + (["ipc-gather"] if gather_ok else []) + \
             (["ipc-zerocopy"] if zc_ok else []) + ([] if shared_gpu else ["ipc-overlap"]) + [REFERENCE] + \
             (["rccl"] if allow_rccl and not host_staged and not shared_gpu else [])
     if forced != "auto":

@@ -189,6 +189,7 @@ dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("schedule,dtype,nproc", [("ipc-inline", "fp32", 2), ("ipc-zerocopy", "fp32", 2), ("ipc-gather", "fp32", 2),
+                                                  ("ipc-gather2", "fp32", 2), ("ipc-gather2", "fp32", 3),
                                                   ("ipc-shard", "fp32", 2), ("ipc-shard", "fp32", 3),
                                                   ("ipc-wshard", "fp32", 2), ("ipc-wshard", "fp32", 3),
                                                   ("ipc-wshard2", "fp32", 2), ("ipc-wshard2", "fp32", 3),

@@ -69,6 +69,7 @@ def test_candidates_by_machine():
     assert sel.candidates(**dict(ALL, wshard_ok=True))[:3] == ["ipc-wshard", "ipc-wshard2", "ipc-shard"]
     assert sel.candidates(**dict(ALL, wshard_ok=True, forced="ipc-wshard")) == ["ipc-wshard"]
     assert sel.candidates(**dict(ALL, wshard_ok=True, forced="ipc-wshard2")) == ["ipc-wshard2"]
+    assert sel.candidates(**dict(ALL, gather2_ok=True))[:3] == ["ipc-shard", "ipc-gather2", "ipc-gather"]
     assert sel.candidates(**dict(ALL, shared_gpu=True)) == ["ipc-shard", "ipc-gather", "ipc-zerocopy", "ipc-inline"]
     assert sel.candidates(**dict(ALL, shard_ok=False, gather_ok=False, host_staged=True)) == ["ipc-zerocopy", "ipc-overlap", "ipc-inline"]
     assert sel.candidates(**dict(ALL, forced="ipc-gather")) == ["ipc-gather"]
