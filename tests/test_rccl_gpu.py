@@ -255,6 +255,10 @@ if len(sys.argv) > 3 and sys.argv[3] == "resume":
     eng.load_state_dict(sd)
     tr.train_steps(37 - out["ckpt_step"])
     out["resumed"] = live("resumed")
+    # once more from the same snapshot: what two runs of the SAME five steps differ by (atomics reorder, ReLU / argmax flips)
+    eng.load_state_dict(sd)
+    tr.train_steps(37 - out["ckpt_step"])
+    live("resumed2")
 json.dump(out, open(os.path.join(sys.argv[2], "%s_r%d.json" % (sched, rank)), "w"))
 dist.barrier()
 tr.close()
@@ -266,9 +270,8 @@ dist.destroy_process_group()
 def test_weight_sharded_schedule_keeps_the_same_state_as_the_gradient_sharded_one(tmp_path, nproc):
     """"ipc-wshard" (updated weight rows travel, W_fc1's optimizer state is sharded) against "ipc-shard" (gradient rows
     travel, every rank updates everything): the same row gradients go through the same Adam arithmetic, so after
-    ``materialize()`` P, M and V agree between the two schedules up to the run-to-run noise of the conv filter gradients'
-    fp32 atomics (1e-7 per step; a weight buffer that is one step stale would show as 1e-2), and bit for bit across the
-    ranks of a run.  A checkpoint taken between two snapshot steps holds the state of the last one (consistent, a few steps
+    ``materialize()`` P, M and V agree between the two schedules up to the run-to-run noise of the step (the conv filter
+    gradients' fp32 atomics, see the thresholds below), and bit for bit across the ranks of a run.  A checkpoint taken between two snapshot steps holds the state of the last one (consistent, a few steps
     old), and resuming from it leads back to the live state."""
     import torch
     script = tmp_path / "sharded_state.py"
@@ -296,15 +299,21 @@ def test_weight_sharded_schedule_keeps_the_same_state_as_the_gradient_sharded_on
                 for k, (o, n) in a["layout"].items()}
 
     by_tensor, by_tensor_resumed = rel_by_tensor("a_5", "w_5"), rel_by_tensor("w_37", "w_resumed")
-    print("first moment by tensor after 5 steps: floor", rel_by_tensor("a_5", "b_5"), "wshard vs shard", by_tensor)
-    # run-to-run noise is 2e-7 .. 1e-6 here (seen once: 1.4e-5); a weight buffer that is one step stale anywhere (forward,
-    # data gradient, update) changes the conv gradients by ~1e-3
-    assert max(by_tensor.values()) < 1e-4 and max(by_tensor_resumed.values()) < 1e-4, (by_tensor, by_tensor_resumed)
+    resumed_floor = rel_by_tensor("w_resumed", "w_resumed2")
+    print("first moment by tensor after 5 steps: floor", rel_by_tensor("a_5", "b_5"), "wshard vs shard", by_tensor,
+          "resumed vs live", by_tensor_resumed, "resumed vs resumed again", resumed_floor)
+    # Two runs of the same steps part in discrete events (scripts/dbg/noise_floor2.py, single GPU, no data parallelism: 3e-7
+    # for the first steps, then jumps to 4e-5 around step 10, 3e-4 .. 2e-3 around step 30: the filter gradients' fp32 atomics
+    # reorder, and a ReLU / max-pool decision on a knife edge then falls the other way).  A weight buffer that is one step
+    # stale anywhere (forward, data gradient, update) shows as >= 1e-3 within five steps; optimizer rows that did not come
+    # back from a checkpoint as >= 0.1.
+    assert max(by_tensor.values()) < 3e-4, by_tensor
+    assert max(by_tensor_resumed.values()) < 1e-2, (by_tensor_resumed, resumed_floor)
     floor5, floor37 = rel("a_5", "b_5"), rel("a_37", "b_37")
     early, late, again = rel("a_5", "w_5"), rel("a_37", "w_37"), rel("w_37", "w_resumed")
     print("noise floor after 5 / 37 steps", floor5, floor37, "wshard vs shard", early, late, "resumed vs live", again)
     for t in ("P", "M", "V"):
-        assert early[t] < 1e-4 and again[t] < 1e-4, (t, early, again)     # (again: 5 steps from the snapshot at 32)
+        assert early[t] < 3e-4, (t, early)
         assert late[t] < max(50 * floor37[t], 1e-2), (t, late, floor37)   # (sanity only: 37 steps amplify the noise)
     for tag in ("a", "b", "w"):
         for o in res[tag]:
@@ -315,7 +324,7 @@ def test_weight_sharded_schedule_keeps_the_same_state_as_the_gradient_sharded_on
     for o in res["w"]:
         assert o["schedule"] == "ipc-wshard" and o["ckpt_step"] == 32, o       # the last agreed snapshot
         assert o["ckpt"] == res["w"][0]["ckpt"] and o["ckpt"] != o["live"], o
-        assert o["resumed"] == res["w"][0]["resumed"], o
+        assert o["resumed"] == res["w"][0]["resumed"], o                        # (bit-identical across the ranks of the run)
 
 
 _HEAD_RCCL = r"""
