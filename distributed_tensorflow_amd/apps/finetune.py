@@ -106,6 +106,17 @@ class DeviceBatchSampler:
         out_y.copy_(self.y.index_select(0, rows))
 
 
+def pair_allowed(at: int, *, start_step: int, warm_steps: int, steps: int, eval_step_interval: int, fault_inject_step: int) -> bool:
+    """May steps ``at`` and ``at + 1`` run as one graph replay?  Not during the eager warm-up (autotuning, lazy allocations),
+    not when either is a logging point (its metrics are read right after it; the pair's second step clears that slot), not
+    across the injected fault, and not the last step (logged as well)."""
+    if at - start_step < max(2, warm_steps) or at + 2 > steps - 1:
+        return False
+    if at % eval_step_interval == 0 or (at + 1) % eval_step_interval == 0:
+        return False
+    return fault_inject_step not in (at, at + 1)
+
+
 class StepPairGraph:
     """Two consecutive training steps — batch sampling, forward, loss, backward, gradient exchange, optimizer — as ONE
     hipGraph replay.  Two, because the step alternates between two sets of batch-norm statistic
@@ -370,13 +381,12 @@ def run(FLAGS, image_lists, image_dir: str, rank: int, world: int, device, seed:
         pair = StepPairGraph(one_step, lambda: trainer._fwd_parity, device, engine.capture_lock, log=lambda m: _log(rank, m))
 
     def pair_ok(at: int) -> bool:
-        if pair is None or not pair.enabled or at - start_step < max(2, warm_steps) or at + 2 > steps - 1:
+        if pair is None or not pair.enabled:
             return False
-        if at % FLAGS.eval_step_interval == 0 or (at + 1) % FLAGS.eval_step_interval == 0:
-            return False  # (a logging point reads the metrics of exactly that step)
-        if FLAGS.fault_inject_step in (at, at + 1):
+        if not pair_allowed(at, start_step=start_step, warm_steps=warm_steps, steps=steps,
+                            eval_step_interval=FLAGS.eval_step_interval, fault_inject_step=FLAGS.fault_inject_step):
             return False
-        return sv is None or sv.steps_allowed(at, 2) >= 2
+        return sv is None or sv.steps_allowed(at, 2) >= 2  # (an agreed stop step is not overshot)
 
     try:
         while i < steps and not (sv is not None and sv.should_stop()):

@@ -138,3 +138,24 @@ def test_retrain2_finetune_stop_relaunch_resume_two_ranks(tmp_path):
     assert min(int(m) for m in re.findall(r"Step (\d+):", r2.stdout)) >= step
     assert "replicas in sync: True" in r2.stdout and os.path.exists(os.path.join(cwd, "retrained_graph.pb"))
     assert os.path.exists(os.path.join(cwd, "logs", "model.ckpt-5"))
+
+
+def test_step_pairs_never_swallow_a_logging_point_or_the_fault():
+    """Which steps of the fine-tune may run as two-step hipGraph replays (``apps/finetune.py``): every logging point, the
+    injected fault and the last step stay single eager steps; everything else pairs up."""
+    from distributed_tensorflow_amd.apps.finetune import pair_allowed
+    kw = dict(start_step=0, warm_steps=5, steps=40, eval_step_interval=10, fault_inject_step=23)
+    i, singles, pairs = 0, [], []
+    while i < 40:
+        if pair_allowed(i, **kw):
+            pairs.append(i)
+            i += 2
+        else:
+            singles.append(i)
+            i += 1
+    assert all(s in singles for s in (0, 1, 2, 3, 4, 10, 20, 23, 30, 39)), singles   # warm-up, logging points, fault, last
+    assert all(p % 10 != 0 and (p + 1) % 10 != 0 and 23 not in (p, p + 1) for p in pairs)
+    assert len(pairs) >= 12 and 2 * len(pairs) + len(singles) == 40
+    # resumed run: the warm-up counts from the resumed step
+    assert not pair_allowed(101, start_step=100, warm_steps=5, steps=200, eval_step_interval=10, fault_inject_step=-1)
+    assert pair_allowed(105, start_step=100, warm_steps=5, steps=200, eval_step_interval=10, fault_inject_step=-1)
