@@ -212,7 +212,7 @@ class StartupMixin:
                 snap = [t.clone() for t in (e.P, e.M, e.V, e.step_t)]
             done0 = e._steps_done
             b1 = float(e.cfg.beta1) if hasattr(e, "cfg") else float(getattr(e, "b1", 0.9))
-            budget = float(os.environ.get("DTF_DP_STARTUP_BUDGET_S", "5"))
+            budget = float(os.environ.get("DTF_DP_STARTUP_BUDGET_S", "10"))
             trainer = self
             dev = "cpu" if self._stage_host else e.device
 
