@@ -139,8 +139,10 @@ struct ImageDesc {
 };
 
 // dst[b, y, x, 0..2] = ((bilinear(src_b, (y+off_y)*scale_y, (x'+off_x)*scale_x) * brightness) - 128) / 128, ch 3..7 = 0
+// F32: the same pixels as fp32 NHWC-8 (the input of the reference-precision forward, models/inception_v3.py Fp32Backbone).
+template <bool F32>
 __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ pixels, const ImageDesc* __restrict__ desc,
-                                                         uint16_t* __restrict__ out, int B, int S) {
+                                                         void* __restrict__ out_, int B, int S) {
   const long total = (long)B * S * S;
   for (long gi = (long)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (long)gridDim.x * 256) {
     const int x = (int)(gi % S);
@@ -162,19 +164,36 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
       const float top = p00 + (p01 - p00) * wx, bot = p10 + (p11 - p10) * wx;
       v[c] = ((top + (bot - top) * wy) * d.brightness - 128.f) * (1.f / 128.f);
     }
-    *reinterpret_cast<uint4*>(out + gi * 8) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], 0.f), 0u, 0u);
+    if constexpr (F32) {
+      float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(out_) + gi * 8);
+      o[0] = make_float4(v[0], v[1], v[2], 0.f);
+      o[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(out_) + gi * 8) =
+          make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], 0.f), 0u, 0u);
+    }
   }
 }
 
-DTF_API int dtf_preprocess_images(const void* pixels, const void* desc, void* out, int B, int S, hipStream_t st) {
+template <bool F32>
+static int launch_preprocess(const void* pixels, const void* desc, void* out, int B, int S, hipStream_t st) {
   if (B <= 0 || S <= 0) return ERR_SHAPE;
   const long total = (long)B * S * S;
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(preprocess_kernel, dim3((int)blocks), dim3(256), 0, st, (const uint8_t*)pixels, (const ImageDesc*)desc,
-                     (uint16_t*)out, B, S);
+  hipLaunchKernelGGL(preprocess_kernel<F32>, dim3((int)blocks), dim3(256), 0, st, (const uint8_t*)pixels,
+                     (const ImageDesc*)desc, out, B, S);
   DTF_CHECK_LAUNCH();
   return 0;
+}
+
+DTF_API int dtf_preprocess_images(const void* pixels, const void* desc, void* out, int B, int S, hipStream_t st) {
+  return launch_preprocess<false>(pixels, desc, out, B, S, st);
+}
+
+// out: fp32 [B, S, S, 8]
+DTF_API int dtf_preprocess_images_f32(const void* pixels, const void* desc, void* out, int B, int S, hipStream_t st) {
+  return launch_preprocess<true>(pixels, desc, out, B, S, st);
 }
 
 // ---------------------------------------------------------------------------------------------- batch gather

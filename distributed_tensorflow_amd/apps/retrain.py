@@ -202,6 +202,10 @@ def run(FLAGS, distributed: bool) -> int:
         return rc
     index = il.build_image_index(image_lists, image_dir)
 
+    backbone_kind = getattr(FLAGS, "backbone", "auto")
+    if backbone_kind == "auto":
+        backbone_kind = "inception" if device.type == "cuda" else "tiny"
+    fp32_backbone = backbone_kind == "inception" and getattr(FLAGS, "backbone_precision", "bf16") == "fp32"
     # the decode processes of the extraction pipeline start now, so they are warm by the time the backbone is on the GPU
     pipeline = None
     if os.environ.get("DTF_EXTRACT_PIPELINE", "1") != "0" and (device.type == "cuda" or os.environ.get("DTF_EXTRACT_PIPELINE") == "1"):
@@ -209,12 +213,10 @@ def run(FLAGS, distributed: bool) -> int:
         # reference recipe by default: full-size decode, bilinear resize on the GPU (retrain1/retrain.py:34-35: DecodeJpeg
         # -> ResizeBilinear inside the graph); --decode_draft asks libjpeg for a reduced-scale decode of large sources
         pipeline = DecodePipeline(device, batch_size=FLAGS.extract_batch_size,
-                                  draft=(2 * 299 if getattr(FLAGS, "decode_draft", False) else 0))
+                                  draft=(2 * 299 if getattr(FLAGS, "decode_draft", False) else 0),
+                                  fp32=fp32_backbone)
 
     # ---- backbone
-    backbone_kind = getattr(FLAGS, "backbone", "auto")
-    if backbone_kind == "auto":
-        backbone_kind = "inception" if device.type == "cuda" else "tiny"
     if backbone_kind == "inception":
         from ..models.inception_v3 import InceptionV3
         pb = maybe_download_and_extract(FLAGS.model_dir)
@@ -239,17 +241,24 @@ def run(FLAGS, distributed: bool) -> int:
             _log(rank, "Inception-v3 backbone: random-init weights (no pretrained artefact offline)")
             need_calibration = True
         backbone = net.forward
+        if fp32_backbone:
+            from ..models.inception_v3 import Fp32Backbone
+            backbone = Fp32Backbone(net)
+            _log(rank, "backbone precision: fp32 filters, activations and accumulation (the reference graph's precision; "
+                       "the default bf16 path is about ten times faster)")
     else:
         backbone = TinyBackbone(device, seed=seed)
         _log(rank, "backbone: TinyBackbone (a fixed random projection of the down-sampled image, %s) — this exercises the "
                    "retrain PLUMBING only; accuracies say nothing about Inception-v3.  Use --backbone inception on a GPU."
              % ("requested" if getattr(FLAGS, "backbone", "auto") == "tiny" else "chosen because no GPU is present"))
-    preproc = ImagePreprocessor(device)
+    preproc = ImagePreprocessor(device, fp32=fp32_backbone)
     if backbone_kind == "inception" and need_calibration and index.num_images > 0:
         # random-init only: BatchNorm statistics from one batch of this dataset (same images on every rank)
         from ..models.inception_train import calibrate_batchnorm
         pick = np.random.RandomState(seed).permutation(index.num_images)[:min(32, index.num_images)]
-        calibrate_batchnorm(net, preproc.load([index.paths[i] for i in sorted(pick)]))
+        calibrate_batchnorm(net, preproc.load([index.paths[i] for i in sorted(pick)]).to(torch.bfloat16))
+        if fp32_backbone:
+            backbone.invalidate()
         _log(rank, "calibrated BatchNorm statistics of the random-init backbone on %d images" % len(pick))
 
     head = RetrainHead(class_count, device, learning_rate=FLAGS.learning_rate, double_softmax=FLAGS.double_softmax,
@@ -552,5 +561,8 @@ def main(argv: Optional[List[str]] = None, distributed: bool = False) -> int:
     from .. import flags
     parser = flags.build_retrain_parser(distributed)
     parser.add_argument("--backbone", type=str, default="auto", help="auto | inception | tiny (CPU plumbing)")
+    parser.add_argument("--backbone_precision", type=str, default="bf16", choices=["bf16", "fp32"],
+                        help="bf16: the native MFMA forward (default).  fp32: filters, activations and accumulation in fp32 "
+                             "like the reference's frozen graph, through the library convolutions (about 10x slower)")
     FLAGS, _unparsed = flags.parse_known(parser, argv)
     return run(FLAGS, distributed)

@@ -21,6 +21,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--labels", type=str, default="retrained_labels.txt")
     p.add_argument("--device", type=str, default="auto")
     p.add_argument("--show", action="store_true")
+    p.add_argument("--backbone_precision", type=str, default="bf16", choices=["bf16", "fp32"])
     return p
 
 
@@ -37,6 +38,7 @@ def run(args) -> List[str]:
     use_cuda = torch.cuda.is_available() and args.device != "cpu"
     device = torch.device("cuda" if use_cuda else "cpu")
     from ..utils import graphdef as gd
+    fp32_input = False
     if gd.is_graphdef(args.graph):
         # the reference's artefact (retrain1/test.py:26-33): a serialized GraphDef holding Inception-v3 + the new layer;
         # parsed without TensorFlow, fed DecodeJpeg/contents -> final_result
@@ -51,6 +53,9 @@ def run(args) -> List[str]:
         head = RetrainHead(int(fb.shape[0]), device, final_tensor_name=final_name)
         head.load_tf_tensors({"final_training_ops/weights/final_weights": fw, "final_training_ops/biases/final_biases": fb})
         backbone = net.forward
+        if args.backbone_precision == "fp32":  # the reference graph's own precision (see models/inception_v3.py Fp32Backbone)
+            from ..models.inception_v3 import Fp32Backbone
+            backbone, fp32_input = Fp32Backbone(net), True
     else:
         t = ckpt.load_tensors(args.graph)
         backbone_kind = bytes(t["_dtf/backbone"]).decode() if "_dtf/backbone" in t else "?"
@@ -66,7 +71,7 @@ def run(args) -> List[str]:
     files = walk_images(args.imgs, (".jpg", ".jpeg"))
     if not files:
         raise FileNotFoundError("no JPEG images under %r" % args.imgs)
-    x = ImagePreprocessor(device).load(files)
+    x = ImagePreprocessor(device, fp32=fp32_input).load(files)
     probs = head.predict(backbone(x)).cpu().numpy()
     top1 = []
     for f, p in zip(files, probs):

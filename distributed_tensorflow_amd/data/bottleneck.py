@@ -77,16 +77,17 @@ def decode_jpeg(path: str) -> np.ndarray:
 class ImagePreprocessor:
     """JPEG decode on a host thread pool + one batched resize/normalise(/distort) kernel."""
 
-    def __init__(self, device, workers: int = 8):
+    def __init__(self, device, workers: int = 8, fp32: bool = False):
         self.device = torch.device(device)
         self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
+        self.dtype = torch.float32 if fp32 else torch.bfloat16   # fp32: the input of the reference-precision forward
 
     def decode(self, paths: Sequence[str]) -> List[np.ndarray]:
         return list(self.pool.map(decode_jpeg, paths))
 
     def batch(self, images: Sequence[np.ndarray], distortion: Optional[Distortion] = None,
               rng: Optional[random.Random] = None) -> torch.Tensor:
-        """uint8 HWC arrays (any sizes) -> bf16 NHWC ``[B,299,299,8]`` ((x-128)/128, channels 3..7 zero)."""
+        """uint8 HWC arrays (any sizes) -> NHWC ``[B,299,299,8]`` in ``self.dtype`` ((x-128)/128, channels 3..7 zero)."""
         B = len(images)
         descs = (ImageDesc * B)()
         total = sum(int(a.size) for a in images)
@@ -105,16 +106,18 @@ class ImagePreprocessor:
             offsets.append(off)
             off += int(a.size)
         if self.device.type != "cuda":
-            return torch.stack([preprocess_reference(a, descs[i]) for i, a in enumerate(images)]).to(torch.bfloat16)
+            return torch.stack([preprocess_reference(a, descs[i]) for i, a in enumerate(images)]).to(self.dtype)
         host = torch.empty(total, dtype=torch.uint8).pin_memory()
         hv = host.numpy()
         for a, o in zip(images, offsets):
             hv[o:o + a.size] = a.reshape(-1)
         pix = host.to(self.device, non_blocking=True)
         dbytes = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.device)
-        out = torch.empty(B, INPUT_SIZE, INPUT_SIZE, 8, dtype=torch.bfloat16, device=self.device)
-        native.check(native.hip().dtf_preprocess_images(pix.data_ptr(), dbytes.data_ptr(), out.data_ptr(), B, INPUT_SIZE,
-                                                        torch.cuda.current_stream().cuda_stream), "preprocess")
+        out = torch.empty(B, INPUT_SIZE, INPUT_SIZE, 8, dtype=self.dtype, device=self.device)
+        lib = native.hip()
+        fn = lib.dtf_preprocess_images_f32 if self.dtype == torch.float32 else lib.dtf_preprocess_images
+        native.check(fn(pix.data_ptr(), dbytes.data_ptr(), out.data_ptr(), B, INPUT_SIZE,
+                        torch.cuda.current_stream().cuda_stream), "preprocess")
         return out
 
     def load(self, paths: Sequence[str], distortion: Optional[Distortion] = None,
@@ -190,12 +193,14 @@ class BottleneckCache:
                     progress(str((first + count) // 100 * 100) + " bottleneck files created.")  # retrain1/retrain.py:179-180
                 done[0] = first + count
 
+            in_dtype = getattr(pipeline, "dtype", torch.bfloat16)
+
             def cpu_batch(imgs, descs):
-                return torch.stack([preprocess_reference(a, descs[i]) for i, a in enumerate(imgs)]).to(torch.bfloat16)
+                return torch.stack([preprocess_reference(a, descs[i]) for i, a in enumerate(imgs)]).to(in_dtype)
 
             def warm() -> None:  # kernel selection + graph capture at this batch size, under the first decodes
                 if self.device.type == "cuda":
-                    backbone(torch.zeros(pipeline.batch_size, INPUT_SIZE, INPUT_SIZE, 8, dtype=torch.bfloat16, device=self.device))
+                    backbone(torch.zeros(pipeline.batch_size, INPUT_SIZE, INPUT_SIZE, 8, dtype=in_dtype, device=self.device))
 
             self.extract_stats = pipeline.run([self.index.paths[i] for i in todo], consume, preprocess_cpu=cpu_batch, warm=warm)
             created = done[0]
@@ -357,7 +362,7 @@ def distorted_bottleneck_stream(index: ImageIndex, how_many: int, category: str,
     dev = pipeline.device
 
     def cpu_batch(imgs, descs):
-        return torch.stack([preprocess_reference(a, descs[i]) for i, a in enumerate(imgs)]).to(torch.bfloat16)
+        return torch.stack([preprocess_reference(a, descs[i]) for i, a in enumerate(imgs)]).to(pipeline.dtype)
 
     def desc(i: int):
         d = dist[i]

@@ -55,8 +55,9 @@ def default_workers() -> int:
 
 class DecodePipeline:
     def __init__(self, device, batch_size: int = 64, workers: Optional[int] = None, slots: int = 4, chunk: int = 8,
-                 draft: int = 2 * INPUT_SIZE, max_image_bytes: int = 64 << 20):
+                 draft: int = 2 * INPUT_SIZE, max_image_bytes: int = 64 << 20, fp32: bool = False):
         self.device = torch.device(device)
+        self.dtype = torch.float32 if fp32 else torch.bfloat16   # fp32: the input of the reference-precision forward
         self.batch_size, self.slots, self.chunk, self.draft = batch_size, max(2, slots), max(1, chunk), draft
         self.max_image_bytes = max_image_bytes
         self.workers = workers or default_workers()
@@ -137,7 +138,7 @@ class DecodePipeline:
     def batches(self, paths: Sequence[str], *, batch_size: Optional[int] = None, preprocess_cpu: Optional[Callable] = None,
                 warm: Optional[Callable[[], None]] = None, desc_fn: Optional[Callable[[int], tuple]] = None,
                 draft: Optional[int] = None):
-        """Generator over ``(first, count, x)``: ``x`` is the bf16 NHWC ``[batch_size, 299, 299, 8]`` network input of
+        """Generator over ``(first, count, x)``: ``x`` is the NHWC ``[batch_size, 299, 299, 8]`` network input (``self.dtype``) of
         ``paths[first : first + count]`` (rows >= count repeat the last image), valid on the current stream until the
         next-but-one batch is requested.  ``warm()`` (one-time work of the consumer: kernel selection, graph capture) runs
         while the decoders fill the first slots.  ``desc_fn(i) -> (precrop, off_y, off_x, flip, brightness)`` gives image
@@ -182,7 +183,8 @@ class DecodePipeline:
             side = torch.cuda.Stream(device=self.device)
             main = torch.cuda.current_stream(self.device)
             pix = [torch.empty(self._slot_bytes, dtype=torch.uint8, device=self.device) for _ in range(2)]
-            xbuf = [torch.empty(B, INPUT_SIZE, INPUT_SIZE, 8, dtype=torch.bfloat16, device=self.device) for _ in range(2)]
+            xbuf = [torch.empty(B, INPUT_SIZE, INPUT_SIZE, 8, dtype=self.dtype, device=self.device) for _ in range(2)]
+            preprocess = lib.dtf_preprocess_images_f32 if self.dtype == torch.float32 else lib.dtf_preprocess_images
             dsz = C.sizeof(ImageDesc)
             desc_host = torch.empty(self.slots, B * dsz, dtype=torch.uint8).pin_memory()
             desc_dev = [torch.empty(B * dsz, dtype=torch.uint8, device=self.device) for _ in range(2)]
@@ -310,8 +312,8 @@ class DecodePipeline:
                     copied[s].record(side)
                     if te:
                         te[1].record(side)
-                    native.check(lib.dtf_preprocess_images(pix[xb].data_ptr(), desc_dev[xb].data_ptr(), xbuf[xb].data_ptr(), B,
-                                                           INPUT_SIZE, side.cuda_stream), "preprocess")
+                    native.check(preprocess(pix[xb].data_ptr(), desc_dev[xb].data_ptr(), xbuf[xb].data_ptr(), B, INPUT_SIZE,
+                                            side.cuda_stream), "preprocess")
                     if te:
                         te[2].record(side)
                     x_ready[xb].record(side)

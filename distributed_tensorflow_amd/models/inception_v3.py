@@ -389,9 +389,10 @@ class InceptionV3:
 # ----------------------------------------------------------------------------------- oracle
 @torch.no_grad()
 def reference_forward(model: InceptionV3, x_nchw: torch.Tensor, bf16_sim: bool = False,
-                      return_buffers: bool = False):
+                      return_buffers: bool = False, weights: Optional[Dict[str, tuple]] = None):
     """Plain PyTorch fp32 forward of the same op program.  ``x_nchw`` fp32 ``[B,3,299,299]`` already
-    normalised.  ``bf16_sim`` rounds weights and every stored activation to bf16 like the native path."""
+    normalised.  ``bf16_sim`` rounds weights and every stored activation to bf16 like the native path.
+    ``weights``: a dict the device copies of the folded filters are kept in between calls."""
     r = (lambda t: t.to(torch.bfloat16).float()) if bf16_sim else (lambda t: t)
     g = model.graph
     dev = x_nchw.device
@@ -401,10 +402,15 @@ def reference_forward(model: InceptionV3, x_nchw: torch.Tensor, bf16_sim: bool =
         src = bufs[op.src]
         if op.kind == "conv":
             s = op.conv
-            w, b = model.folded(s.name)
-            w = r(w.to(dev)).permute(3, 2, 0, 1)
+            if weights is not None and s.name in weights:
+                w, b = weights[s.name]
+            else:
+                w, b = model.folded(s.name)
+                w, b = r(w.to(dev)).permute(3, 2, 0, 1).contiguous(), b.to(dev)
+                if weights is not None:
+                    weights[s.name] = (w, b)
             cin = w.shape[1]
-            y = F.relu(F.conv2d(src[:, op.src_off:op.src_off + cin], w, b.to(dev), stride=s.stride, padding=s.pad))
+            y = F.relu(F.conv2d(src[:, op.src_off:op.src_off + cin], w, b, stride=s.stride, padding=s.pad))
             y = r(y)
         elif op.kind == "maxpool":
             y = F.max_pool2d(src, 3, op.stride)
@@ -418,3 +424,33 @@ def reference_forward(model: InceptionV3, x_nchw: torch.Tensor, bf16_sim: bool =
             bufs[op.dst] = torch.zeros(B, c, h, w_, device=dev)
         bufs[op.dst][:, op.dst_off:op.dst_off + y.shape[1]] = y
     return (bufs["pool_3"], bufs) if return_buffers else bufs["pool_3"]
+
+
+class Fp32Backbone:
+    """Reference-precision feature extractor (``--backbone_precision fp32``): the op program of ``InceptionV3`` with fp32
+    filters, fp32 stored activations and fp32 accumulation, run through the library convolutions of PyTorch-ROCm (MIOpen),
+    no reduced-precision modes.  The reference computes ``pool_3/_reshape:0`` in float32 (the frozen graph it loads is a
+    float32 graph, ``/root/reference/retrain1/retrain.py:73-82``, one image per ``sess.run``); the default path here stores
+    activations in bf16 (``tests/test_inception_gpu.py`` bounds what that costs: about 1e-2 of the feature scale) and this one
+    is for the user who wants bottleneck files of the reference's precision, at about a tenth of the default's speed.
+    Takes the same NHWC-8 input batch as ``InceptionV3.forward`` (bf16, or fp32 from ``ImagePreprocessor(fp32=True)`` /
+    ``DecodePipeline(fp32=True)``, which keep the bilinear-resized pixels unrounded)."""
+
+    def __init__(self, model: InceptionV3):
+        self.model = model
+        self._weights: Dict[str, tuple] = {}
+
+    def invalidate(self) -> None:
+        """After the model's weights changed (``load_tf_weights`` / ``load_folded`` / calibration)."""
+        self._weights = {}
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        assert x.shape[1:] == (299, 299, INPUT_PAD_CHANNELS), tuple(x.shape)
+        x = x[..., :3].permute(0, 3, 1, 2).float().contiguous()
+        conv_tf32, mm_tf32 = torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32
+        torch.backends.cudnn.allow_tf32 = torch.backends.cuda.matmul.allow_tf32 = False
+        try:
+            return reference_forward(self.model, x, weights=self._weights)
+        finally:
+            torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32 = conv_tf32, mm_tf32

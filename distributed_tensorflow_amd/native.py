@@ -178,6 +178,7 @@ def hip() -> C.CDLL:
         # Inception / retrain ops (csrc/hip/inception_ops.hip, retrain_head.hip).  Every exported function gets
         # an explicit signature here: a missing one would make ctypes truncate 64-bit pointers to c_int.
         _sig(lib, "dtf_preprocess_images", I, [P, P, P, I, I, P])
+        _sig(lib, "dtf_preprocess_images_f32", I, [P, P, P, I, I, P])
         _sig(lib, "dtf_maxpool3x3", I, [P, P] + [I] * 7 + [P])
         _sig(lib, "dtf_avgpool3x3_same", I, [P, P] + [I] * 6 + [P])
         _sig(lib, "dtf_global_avgpool", I, [P, P, I, I, I, P])
