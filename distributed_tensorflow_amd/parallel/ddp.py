@@ -40,8 +40,17 @@ def init_process_group(backend: str = "auto", rank: Optional[int] = None, world:
         return 0, 1
     if dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
+    ndev = torch.cuda.device_count()
     if backend == "auto":
         backend = "nccl" if torch.cuda.is_available() else "gloo"
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        if backend == "nccl" and ndev < local_world:
+            # more ranks on this host than GPUs (functional runs, rehearsals on a one-GPU box): RCCL refuses two ranks on
+            # one device, the ranks share the GPUs and the process group is gloo (device tensors staged, see all_reduce_)
+            backend = "gloo"
+            if rank == 0:
+                print("%d ranks on this host for %d GPU(s): ranks share devices, process group backend gloo" % (local_world, ndev),
+                      flush=True)
     if master_addr is not None:
         os.environ["MASTER_ADDR"] = master_addr
     if master_port is not None:
@@ -49,9 +58,8 @@ def init_process_group(backend: str = "auto", rank: Optional[int] = None, world:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if backend == "nccl":
-        local = int(os.environ.get("LOCAL_RANK", rank % max(1, torch.cuda.device_count())))
-        torch.cuda.set_device(local)
+    if ndev > 0 and torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)) % ndev)
     dist.init_process_group(backend=backend, rank=rank, world_size=world,
                             timeout=datetime.timedelta(seconds=timeout_s))
     return rank, world
