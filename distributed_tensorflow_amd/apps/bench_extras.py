@@ -6,7 +6,7 @@ headline number.  Nothing here is the headline; every record says what it is.
   files -> batched Inception-v3 forward -> HBM bottleneck cache (images/s end to end), head training (steps/s), final
   test accuracy;
 * ``extra_inception_forward`` — the batched Inception-v3 forward alone at batch 128 (bf16 operands, hipGraph);
-* ``extra_finetune_bf16`` — config 5: the full fine-tune at batch 128 measured THROUGH ``retrain1/retrain.py --finetune``
+* ``extra_finetune_bf16`` (and ``extra_finetune_bf16_b256``) — config 5: the full fine-tune at batch 128 (256) measured THROUGH ``retrain1/retrain.py --finetune``
   (device-side sampling, logging and validation included), with the loss after the run.
 """
 from __future__ import annotations
@@ -96,20 +96,23 @@ def run_extras(budget_s: float = 130.0, which=("retrain1", "inception_forward", 
             else:
                 rec.update(value=None, error=log[-400:])
             out["extra_retrain1"] = rec
-        if "finetune_bf16" in which and left() > 45:
-            steps = 150
+        # batch 128 (the batch the earlier rounds quote) and batch 256 ("large global batch": 16.7 GB of activations of the
+        # 288 GB, the 8x8 and 17x17 layers fill the 256 CUs only there)
+        for batch, steps, key in ((128, 150, "extra_finetune_bf16"), (256, 100, "extra_finetune_bf16_b256")):
+            if "finetune_bf16" not in which or left() <= 45:
+                continue
             rc, log, dt = _run([py, os.path.join(ROOT, "retrain1", "retrain.py"), "--synthetic", "--finetune", "--synthetic_classes", "5",
-                                "--synthetic_images_per_class", "200", "--training_steps", str(steps), "--finetune_batch_size", "128",
-                                "--eval_step_interval", "1000", "--learning_rate", "0.01", "--seed", "3",
-                                "--finetune_bn_recalibrate", "2"], tmp, min(110.0, left()))
-            rec = {"config": "Inception-v3 full fine-tune through retrain1/retrain.py --finetune: batch 128, SGD 0.01, 5 synthetic "
-                             "classes, batch drawn by the device-side sampler, random-init weights",
+                                "--synthetic_images_per_class", "200", "--training_steps", str(steps),
+                                "--finetune_batch_size", str(batch), "--eval_step_interval", "1000", "--learning_rate", "0.01",
+                                "--seed", "3", "--finetune_bn_recalibrate", "2"], tmp, min(110.0, left()))
+            rec = {"config": "Inception-v3 full fine-tune through retrain1/retrain.py --finetune: batch %d, SGD 0.01, 5 synthetic "
+                             "classes, batch drawn by the device-side sampler, random-init weights" % batch,
                    "dtype": "bf16", "unit": "images/s", "steps": steps, "wall_seconds": round(dt, 1)}
             p = parse_finetune(log)
             if rc == 0 and p["value"]:
                 rec.update(p)
-                rec["ms"] = round(1000.0 * 128 / p["value"], 2)
+                rec["ms"] = round(1000.0 * batch / p["value"], 2)
             else:
                 rec.update(value=None, error=log[-400:])
-            out["extra_finetune_bf16"] = rec
+            out[key] = rec
     return out

@@ -245,7 +245,7 @@ def run(FLAGS, distributed: bool) -> int:
             from ..models.inception_v3 import Fp32Backbone
             backbone = Fp32Backbone(net)
             _log(rank, "backbone precision: fp32 filters, activations and accumulation (the reference graph's precision; "
-                       "the default bf16 path is about ten times faster)")
+                       "4.5 k images/s at batch 128 after ~9 s of library algorithm search; the default bf16 path does 27 k)")
     else:
         backbone = TinyBackbone(device, seed=seed)
         _log(rank, "backbone: TinyBackbone (a fixed random projection of the down-sampled image, %s) — this exercises the "
@@ -563,6 +563,6 @@ def main(argv: Optional[List[str]] = None, distributed: bool = False) -> int:
     parser.add_argument("--backbone", type=str, default="auto", help="auto | inception | tiny (CPU plumbing)")
     parser.add_argument("--backbone_precision", type=str, default="bf16", choices=["bf16", "fp32"],
                         help="bf16: the native MFMA forward (default).  fp32: filters, activations and accumulation in fp32 "
-                             "like the reference's frozen graph, through the library convolutions (about 10x slower)")
+                             "like the reference's frozen graph, through the library convolutions (4.5 k instead of 27 k images/s)")
     FLAGS, _unparsed = flags.parse_known(parser, argv)
     return run(FLAGS, distributed)
