@@ -205,7 +205,9 @@ def run(FLAGS, distributed: bool) -> int:
     backbone_kind = getattr(FLAGS, "backbone", "auto")
     if backbone_kind == "auto":
         backbone_kind = "inception" if device.type == "cuda" else "tiny"
-    fp32_backbone = backbone_kind == "inception" and getattr(FLAGS, "backbone_precision", "bf16") == "fp32"
+    # (the native bf16 forward needs the GPU; on a CPU-only box the Inception backbone runs as the fp32 reference forward)
+    fp32_backbone = backbone_kind == "inception" and (getattr(FLAGS, "backbone_precision", "bf16") == "fp32"
+                                                      or device.type != "cuda")
     # the decode processes of the extraction pipeline start now, so they are warm by the time the backbone is on the GPU
     pipeline = None
     if os.environ.get("DTF_EXTRACT_PIPELINE", "1") != "0" and (device.type == "cuda" or os.environ.get("DTF_EXTRACT_PIPELINE") == "1"):
@@ -244,8 +246,11 @@ def run(FLAGS, distributed: bool) -> int:
         if fp32_backbone:
             from ..models.inception_v3 import Fp32Backbone
             backbone = Fp32Backbone(net)
-            _log(rank, "backbone precision: fp32 filters, activations and accumulation (the reference graph's precision; "
-                       "4.5 k images/s at batch 128 after ~9 s of library algorithm search; the default bf16 path does 27 k)")
+            if device.type == "cuda":
+                _log(rank, "backbone precision: fp32 filters, activations and accumulation (the reference graph's precision; "
+                           "4.5 k images/s at batch 128 after ~9 s of library algorithm search; the default bf16 path does 27 k)")
+            else:
+                _log(rank, "no GPU: the Inception-v3 backbone runs as the fp32 reference forward on the CPU (a few images/s)")
     else:
         backbone = TinyBackbone(device, seed=seed)
         _log(rank, "backbone: TinyBackbone (a fixed random projection of the down-sampled image, %s) — this exercises the "
@@ -254,9 +259,14 @@ def run(FLAGS, distributed: bool) -> int:
     preproc = ImagePreprocessor(device, fp32=fp32_backbone)
     if backbone_kind == "inception" and need_calibration and index.num_images > 0:
         # random-init only: BatchNorm statistics from one batch of this dataset (same images on every rank)
-        from ..models.inception_train import calibrate_batchnorm
         pick = np.random.RandomState(seed).permutation(index.num_images)[:min(32, index.num_images)]
-        calibrate_batchnorm(net, preproc.load([index.paths[i] for i in sorted(pick)]).to(torch.bfloat16))
+        calib = preproc.load([index.paths[i] for i in sorted(pick)])
+        if device.type == "cuda":
+            from ..models.inception_train import calibrate_batchnorm
+            calibrate_batchnorm(net, calib.to(torch.bfloat16))
+        else:
+            from ..models.inception_v3 import calibrate_batchnorm_reference
+            calibrate_batchnorm_reference(net, calib)
         if fp32_backbone:
             backbone.invalidate()
         _log(rank, "calibrated BatchNorm statistics of the random-init backbone on %d images" % len(pick))

@@ -42,8 +42,6 @@ def run(args) -> List[str]:
     if gd.is_graphdef(args.graph):
         # the reference's artefact (retrain1/test.py:26-33): a serialized GraphDef holding Inception-v3 + the new layer;
         # parsed without TensorFlow, fed DecodeJpeg/contents -> final_result
-        if not use_cuda:
-            raise RuntimeError("this graph holds the Inception-v3 backbone, which needs the GPU path")
         layers, fw, fb, final_name, ops = gd.read_retrained_graph(args.graph)
         from ..models.inception_v3 import InceptionV3
         net = InceptionV3(device, seed=0)
@@ -53,7 +51,7 @@ def run(args) -> List[str]:
         head = RetrainHead(int(fb.shape[0]), device, final_tensor_name=final_name)
         head.load_tf_tensors({"final_training_ops/weights/final_weights": fw, "final_training_ops/biases/final_biases": fb})
         backbone = net.forward
-        if args.backbone_precision == "fp32":  # the reference graph's own precision (see models/inception_v3.py Fp32Backbone)
+        if args.backbone_precision == "fp32" or not use_cuda:  # the graph's own precision (models/inception_v3.py Fp32Backbone); the only path without a GPU
             from ..models.inception_v3 import Fp32Backbone
             backbone, fp32_input = Fp32Backbone(net), True
     else:

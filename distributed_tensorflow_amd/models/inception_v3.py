@@ -455,3 +455,37 @@ class Fp32Backbone:
             return reference_forward(self.model, x, weights=self._weights)
         finally:
             torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32 = conv_tf32, mm_tf32
+
+
+@torch.no_grad()
+def calibrate_batchnorm_reference(model: InceptionV3, x: torch.Tensor) -> None:
+    """``inception_train.calibrate_batchnorm`` in plain PyTorch fp32 (runs on the CPU too): every conv's moving statistics
+    become the batch statistics of the calibration batch ``x`` (NHWC-8 like ``forward``'s input), layer by layer, so that a
+    RANDOM-INIT backbone keeps sane activation scales.  Pretrained weights need none of this."""
+    g = model.graph
+    x = x[..., :3].permute(0, 3, 1, 2).float().contiguous()
+    dev = x.device
+    bufs: Dict[str, torch.Tensor] = {"input": x}
+    B = x.shape[0]
+    for op in g.ops:
+        src = bufs[op.src]
+        if op.kind == "conv":
+            s = op.conv
+            p = model.params[s.name]
+            w = p["weights"].to(dev).permute(3, 2, 0, 1).contiguous()
+            raw = F.conv2d(src[:, op.src_off:op.src_off + w.shape[1]], w, None, stride=s.stride, padding=s.pad)
+            var, mean = torch.var_mean(raw, dim=(0, 2, 3), unbiased=False)
+            p["moving_mean"], p["moving_variance"] = mean.cpu(), var.cpu()
+            scale = (p["gamma"].to(dev) / torch.sqrt(var + BN_EPS)).view(1, -1, 1, 1)
+            y = F.relu((raw - mean.view(1, -1, 1, 1)) * scale + p["beta"].to(dev).view(1, -1, 1, 1))
+        elif op.kind == "maxpool":
+            y = F.max_pool2d(src, 3, op.stride)
+        elif op.kind == "avgpool":
+            y = F.avg_pool2d(src, 3, 1, 1, count_include_pad=False)
+        else:
+            continue
+        if op.dst not in bufs:
+            h, w_, c = g.shapes[op.dst]
+            bufs[op.dst] = torch.zeros(B, c, h, w_, device=dev)
+        bufs[op.dst][:, op.dst_off:op.dst_off + y.shape[1]] = y
+    model._packed.clear()

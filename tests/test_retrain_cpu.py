@@ -14,7 +14,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _cli(args, cwd, timeout=600, env_extra=None):
-    env = dict(os.environ, PYTHONPATH=REPO, OMP_NUM_THREADS="2", **(env_extra or {}))
+    env = dict(os.environ, PYTHONPATH=REPO, OMP_NUM_THREADS="2")
+    env.update(env_extra or {})
     return subprocess.run([sys.executable] + args, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                           text=True, timeout=timeout)
 
@@ -142,3 +143,28 @@ def test_retrain2_stop_relaunch_resume_two_ranks(tmp_path):
     files = [l for l in r3.stdout.splitlines() if l.endswith(".jpg")]
     truth = [os.path.basename(os.path.dirname(f)).replace("_", " ") for f in files]
     assert len(top1) == len(truth) == 12 and np.mean([a == b for a, b in zip(top1, truth)]) >= 0.75, list(zip(top1, truth))
+
+
+def test_inception_backbone_without_a_gpu(tmp_path):
+    """``--backbone inception`` on a CPU-only box: the 2015 op program runs as the fp32 reference forward
+    (``models/inception_v3.py::Fp32Backbone``; the reference itself is CPU-runnable TensorFlow,
+    ``/root/reference/retrain1/retrain.py:73-82``), batch-norm statistics of the random-init network are calibrated in
+    PyTorch, the export is the whole-network GraphDef, and ``retrain1/test.py`` classifies held-out JPEGs from that file."""
+    from distributed_tensorflow_amd.data import image_lists as il
+    from distributed_tensorflow_amd.utils import graphdef as gd
+    cwd = str(tmp_path)
+    env = {"OMP_NUM_THREADS": "4"}
+    r = _cli([os.path.join(REPO, "retrain1", "retrain.py"), "--device", "cpu", "--backbone", "inception", "--synthetic",
+              "--synthetic_classes", "2", "--synthetic_images_per_class", "12", "--training_steps", "30",
+              "--train_batch_size", "8", "--validation_batch_size", "4", "--eval_step_interval", "10",
+              "--extract_batch_size", "8", "--learning_rate", "0.05", "--seed", "3"], cwd, env_extra=env)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "fp32 reference forward on the CPU" in r.stdout and "calibrated BatchNorm statistics" in r.stdout
+    assert gd.is_graphdef(os.path.join(cwd, "retrained_graph.pb"))
+    held = il.make_synthetic_image_dir(os.path.join(cwd, "held_out"), num_classes=2, images_per_class=4, seed=999)
+    r2 = _cli([os.path.join(REPO, "retrain1", "test.py"), "--imgs", held, "--device", "cpu"], cwd, env_extra=env)
+    assert r2.returncode == 0, r2.stdout[-3000:]
+    files = [l for l in r2.stdout.splitlines() if l.endswith(".jpg")]
+    top1 = [l[3:] for l in r2.stdout.splitlines() if l.startswith("=> ")]
+    truth = [os.path.basename(os.path.dirname(f)).replace("_", " ") for f in files]
+    assert len(files) == 8 and np.mean([a == b for a, b in zip(top1, truth)]) >= 0.75, list(zip(top1, truth))
