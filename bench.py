@@ -131,6 +131,12 @@ def main():
                os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
+    # stdout carries the ONE JSON line and nothing else: every other line of this process (the trainer's start-up report,
+    # C++ libraries that write to descriptor 1 such as gloo's connection messages) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     if os.environ.get("DTF_HANG_DUMP_SECS"):  # debugging aid: dump every thread's stack if the run stalls
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["DTF_HANG_DUMP_SECS"]), exit=True)
@@ -284,10 +290,9 @@ def main():
             "allreduce_us_at_startup": trainer.transport_us,
         }
         out.update(extras)
-        # ONE write call for the whole line: with unbuffered stdio print() issues the text and the newline separately, and
-        # another rank's output on the shared pipe could land between them
-        sys.stdout.write(json.dumps(out) + "\n")
+        # ONE write call for the whole line, on the process's original stdout
         sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
     trainer.close()

@@ -173,7 +173,8 @@ class DataParallelTrainer(StartupMixin, ShardedStateMixin):
         self.startup_seconds = round(time.perf_counter() - t_start, 3) if self._multi else 0.0
         if self._multi and self.rank == 0:
             print("data-parallel start-up: %.2f s; transport %s, schedule %s%s" % (
-                self.startup_seconds, self.comm, self.schedule,
+                self.startup_seconds,
+                self.comm if self.comm != "rccl" else "process group (%s)" % dist.get_backend(self.group), self.schedule,
                 "".join("\n  " + l for l in self.startup_log)), flush=True)
 
     def ensure_healthy(self) -> bool:
