@@ -377,7 +377,7 @@ def run(FLAGS, image_lists, image_dir: str, rank: int, world: int, device, seed:
     # pairs of steps as one hipGraph replay wherever the host has nothing to do in between (no logging point, no fault
     # injection, no agreed stop step inside the pair); everything else, and the warm-up, runs eagerly
     pair = None
-    if native_ok and sampler is not None and getattr(FLAGS, "finetune_graph", True) and dp.graph_capable():
+    if native_ok and sampler is not None and getattr(FLAGS, "finetune_graph", False) and dp.graph_capable():
         pair = StepPairGraph(one_step, lambda: trainer._fwd_parity, device, engine.capture_lock, log=lambda m: _log(rank, m))
 
     def pair_ok(at: int) -> bool:

@@ -21,6 +21,7 @@ when the artefact is available.  ``reference_forward`` is the PyTorch fp32 oracl
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
@@ -200,6 +201,79 @@ def graph_flops(g: _Builder) -> float:
     return total
 
 
+class StreamPlan:
+    """The op program over ``K`` HIP streams: static list scheduling (an op goes where it finishes first by the given cost
+    estimates; a dependency that crosses streams costs ``edge_us``, an event wait between two hardware queues was measured at
+    5-10 us) plus the events that carry the dependencies.  The branches of a mixed block are independent until the concat and
+    no single launch of the 17x17 / 8x8 layers fills 256 CUs for its whole duration: a second and third stream fill the
+    partial rounds.  Dependencies are buffer-level: an op waits for every earlier op that wrote its source buffer.
+
+    ``begin(main)`` / ``stream_for(i)`` (waits issued, returns the stream op ``i`` runs on) / ``done(i)`` / ``end()`` (every
+    side stream joined back into ``main``) — fork / join in the form stream capture wants, so the same code runs eagerly and
+    inside a hipGraph capture.  An edge between two SIDE streams is relayed through ``main``: ending the capture of a graph
+    that holds such an edge crashes inside the HIP runtime (ROCm 7.0.2), and the relay costs nothing here because those
+    edges are the concat points, where everything waits for everything."""
+
+    def __init__(self, ops, costs_us, K: int, device, edge_us: float = 6.0):
+        edge_us = float(os.environ.get("DTF_STREAM_EDGE_US", edge_us))
+        n = len(ops)
+        writers: Dict[str, List[int]] = {}
+        avail, finish, stream = [0.0] * K, [0.0] * n, [0] * n
+        waits: List[List[int]] = [[] for _ in range(n)]
+        for i, op in enumerate(ops):
+            deps = writers.get(op.src, [])
+            best = None
+            for k in range(K):
+                ready = max([avail[k]] + [finish[d] + (edge_us if stream[d] != k else 0.0) for d in deps])
+                if best is None or ready + costs_us[i] < best[0] - 1e-9:
+                    best = (ready + costs_us[i], k)
+            finish[i], stream[i] = best
+            avail[stream[i]] = finish[i]
+            latest: Dict[int, int] = {}
+            for d in deps:  # (stream order: the latest writer on each other stream covers the earlier ones)
+                if stream[d] != stream[i]:
+                    latest[stream[d]] = max(latest.get(stream[d], -1), d)
+            waits[i] = sorted(latest.values())
+            writers.setdefault(op.dst, []).append(i)
+        self.stream_of, self.waits = stream, waits
+        self.waited = {d for w in waits for d in w}
+        self.serial_us, self.planned_us = float(sum(costs_us)), float(max(finish)) if n else 0.0
+        self.K, self.device = K, device
+        self.used = sorted({k for k in stream if k != 0})
+        self.side = None   # streams and events are made at the first begin(): the plan itself needs no GPU
+
+    def begin(self, main) -> None:
+        if self.side is None:
+            self.side = [torch.cuda.Stream(device=self.device) for _ in range(self.K - 1)]
+            self.ev = {d: torch.cuda.Event() for d in self.waited}
+            self.relay = {d: torch.cuda.Event() for d in self.waited if self.stream_of[d] != 0}
+            self.join = [torch.cuda.Event() for _ in self.side]
+        self.main, self.streams, self.relayed = main, [main] + self.side, set()
+
+    def stream_for(self, i: int):
+        k = self.stream_of[i]
+        s = self.streams[k]
+        for d in self.waits[i]:
+            if k != 0 and self.stream_of[d] != 0:
+                if d not in self.relayed:
+                    self.main.wait_event(self.ev[d])
+                    self.relay[d].record(self.main)
+                    self.relayed.add(d)
+                s.wait_event(self.relay[d])
+            else:
+                s.wait_event(self.ev[d])
+        return s
+
+    def done(self, i: int) -> None:
+        if i in self.waited:
+            self.ev[i].record(self.streams[self.stream_of[i]])
+
+    def end(self) -> None:
+        for k in self.used:
+            self.join[k - 1].record(self.streams[k])
+            self.main.wait_event(self.join[k - 1])
+
+
 class InceptionV3:
     """Weights + native batched executor."""
 
@@ -207,6 +281,8 @@ class InceptionV3:
         self.graph = build_graph()
         self.conv_core = conv_core       # "v1" | "v2" | "auto" (time both GEMM cores per layer and batch size once)
         self._core: Dict[int, Dict[str, int]] = {}
+        self._core_us: Dict[int, Dict[str, float]] = {}   # measured duration of the chosen core per layer (stream planner)
+        self._plans: Dict[int, "StreamPlan"] = {}
         self.device = torch.device(device)
         self.params: "OrderedDict[str, Dict[str, torch.Tensor]]" = OrderedDict()
         gen = torch.Generator(device="cpu")
@@ -301,16 +377,23 @@ class InceptionV3:
         from .. import native
         from ..ops import hip_ops
         lib = native.hip()
-        st = torch.cuda.current_stream().cuda_stream
+        main = torch.cuda.current_stream()
+        st = main.cuda_stream
         B = x.shape[0]
-        for op in self.graph.ops:
+        plan = self._stream_plan(B, bufs)
+        if plan is not None:
+            plan.begin(main)
+        for i, op in enumerate(self.graph.ops):
             src = x if op.src == "input" else bufs[op.src]
+            cur = main if plan is None else plan.stream_for(i)
+            st = cur.cuda_stream
             if op.kind == "conv":
                 s = op.conv
                 wp, b = self.packed(s.name)
-                hip_ops.conv_bias_relu(src, wp, b, Cin=s.cin, KH=s.kh, KW=s.kw, stride=s.stride, pad=s.pad, relu=True,
-                                       out=bufs[op.dst], out_channel_offset=op.dst_off, in_channel_offset=op.src_off,
-                                       core=self._core.get(B, {}).get(s.name, 1))
+                with torch.cuda.stream(cur):  # (the op wrapper launches on the current stream)
+                    hip_ops.conv_bias_relu(src, wp, b, Cin=s.cin, KH=s.kh, KW=s.kw, stride=s.stride, pad=s.pad, relu=True,
+                                           out=bufs[op.dst], out_channel_offset=op.dst_off, in_channel_offset=op.src_off,
+                                           core=self._core.get(B, {}).get(s.name, 1))
             elif op.kind == "maxpool":
                 dst = bufs[op.dst]
                 _, H, W, Cs = src.shape
@@ -324,7 +407,31 @@ class InceptionV3:
             elif op.kind == "gap":
                 _, H, W, Cs = src.shape
                 native.check(lib.dtf_global_avgpool(src.data_ptr(), bufs["pool_3"].data_ptr(), B, H * W, Cs, st), "gap")
+            if plan is not None:
+                plan.done(i)
+        if plan is not None:
+            plan.end()
         return bufs["pool_3"]
+
+    def _stream_plan(self, B: int, bufs) -> Optional["StreamPlan"]:
+        """The forward program over ``DTF_INCEPTION_STREAMS`` streams (default 2; 1 = one stream; batch 128: 4.78 / 4.13 / 4.38 / 4.48 ms with 1 / 2 / 3 / 4), planned once per batch
+        size with the core-selection timings as cost estimates."""
+        K = max(1, int(os.environ.get("DTF_INCEPTION_STREAMS", "2")))
+        if K == 1 or B not in self._core:
+            return None   # (core selection itself runs layer by layer on one stream)
+        if B not in self._plans:
+            costs = []
+            for op in self.graph.ops:
+                if op.kind == "conv":
+                    s = op.conv
+                    _, ho, wo, _ = bufs[op.dst].shape
+                    t = self._core_us.get(B, {}).get(s.name)
+                    costs.append(t if t else 4.0 + 2.0 * B * ho * wo * s.cout * s.kh * s.kw * s.cin / 350e12 * 1e6)
+                else:
+                    src = bufs.get(op.src)
+                    costs.append(4.0 + (4.0 * src.numel() / 3e12 * 1e6 if src is not None else 0.0))
+            self._plans[B] = StreamPlan(self.graph.ops, costs, K, self.device)
+        return self._plans[B]
 
     def _select_cores(self, x: torch.Tensor, bufs: Dict[str, torch.Tensor]) -> None:
         """Per-layer choice between the two conv GEMM cores for this batch size (measured once, best of 3)."""
@@ -359,6 +466,7 @@ class InceptionV3:
                 t[core] = best
             fastest = min(t, key=t.get)
             choice[s.name] = fastest if t[fastest] < 0.97 * t[1] else 1
+            self._core_us.setdefault(B, {})[s.name] = 1e3 * t[choice[s.name]]
         self._core[B] = choice
 
     def forward(self, x: torch.Tensor, use_graph: bool = True) -> torch.Tensor:

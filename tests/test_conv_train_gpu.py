@@ -417,7 +417,7 @@ def test_retrain_cli_finetune_on_gpu(tmp_path):
            "--synthetic_images_per_class", "30", "--training_steps", "40", "--finetune_batch_size", "16", "--learning_rate", "0.05",
            "--eval_step_interval", "10", "--bottleneck_dir", os.path.join(cwd, "bn"), "--summaries_dir", os.path.join(cwd, "logs"),
            "--output_graph", os.path.join(cwd, "ft.pb"), "--output_labels", os.path.join(cwd, "labels.txt"),
-           "--model_dir", os.path.join(cwd, "model"), "--seed", "3"]
+           "--model_dir", os.path.join(cwd, "model"), "--seed", "3", "--finetune_graph", "true"]
     r = subprocess.run(cmd, cwd=cwd, env=dict(os.environ, PYTHONPATH=repo), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=500)
     assert r.returncode == 0, r.stdout[-3000:]

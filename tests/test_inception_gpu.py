@@ -372,3 +372,21 @@ def test_retrain_cli_with_the_reference_precision_backbone(tmp_path):
         assert rc == 0 and os.path.exists("retrained_graph.pb")
     finally:
         os.chdir(cwd)
+
+
+def test_multi_stream_forward_is_bit_identical_to_one_stream(monkeypatch):
+    """``StreamPlan`` only reorders launches between streams: same kernels, same operands, same bits — eagerly and as a
+    hipGraph replay, with two and with three streams (three: side-to-side edges relayed through the main stream)."""
+    from distributed_tensorflow_amd.models import inception_v3 as iv3
+    torch.manual_seed(5)
+    xin = torch.zeros(16, 299, 299, 8, device=DEV, dtype=torch.bfloat16)
+    xin[..., :3] = (torch.rand(16, 299, 299, 3, device=DEV) * 2 - 1).to(torch.bfloat16)
+    outs = {}
+    for K in (1, 2, 3):
+        monkeypatch.setenv("DTF_INCEPTION_STREAMS", str(K))
+        net = iv3.InceptionV3(DEV, seed=4, conv_core="v1")   # (one core everywhere: the choice must not differ between the nets)
+        outs[K] = (net.forward(xin, use_graph=False), net.forward(xin, use_graph=True), net.forward(xin, use_graph=True))
+        assert (net._plans[16].K if K > 1 else not net._plans) and float(outs[K][0].abs().mean()) > 1e-3
+    for K in (2, 3):
+        for o in outs[K]:
+            assert torch.equal(o, outs[1][0]), K
