@@ -226,6 +226,33 @@ def main():
                  "note": "same config and timing; NOT the headline (the reference trains in fp32)"}
         del eng2, tr2, dd2
 
+    # fp32 headline with bf16x6 kernels in it: the same step on the exact-fp32 MFMA only, as a labelled extra
+    emu = None
+    extra_exact = None
+    if use_cuda and args.engine == "native" and args.dtype == "fp32":
+        from distributed_tensorflow_amd import native
+        emu = native.f32_emulation_note()
+        if emu and world == 1 and not args.dp_path and extra_dtype:
+            native.hip().dtf_f32_emulation_set(0)
+            try:
+                dd3 = mnist.DeviceDataset(train, device, seed=1)
+                eng3 = make_engine("native", dd3, batch_size=args.batch, lr=1e-4, keep_prob=0.7, double_softmax=True,
+                                   seed=1234, device=device, use_graph=not args.no_graph, dtype="fp32")
+                tr3 = DataParallelTrainer(eng3, sync=True)
+                tr3.prepare()
+                tr3.train_steps(args.warmup)
+                sync()
+                _warm_by_time(tr3, sync, reduce_max, args.warmup_seconds, use_cuda)
+                b3 = _time_blocks(tr3, args.steps, sync, reduce_max)
+                d3 = sorted(b3)[len(b3) // 2]
+                extra_exact = {"dtype": "fp32", "fp32_emulation": None, "value": round(args.steps * args.batch / d3, 1),
+                               "unit": "images/s", "ms_per_step": round(1000.0 * d3 / args.steps, 5), "timed_blocks": len(b3),
+                               "note": "same config and timing with DTF_F32_EMULATION=0: every GEMM-shaped kernel on "
+                                       "v_mfma_f32_16x16x4_f32 (the round-2 headline path)"}
+                del eng3, tr3, dd3
+            finally:
+                native.hip().dtf_f32_emulation_set(1)
+
     # the reference schedule on real digits, outside the timed region
     ref_acc = None
     if args.eval and args.ref_steps > 0 and use_cuda and args.engine == "native":
@@ -260,6 +287,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": round(value / BASELINE_IMAGES_PER_SEC, 2),
             "dtype": dtype,
+            "fp32_emulation": emu,
+            "extra_fp32_exact_mfma": extra_exact,
             "data": "synthetic MNIST-shaped (28x28x1, 10 classes), random-init weights",
             "config": {"model": "demo2 MNIST CNN (conv5x5x32-pool-conv5x5x64-pool-fc1024-dropout-fc10), Adam 1e-4",
                        "global_batch": global_batch, "seq_len": None, "parallelism": "dp%d" % world,

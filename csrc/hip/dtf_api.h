@@ -81,6 +81,21 @@ DTF_API int dtf_conv_dw_duo_f32(const float* dpool2, const float* pool2, const v
                                 const float* dpool1, const void* amax1, float* dW1, float* db1, const struct OptimParams* adam,
                                 hipStream_t st);
 
+// ---- fp32 on the bf16 matrix cores ("bf16x6", bf16x3.h): f32x3_conv2.hip
+DTF_API void dtf_f32_emulation_set(int on);
+DTF_API int dtf_f32_emulation();
+DTF_API int dtf_conv2_pack3(const float* W, void* Wf3, void* Wb3, hipStream_t st);
+DTF_API int dtf_conv2_fwd_x3_packed(const float* x, const void* Wf3, const float* bias, float* out, void* amax, int B,
+                                    hipStream_t st);
+DTF_API int dtf_conv2_bwd_data_x3_packed(const float* dpool2, const float* pool2, const void* amax2, const void* Wb3,
+                                         const float* pool1, float* dpool1, int B, hipStream_t st);
+DTF_API int dtf_conv2_fwd_x3(const float* x, const float* W, const float* bias, float* out, void* amax, int B, hipStream_t st);
+DTF_API int dtf_conv2_bwd_data_x3(const float* dpool2, const float* pool2, const void* amax2, const float* W,
+                                  const float* pool1, float* dpool1, int B, hipStream_t st);
+DTF_API int dtf_conv1_fwd_f32_pack3(const float* images, const int* perm, const int* step_ptr, int spe, int B, const float* Wt,
+                                    const float* bias, float* out, void* amax, const float* Wc2, void* Wf3, void* Wb3,
+                                    hipStream_t st);
+
 // ---- "shard" data parallelism (shard_body.h): per-rank work independent of the number of ranks
 DTF_API int dtf_conv2_bwd_data_f32_push(const float* dpool2, const float* pool2, const void* amax2, const float* W,
                                         const float* pool1, float* dpool1, int B, const struct OptimParams* adam,

@@ -99,13 +99,24 @@ static constexpr int SHARD_RANKS_PER_SET = 2;
     if (_r != 0) return _r;   \
   } while (0)
 
+// fp32 path: conv2 forward / data gradient as bf16x6 (f32x3_conv2.hip) when the switch is on and the engine carries the
+// three-plane filter copies (wc2f / wc2b sized 3 x 102 400 B by engine/mnist_engine.py)
+static bool x3_convs(const MnistEngine* e) { return e->f32 && dtf_f32_emulation() && e->wc2f && e->wc2b; }
+
 static int forward_to_slabs(const MnistEngine* e, const float* images, const int* perm, const int* step, int n,
                             int splits, bool need_argmax, hipStream_t st, const ShardPush* push = nullptr) {
   if (e->f32) {
-    DTF_TRY(dtf_conv1_fwd_f32(images, perm, step, e->spe, n, e->P + e->off_Wc1, e->P + e->off_bc1, (float*)e->pool1,
-                              need_argmax ? e->amax1 : nullptr, st));
-    DTF_TRY(dtf_conv2_fwd_f32((const float*)e->pool1, e->P + e->off_Wc2, e->P + e->off_bc2, (float*)e->pool2,
-                              need_argmax ? e->amax2 : nullptr, n, st));
+    if (x3_convs(e)) {  // bf16x6: conv2's filter planes are rewritten by leading workgroups of the conv1 launch
+      DTF_TRY(dtf_conv1_fwd_f32_pack3(images, perm, step, e->spe, n, e->P + e->off_Wc1, e->P + e->off_bc1, (float*)e->pool1,
+                                      need_argmax ? e->amax1 : nullptr, e->P + e->off_Wc2, e->wc2f, e->wc2b, st));
+      DTF_TRY(dtf_conv2_fwd_x3_packed((const float*)e->pool1, e->wc2f, e->P + e->off_bc2, (float*)e->pool2,
+                                      need_argmax ? e->amax2 : nullptr, n, st));
+    } else {
+      DTF_TRY(dtf_conv1_fwd_f32(images, perm, step, e->spe, n, e->P + e->off_Wc1, e->P + e->off_bc1, (float*)e->pool1,
+                                need_argmax ? e->amax1 : nullptr, st));
+      DTF_TRY(dtf_conv2_fwd_f32((const float*)e->pool1, e->P + e->off_Wc2, e->P + e->off_bc2, (float*)e->pool2,
+                                need_argmax ? e->amax2 : nullptr, n, st));
+    }
     if (e->wshard) {
       float* w[16];
       DTF_TRY(dtf_ipc_wshard_bufs(e->shard_comm, 0, 3136L * 1024, w));
@@ -309,7 +320,10 @@ DTF_API int dtf_mnist_fwd_bwd(const MnistEngine* e_in, int parts, hipStream_t st
                                  e->G + e->off_Wfc1 + (long)e->shard_lo * 1024, e->shard_n > SHARD_RANKS_PER_SET, &push));
       fc1.Gsrc = dtf_ipc_landing(e->shard_comm);  // the assembled global gradient (the push below zeroes the slice in G)
     }
-    if (e->f32)
+    if (x3_convs(e) && rows_a <= 0 && !(shard && !wshard))  // (no hosted role: the planes written by this step's conv1 launch)
+      DTF_TRY(dtf_conv2_bwd_data_x3_packed(e->dpool2, (const float*)e->pool2, e->amax2, e->wc2b, (const float*)e->pool1,
+                                           e->dpool1, B, st));
+    else if (e->f32)
       DTF_TRY(dtf_conv2_bwd_data_f32_push(e->dpool2, (const float*)e->pool2, e->amax2, e->P + e->off_Wc2,
                                           (const float*)e->pool1, e->dpool1, B, rows_a > 0 ? &fc1a : nullptr,
                                           shard && !wshard ? &push : nullptr, st));

@@ -684,6 +684,7 @@ DTF_API int dtf_conv2_f32_init() {
 
 DTF_API int dtf_conv2_fwd_f32(const float* x, const float* W, const float* bias, float* out, void* amax, int B, hipStream_t st) {
   if (B <= 0) return ERR_SHAPE;
+  if (dtf_f32_emulation()) return dtf_conv2_fwd_x3(x, W, bias, out, amax, B, st);
   if (!g_f32_attr_set) {
     const int rc = dtf_conv2_f32_init();
     if (rc) return rc;
@@ -707,6 +708,8 @@ DTF_API int dtf_conv2_bwd_data_f32_push(const float* dpool2, const float* pool2,
   if (!wsh_fields_ok(adam)) return ERR_SHAPE;
   if (push && (push->n4 <= 0 || !push->src || push->world < 1 || push->world > 8 || push->rank < 0 || push->rank >= push->world))
     return ERR_SHAPE;
+  // (the bf16x6 kernel holds 122 KB of LDS: one workgroup per CU, no resident slots for hosted roles)
+  if (!adam && !push && dtf_f32_emulation()) return dtf_conv2_bwd_data_x3(dpool2, pool2, amax2, W, pool1, dpool1, B, st);
   if (!g_f32_attr_set) {
     const int rc = dtf_conv2_f32_init();
     if (rc) return rc;

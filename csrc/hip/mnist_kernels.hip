@@ -10,6 +10,7 @@
 #include "common.h"
 #include "conv1_dw_body.h"
 #include "conv2_pack.h"
+#include "conv2_pack3.h"
 #include "dtf_structs.h"
 
 namespace {
@@ -35,7 +36,8 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
   // weights for the kernels that follow; the rest are (image, channel group) pairs, channel group fastest.
   const int npack = (int)gridDim.x - 4 * B;
   if ((int)blockIdx.x < npack) {
-    conv2_pack_body(Wc2, Wc2f, Wc2b, blockIdx.x, npack);
+    if (F32OUT) conv2_pack3_body(Wc2, Wc2f, Wc2b, blockIdx.x, npack);  // (three bf16 planes for the bf16x6 conv2 kernels)
+    else conv2_pack_body(Wc2, Wc2f, Wc2b, blockIdx.x, npack);
     return;
   }
   const int b = ((int)blockIdx.x - npack) >> 2, cg = ((int)blockIdx.x - npack) & 3, tid = threadIdx.x;
@@ -145,6 +147,17 @@ DTF_API int dtf_conv1_fwd_f32(const float* images, const int* perm, const int* s
   if (B <= 0 || (perm && spe <= 0)) return ERR_SHAPE;
   hipLaunchKernelGGL(conv1_fwd_kernel<true>, dim3(4 * B), dim3(256), 0, st, images, perm, step_ptr, spe, B, Wt, bias,
                      (void*)out, (uint8_t*)amax, (const float*)nullptr, (char*)nullptr, (char*)nullptr);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
+
+// the same with the three-plane copies of conv2's filter (conv2_pack3.h) written by 25 leading workgroups
+DTF_API int dtf_conv1_fwd_f32_pack3(const float* images, const int* perm, const int* step_ptr, int spe, int B, const float* Wt,
+                                    const float* bias, float* out, void* amax, const float* Wc2, void* Wf3, void* Wb3,
+                                    hipStream_t st) {
+  if (B <= 0 || (perm && spe <= 0) || !Wc2 || !Wf3 || !Wb3) return ERR_SHAPE;
+  hipLaunchKernelGGL(conv1_fwd_kernel<true>, dim3(4 * B + 25), dim3(256), 0, st, images, perm, step_ptr, spe, B, Wt, bias,
+                     (void*)out, (uint8_t*)amax, Wc2, (char*)Wf3, (char*)Wb3);
   DTF_CHECK_LAUNCH();
   return 0;
 }

@@ -117,8 +117,10 @@ class NativeMnistEngine(_EngineBase):
             "dz": torch.zeros(batch_size * 16, **bf),
             "dpool2": torch.zeros(batch_size * 3136, **f32), "dy2": torch.zeros(batch_size * 196 * 64, **bf),
             "dpool1": torch.zeros(batch_size * 196 * 32, **f32),
-            # packed bf16 copies of the conv2 filter in the two LDS layouts (csrc/hip/conv2_pack.h)
-            "wc2f": torch.zeros(2 * 800 * 32, **bf), "wc2b": torch.zeros(800 * 64, **bf),
+            # packed bf16 copies of the conv2 filter: the two LDS layouts of the bf16 path (csrc/hip/conv2_pack.h), or the
+            # three bf16 planes per operand of the fp32 path's bf16x6 conv kernels (csrc/hip/conv2_pack3.h)
+            "wc2f": torch.zeros((3 if is_f32 else 1) * 800 * 64, dtype=torch.bfloat16, device=dev),
+            "wc2b": torch.zeros((3 if is_f32 else 1) * 800 * 64, dtype=torch.bfloat16, device=dev),
         }
         self.seed = int(seed if seed is not None else np.random.SeedSequence().entropy % (2 ** 62))
         self.spe = dataset.steps_per_epoch(batch_size) if dataset is not None else 1

@@ -170,6 +170,16 @@ def hip() -> C.CDLL:
         _sig(lib, "dtf_conv2_fwd_f32", I, [P, P, P, P, P, I, P])
         _sig(lib, "dtf_conv2_bwd_data_f32", I, [P, P, P, P, P, P, I, C.POINTER(OptimParams), P])
         _sig(lib, "dtf_conv_dw_duo_f32", I, [P, P, P, P, P, P, I, P, P, P, I, P, P, P, P, C.POINTER(OptimParams), P])
+        # fp32 on the bf16 matrix cores ("bf16x6": csrc/hip/bf16x3.h, f32x3_conv2.hip).  DTF_F32_EMULATION=0 -> exact-fp32 MFMA
+        _sig(lib, "dtf_f32_emulation_set", None, [I])
+        _sig(lib, "dtf_f32_emulation", I, [])
+        _sig(lib, "dtf_conv2_pack3", I, [P, P, P, P])
+        _sig(lib, "dtf_conv2_fwd_x3_packed", I, [P, P, P, P, P, I, P])
+        _sig(lib, "dtf_conv2_bwd_data_x3_packed", I, [P, P, P, P, P, P, I, P])
+        _sig(lib, "dtf_conv2_fwd_x3", I, [P, P, P, P, P, I, P])
+        _sig(lib, "dtf_conv2_bwd_data_x3", I, [P, P, P, P, P, P, I, P])
+        _sig(lib, "dtf_conv1_fwd_f32_pack3", I, [P, P, P, I, I, P, P, P, P, P, P, P, P])
+        lib.dtf_f32_emulation_set(0 if os.environ.get("DTF_F32_EMULATION", "1").lower() in ("0", "off", "false", "no") else 1)
         _sig(lib, "dtf_graph_begin", I, [P])
         _sig(lib, "dtf_graph_end", I, [P, C.POINTER(c_void_p)])
         _sig(lib, "dtf_graph_launch", I, [P, P])
@@ -201,6 +211,19 @@ def hip() -> C.CDLL:
                     mirror.__name__, C.sizeof(mirror), native_size))
         _hip = lib
         return lib
+
+
+def f32_emulation_note() -> Optional[str]:
+    """What the fp32 path runs on the bf16 matrix cores (``csrc/hip/bf16x3.h``), for bench records; None = nothing
+    (``DTF_F32_EMULATION=0``: every GEMM-shaped kernel on the exact-fp32 MFMA)."""
+    if not hip().dtf_f32_emulation():
+        return None
+    return ("bf16x6: " + ", ".join(F32_EMULATED_KERNELS) + " take each fp32 operand as three bf16 planes and each product as "
+            "six v_mfma_f32_16x16x32_bf16 (fp32 accumulate); same float64-oracle tolerances as the exact-fp32 MFMA kernels "
+            "(tests/test_f32_gpu.py, 1e-5 per kernel, 1e-4 step gradients); everything else is plain fp32")
+
+
+F32_EMULATED_KERNELS = ("conv2 forward", "conv2 data gradient")
 
 
 # signatures of optional kernels (Inception pools / image ops / stats / retrain head) registered by
