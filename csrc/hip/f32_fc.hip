@@ -1,7 +1,10 @@
 // C ABI launchers of the exact-fp32 dense GEMMs (f32_gemm.h): the fc layers of the MNIST CNN at the reference's precision
 // (demo1/train.py:94-120: tf.matmul on float32).  Same roles and the same horizontal fusion as the bf16 launchers in
 // gemm_api.hip; operands and results are fp32 everywhere.
+#include <type_traits>
 #include "f32_gemm.h"
+#include "f32x3_gemm.h"
+#include "dtf_api.h"
 #include "shard_body.h"
 
 namespace {
@@ -40,24 +43,63 @@ struct F32ColKSeg : F32ColK<R, NT, BK, IS_A> {
   const float* const* tab;
   const float* nxt;  // block pointer of the slab this register set loads next (fetched one load() early: a table read
   int seg, nxt_s;    // in front of a slab's loads would put its latency into every slab, +6.5 us on the launch)
+  int segp;          // places per block in the k index space (GemmParams::ksegp)
   __device__ __forceinline__ void init(const GemmParams& p, int r0_, int tid) {
     Base::init(p, r0_, tid);
     tab = reinterpret_cast<const float* const*>(IS_A ? p.A : p.B);
     seg = p.kseg;
+    segp = p.ksegp > 0 ? p.ksegp : p.kseg;
     nxt_s = -1;
     nxt = nullptr;
   }
   __device__ __forceinline__ void load(int k0_, int kend_, int tid) {
-    const int s = k0_ / seg;
+    const int s = k0_ / segp;
     this->src = s == nxt_s ? nxt : tab[s];
-    Base::load(k0_ - s * seg, seg, tid);
-    nxt_s = (k0_ + 2 * BK) / seg;  // (the two register sets of the body alternate slabs)
+    Base::load(k0_ - s * segp, seg, tid);
+    nxt_s = (k0_ + 2 * BK) / segp;  // (the two register sets of the body alternate slabs)
     if (k0_ + 2 * BK < kend_) nxt = tab[nxt_s];
     else nxt_s = -1;
   }
 };
 using DwAg = F32ColKSeg<128, 256, 20, true>;
 using DwBg = F32ColKSeg<64, 256, 20, false>;
+// bf16x6 forms of the filter-gradient roles (f32x3_gemm.h): k-steps of 32, the batch of 100 pads to 128 per operand block
+using DwA3 = F32ColK<128, 256, 32, true>;
+using DwB3 = F32ColK<64, 256, 32, false>;
+using DwBn3 = F32ColK<16, 256, 32, false>;
+using DwAg3 = F32ColKSeg<128, 256, 32, true>;
+using DwBg3 = F32ColKSeg<64, 256, 32, false>;
+
+// one role of a launch: the exact-fp32 body or its bf16x6 form (BK = the loaders' slab depth)
+template <bool X3, int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int KW = 1>
+__device__ __forceinline__ void gemm_role(const GemmParams& p, const int m0, const int n0, const int z, float* smem) {
+  if constexpr (X3) dtf_gemm32x3_body<BM, BN, BK, WM, WN, AL, BL, EP, KW>(p, m0, n0, z, reinterpret_cast<char*>(smem));
+  else dtf_gemm32_body<BM, BN, BK, WM, WN, AL, BL, EP, 2, KW>(p, m0, n0, z, smem);
+}
+template <bool X3, int BM, int BN, int BK, class AL, class BL>
+constexpr int role_lds_floats() {
+  if constexpr (X3) return dtf_gemm32x3_lds<BM, BN, BK, AL, BL>() / 4;
+  else return dtf_gemm32_lds<BM, BN, AL, BL>();
+}
+
+// the fc1 forward (112 x 64 tile, 8 waves) in both forms; SEL: W double-buffered by step parity; PUSH: a copy role in the z
+// planes behind the K splits (dtf_fc_fwd_f32_push)
+template <bool X3, bool SEL>
+__global__ __launch_bounds__(512) void fc_fwd32_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[role_lds_floats<X3, 112, 64, 32, FwdA, FwdB>()];
+  GemmParams q = p;
+  if constexpr (SEL) {
+    if (*p.bsel & 1) q.B = p.B_alt;  // (workgroup-uniform)
+  }
+  gemm_role<X3, 112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store, 2>(q, blockIdx.x * 112, blockIdx.y * 64, blockIdx.z, smem);
+}
+template <bool X3, bool SEL>
+int launch_fc_fwd32(const GemmParams& p, int splits, hipStream_t st) {
+  dim3 grid(dtf_cdiv(p.M, 112), dtf_cdiv(p.N, 64), splits);
+  hipLaunchKernelGGL((fc_fwd32_kernel<X3, SEL>), grid, dim3(512), 0, st, p);
+  DTF_CHECK_LAUNCH();
+  return 0;
+}
 }  // namespace
 
 // out[z][M][N] (fp32 slabs) = X[M][K] (fp32 row-major) * W[K][N] (fp32, TF [in,out] layout)
@@ -69,7 +111,7 @@ DTF_API int dtf_fc_fwd_f32(const float* X, const float* W, float* out, int M, in
   const int s = eff_splits32(p);
   p.bias = (s == 1) ? bias : nullptr;
   p.relu = (s == 1) ? relu : 0;
-  return dtf_launch_gemm32<112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store, 2, 2>(p, s, st);
+  return dtf_f32_emulation() ? launch_fc_fwd32<true, false>(p, s, st) : launch_fc_fwd32<false, false>(p, s, st);
 }
 
 // The same with W double-buffered by step parity ("wshard" schedule, engine.hip: MnistEngine::wshard): W1 is read when *sel is odd.
@@ -80,7 +122,8 @@ DTF_API int dtf_fc_fwd_f32_sel(const float* X, const float* W0, const float* W1,
   GemmParams p = base_params32(X, W0, out, M, N, K, K, N, N, splits, 32);
   p.bsel = sel;
   p.B_alt = W1;
-  return dtf_launch_gemm32_bsel<112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store, 2, 2>(p, eff_splits32(p), st);
+  return dtf_f32_emulation() ? launch_fc_fwd32<true, true>(p, eff_splits32(p), st)
+                             : launch_fc_fwd32<false, true>(p, eff_splits32(p), st);
 }
 
 // The fc1 forward with a copy role riding in spare workgroups ("ipc-gather2", ipc_allreduce.hip: dtf_ipc_push_desc): X (this
@@ -88,16 +131,15 @@ DTF_API int dtf_fc_fwd_f32_sel(const float* X, const float* W0, const float* W1,
 // operand exchange that follows the loss head only has dh left to move.  z planes [splits, splits + PUSH_PLANES) push.
 namespace {
 constexpr int PUSH_PLANES = 2;
-template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int PF, int KW>
-__global__ __launch_bounds__(64 * WM * WN * KW) void dtf_gemm32_push_kernel(const GemmParams p, const int splits, const ShardPush push) {
-  __shared__ __attribute__((aligned(16))) float smem[dtf_gemm32_lds<BM, BN, AL, BL>()];
+template <bool X3>
+__global__ __launch_bounds__(512) void fc_fwd32_push_kernel(const GemmParams p, const int splits, const ShardPush push) {
+  __shared__ __attribute__((aligned(16))) float smem[role_lds_floats<X3, 112, 64, 32, FwdA, FwdB>()];
   if ((int)blockIdx.z >= splits) {  // (workgroup-uniform)
     const int per = gridDim.x * gridDim.y;
-    shard_push_body(push, ((int)blockIdx.z - splits) * per + blockIdx.y * gridDim.x + blockIdx.x, PUSH_PLANES * per,
-                    64 * WM * WN * KW);
+    shard_push_body(push, ((int)blockIdx.z - splits) * per + blockIdx.y * gridDim.x + blockIdx.x, PUSH_PLANES * per, 512);
     return;
   }
-  dtf_gemm32_body<BM, BN, BK, WM, WN, AL, BL, EP, PF, KW>(p, blockIdx.x * BM, blockIdx.y * BN, blockIdx.z, smem);
+  gemm_role<X3, 112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store, 2>(p, blockIdx.x * 112, blockIdx.y * 64, blockIdx.z, smem);
 }
 }  // namespace
 
@@ -111,7 +153,8 @@ DTF_API int dtf_fc_fwd_f32_push(const float* X, const float* W, float* out, int 
   GemmParams p = base_params32(X, W, out, M, N, K, K, N, N, splits, 32);
   const int s = eff_splits32(p);
   dim3 grid(dtf_cdiv(p.M, 112), dtf_cdiv(p.N, 64), s + PUSH_PLANES);
-  hipLaunchKernelGGL((dtf_gemm32_push_kernel<112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store, 2, 2>), grid, dim3(512), 0, st, p, s, *push);
+  if (dtf_f32_emulation()) hipLaunchKernelGGL((fc_fwd32_push_kernel<true>), grid, dim3(512), 0, st, p, s, *push);
+  else hipLaunchKernelGGL((fc_fwd32_push_kernel<false>), grid, dim3(512), 0, st, p, s, *push);
   DTF_CHECK_LAUNCH();
   return 0;
 }
@@ -130,6 +173,10 @@ DTF_API int dtf_fc_bwd_data_f32(const float* dY, const float* W, float* dX, int 
   if (M <= 0 || N <= 0 || K <= 0 || K % 4 || splits < 1 || !aligned16(dY) || !aligned16(W)) return ERR_SHAPE;
   GemmParams p = base_params32(dY, W, dX, M, N, K, K, K, N, splits, 32);
   const int s = eff_splits32(p);
+  if (dtf_f32_emulation()) {
+    if (s == 1) return dtf_launch_gemm32x3<112, 64, 32, 1, 4, BdA, BdB, Ep32Store>(p, 1, st);
+    return dtf_launch_gemm32x3<112, 64, 32, 1, 4, BdA, BdB, Ep32Atomic>(p, s, st);
+  }
   if (s == 1) return dtf_launch_gemm32<112, 64, 32, 1, 4, BdA, BdB, Ep32Store>(p, 1, st);
   return dtf_launch_gemm32<112, 64, 32, 1, 4, BdA, BdB, Ep32Atomic>(p, s, st);
 }
@@ -141,6 +188,16 @@ DTF_API int dtf_fc_dw_f32(const float* X, int ldx, const float* dY, int ldy, flo
                           hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0 || ldx % 4 || ldy % 4 || ldx < M || ldy < N || splits < 1 || !aligned16(X) || !aligned16(dY))
     return ERR_SHAPE;
+  if (dtf_f32_emulation()) {
+    GemmParams p = base_params32(X, dY, dW, M, N, K, ldx, ldy, N, splits, 32);
+    const int s = eff_splits32(p);
+    if (N <= 16) {
+      if (s == 1) return dtf_launch_gemm32x3<128, 16, 32, 4, 1, DwA3, DwBn3, Ep32Store>(p, 1, st);
+      return dtf_launch_gemm32x3<128, 16, 32, 4, 1, DwA3, DwBn3, Ep32Atomic>(p, s, st);
+    }
+    if (s == 1) return dtf_launch_gemm32x3<128, 64, 32, 4, 1, DwA3, DwB3, Ep32Store>(p, 1, st);
+    return dtf_launch_gemm32x3<128, 64, 32, 4, 1, DwA3, DwB3, Ep32Atomic>(p, s, st);
+  }
   GemmParams p = base_params32(X, dY, dW, M, N, K, ldx, ldy, N, splits, 20);
   const int s = eff_splits32(p);
   if (N <= 16) {
@@ -164,17 +221,28 @@ struct GemmTrio32 {
   const float* gB[8];
   int ksets;  // shard modes: K sets of problem 0 (see the kernel)
 };
-constexpr int TRIO32_LDS = dtf_gemm32_lds<112, 64, BdA, BdB>() > dtf_gemm32_lds<128, 64, DwA, DwB>()
-                               ? dtf_gemm32_lds<112, 64, BdA, BdB>() : dtf_gemm32_lds<128, 64, DwA, DwB>();
+template <bool X3>
+constexpr int trio32_lds() {
+  return role_lds_floats<X3, 112, 64, 32, BdA, BdB>() > role_lds_floats<X3, 128, 64, X3 ? 32 : 20, DwA, DwB>()
+             ? role_lds_floats<X3, 112, 64, 32, BdA, BdB>() : role_lds_floats<X3, 128, 64, X3 ? 32 : 20, DwA, DwB>();
+}
 
 // (the mode is a template parameter for the reason given at fc_bwd_trio_kernel in gemm_api.hip)
 // MODE 0: this rank's operands; 1 ("gather"): K runs over all ranks' operand pairs; 2 / 3 ("shard"): problem 0 is this
 // rank's row slice of the global gradient -- per-rank MFMA work independent of the number of ranks (shard_body.h).  3: one
 // K set, plain stores; 2: several K sets of ranks_per_set source ranks each (enough workgroups to fill the chip at 8 ranks),
 // accumulated with atomics into a pre-zeroed slice.
-template <int MODE>
+// X3: every role as bf16x6 (f32x3_gemm.h); the filter-gradient roles then walk K = batch in slabs of 32 (operand blocks
+// padded to 128 places, GemmParams::ksegp).
+template <int MODE, bool X3>
 __global__ __launch_bounds__(256, 3) void fc_bwd_trio_f32_kernel(const GemmTrio32 g) {
-  __shared__ __attribute__((aligned(16))) float smem[TRIO32_LDS];
+  __shared__ __attribute__((aligned(16))) float smem[trio32_lds<X3>()];
+  constexpr int DBK = X3 ? 32 : 20;
+  using TA = std::conditional_t<X3, DwA3, DwA>;
+  using TB = std::conditional_t<X3, DwB3, DwB>;
+  using TBn = std::conditional_t<X3, DwBn3, DwBn>;
+  using TAg = std::conditional_t<X3, DwAg3, DwAg>;
+  using TBg = std::conditional_t<X3, DwBg3, DwBg>;
   const int id = blockIdx.x;
   if (id < g.nblk_q) {
     const int mt = id % g.q_mt, r = id / g.q_mt;
@@ -182,11 +250,11 @@ __global__ __launch_bounds__(256, 3) void fc_bwd_trio_f32_kernel(const GemmTrio3
       if (g.q.bsel) {  // "wshard": W_fc1 double-buffered by step parity (workgroup-uniform choice)
         GemmParams q = g.q;
         if (*g.q.bsel & 1) q.B = g.q.B_alt;
-        dtf_gemm32_body<112, 64, 32, 1, 4, BdA, BdB, Ep32Atomic>(q, mt * 112, (r % g.q_nt) * 64, r / g.q_nt, smem);
+        gemm_role<X3, 112, 64, 32, 1, 4, BdA, BdB, Ep32Atomic>(q, mt * 112, (r % g.q_nt) * 64, r / g.q_nt, smem);
         return;
       }
     }
-    dtf_gemm32_body<112, 64, 32, 1, 4, BdA, BdB, Ep32Atomic>(g.q, mt * 112, (r % g.q_nt) * 64, r / g.q_nt, smem);
+    gemm_role<X3, 112, 64, 32, 1, 4, BdA, BdB, Ep32Atomic>(g.q, mt * 112, (r % g.q_nt) * 64, r / g.q_nt, smem);
   } else if (id < g.nblk_q + g.nblk0) {
     const int k = id - g.nblk_q;
     if constexpr (MODE == 2 || MODE == 3) {
@@ -196,20 +264,28 @@ __global__ __launch_bounds__(256, 3) void fc_bwd_trio_f32_kernel(const GemmTrio3
       d.A = g.gA;
       d.B = g.gB;
       if constexpr (MODE == 2)
-        dtf_gemm32_body<128, 64, 20, 4, 1, DwAg, DwBg, Ep32Atomic>(d, (kk % g.mt0) * 128, (kk / g.mt0) * 64, z, smem);
+        gemm_role<X3, 128, 64, DBK, 4, 1, TAg, TBg, Ep32Atomic>(d, (kk % g.mt0) * 128, (kk / g.mt0) * 64, z, smem);
       else
-        dtf_gemm32_body<128, 64, 20, 4, 1, DwAg, DwBg, Ep32Store>(d, (kk % g.mt0) * 128, (kk / g.mt0) * 64, 0, smem);
+        gemm_role<X3, 128, 64, DBK, 4, 1, TAg, TBg, Ep32Store>(d, (kk % g.mt0) * 128, (kk / g.mt0) * 64, 0, smem);
     } else if constexpr (MODE == 1) {
       GemmParams d = g.d0;
       d.A = g.gA;
       d.B = g.gB;
-      dtf_gemm32_body<128, 64, 20, 4, 1, DwAg, DwBg, Ep32Store>(d, (k % g.mt0) * 128, (k / g.mt0) * 64, 0, smem);
+      gemm_role<X3, 128, 64, DBK, 4, 1, TAg, TBg, Ep32Store>(d, (k % g.mt0) * 128, (k / g.mt0) * 64, 0, smem);
     } else
-      dtf_gemm32_body<128, 64, 20, 4, 1, DwA, DwB, Ep32Store>(g.d0, (k % g.mt0) * 128, (k / g.mt0) * 64, 0, smem);
+      gemm_role<X3, 128, 64, DBK, 4, 1, TA, TB, Ep32Store>(g.d0, (k % g.mt0) * 128, (k / g.mt0) * 64, 0, smem);
   } else {
     const int k = id - g.nblk_q - g.nblk0;
-    dtf_gemm32_body<128, 16, 20, 4, 1, DwA, DwBn, Ep32Store>(g.d1, (k % g.mt1) * 128, (k / g.mt1) * 16, 0, smem);
+    gemm_role<X3, 128, 16, DBK, 4, 1, TA, TBn, Ep32Store>(g.d1, (k % g.mt1) * 128, (k / g.mt1) * 16, 0, smem);
   }
+}
+
+template <int MODE>
+int launch_trio32(const GemmTrio32& g, int nblocks, hipStream_t st) {
+  if (dtf_f32_emulation()) hipLaunchKernelGGL((fc_bwd_trio_f32_kernel<MODE, true>), dim3(nblocks), dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((fc_bwd_trio_f32_kernel<MODE, false>), dim3(nblocks), dim3(256), 0, st, g);
+  DTF_CHECK_LAUNCH();
+  return 0;
 }
 }  // namespace
 
@@ -238,9 +314,12 @@ DTF_API int dtf_fc_bwd_trio_f32(const float* X0, const float* dY0, float* dW0, i
     g.gB[r] = r < granks ? static_cast<const float*>(gB[r]) : nullptr;
     if (r < granks && (!g.gA[r] || !g.gB[r] || !aligned16(g.gA[r]) || !aligned16(g.gB[r]))) return ERR_SHAPE;
   }
-  g.d0 = base_params32(X0, dY0, dW0, M0, N0, granks > 0 ? granks * K : K, M0, N0, N0, 1, 20);
+  const bool x3 = dtf_f32_emulation() != 0;
+  const int dbk = x3 ? 32 : 20, Kp = x3 ? dtf_cdiv(K, 32) * 32 : K;  // (bf16x6: operand blocks of Kp places, rows >= K zero)
+  g.d0 = base_params32(X0, dY0, dW0, M0, N0, granks > 0 ? granks * Kp : K, M0, N0, N0, 1, dbk);
   g.d0.kseg = granks > 0 ? K : 0;
-  g.d1 = base_params32(X1, dY1, dW1, M1, N1, K, M1, ldy1, N1, 1, 20);
+  g.d0.ksegp = granks > 0 ? Kp : 0;
+  g.d1 = base_params32(X1, dY1, dW1, M1, N1, K, M1, ldy1, N1, 1, dbk);
   g.mt0 = dtf_cdiv(M0, 128);
   g.mt1 = dtf_cdiv(M1, 128);
   g.nblk0 = g.mt0 * dtf_cdiv(N0, 64);
@@ -254,12 +333,7 @@ DTF_API int dtf_fc_bwd_trio_f32(const float* X0, const float* dY0, float* dW0, i
 #ifdef DTF_GEMM32_STAMPS
   g.q.aux_out = g.d0.aux_out = g.d1.aux_out = g_trio_stamps;
 #endif
-  if (granks > 0)
-    hipLaunchKernelGGL(fc_bwd_trio_f32_kernel<1>, dim3(g.nblk_q + g.nblk0 + nblk1), dim3(256), 0, st, g);
-  else
-    hipLaunchKernelGGL(fc_bwd_trio_f32_kernel<0>, dim3(g.nblk_q + g.nblk0 + nblk1), dim3(256), 0, st, g);
-  DTF_CHECK_LAUNCH();
-  return 0;
+  return granks > 0 ? launch_trio32<1>(g, g.nblk_q + g.nblk0 + nblk1, st) : launch_trio32<0>(g, g.nblk_q + g.nblk0 + nblk1, st);
 }
 
 // The same launch for the "shard" data-parallel schedule (shard_body.h):
@@ -287,10 +361,13 @@ DTF_API int dtf_fc_bwd_trio_f32_shard(const float* X1, const float* dY1, int ldy
     g.gB[r] = r < granks ? static_cast<const float*>(gB[r]) : nullptr;
     if (r < granks && (!g.gA[r] || !g.gB[r] || !aligned16(g.gA[r]) || !aligned16(g.gB[r]))) return ERR_SHAPE;
   }
-  g.d0 = base_params32(nullptr, nullptr, dW0_slice, M0_slice, N0, granks * K, lda0, N0, N0, 1, 20);
+  const bool x3 = dtf_f32_emulation() != 0;
+  const int dbk = x3 ? 32 : 20, Kp = x3 ? dtf_cdiv(K, 32) * 32 : K;  // (bf16x6: operand blocks of Kp places, rows >= K zero)
+  g.d0 = base_params32(nullptr, nullptr, dW0_slice, M0_slice, N0, granks * Kp, lda0, N0, N0, 1, dbk);
   g.d0.kseg = K;
-  g.d0.kchunk = ranks_per_set * K;  // (a multiple of the slab depth: K % 20 == 0)
-  g.d1 = base_params32(X1, dY1, dW1, M1, N1, K, M1, ldy1, N1, 1, 20);
+  g.d0.ksegp = Kp;
+  g.d0.kchunk = ranks_per_set * Kp;  // (a multiple of the slab depth)
+  g.d1 = base_params32(X1, dY1, dW1, M1, N1, K, M1, ldy1, N1, 1, dbk);
   g.mt0 = dtf_cdiv(M0_slice, 128);
   g.mt1 = dtf_cdiv(M1, 128);
   g.nblk0 = g.mt0 * dtf_cdiv(N0, 64) * g.ksets;
@@ -306,10 +383,5 @@ DTF_API int dtf_fc_bwd_trio_f32_shard(const float* X1, const float* dY1, int ldy
 #ifdef DTF_GEMM32_STAMPS
   g.q.aux_out = g.d0.aux_out = g.d1.aux_out = g_trio_stamps;
 #endif
-  if (g.ksets > 1)
-    hipLaunchKernelGGL(fc_bwd_trio_f32_kernel<2>, dim3(g.nblk_q + g.nblk0 + nblk1), dim3(256), 0, st, g);
-  else
-    hipLaunchKernelGGL(fc_bwd_trio_f32_kernel<3>, dim3(g.nblk_q + g.nblk0 + nblk1), dim3(256), 0, st, g);
-  DTF_CHECK_LAUNCH();
-  return 0;
+  return g.ksets > 1 ? launch_trio32<2>(g, g.nblk_q + g.nblk0 + nblk1, st) : launch_trio32<3>(g, g.nblk_q + g.nblk0 + nblk1, st);
 }

@@ -47,6 +47,8 @@ struct GemmParams {
   ConvGeom g;
   int accumulate;  // epilogues that support it add to the existing output instead of overwriting
   int kseg;        // segmented-K loaders (f32_fc.hip): A / B are tables of operand blocks of kseg k-rows each; 0 = plain
+  int ksegp;       // > 0: the k index space gives every block ksegp >= kseg places (kseg padded to the slab depth; the rows
+                   // past kseg read as zero), so a slab never straddles two blocks; 0 = kseg
   // double-buffered B operand (the "wshard" data-parallel schedule keeps W_fc1 in two buffers that alternate by step parity,
   // engine.hip: MnistEngine::wshard): kernels that honour it read B_alt instead of B when *bsel is odd; null = plain
   const int* bsel;
