@@ -350,7 +350,11 @@ def test_fp32_trajectory_matches_eager_fp32_on_real_digits(assets_dir):
     ln, le = np.concatenate(ln), np.concatenate(le)
     _l, acc_n = nat.evaluate(xt, yt)
     _l, acc_e = eag.evaluate(xt, yt)
-    assert np.abs(ln[:100] - le[:100]).max() < 1e-3, np.abs(ln[:100] - le[:100]).max()
+    # Before the run-to-run noise sets in the curves agree to rounding (measured 2e-6 over 30 steps); from there two runs of
+    # the SAME binary part in discrete events (atomics reorder, a ReLU / max-pool tie falls the other way: 4e-4 .. 2e-3 by
+    # step 100, profiles/r3/x3_error_and_noise.txt), so the 100-step bound is that floor, not a precision statement.
+    assert np.abs(ln[:30] - le[:30]).max() < 1e-4, np.abs(ln[:30] - le[:30]).max()
+    assert np.abs(ln[:100] - le[:100]).max() < 1e-2, np.abs(ln[:100] - le[:100]).max()
     assert abs(ln[-200:].mean() - le[-200:].mean()) < 0.01
     assert acc_n > 0.93 and acc_e > 0.93, (acc_n, acc_e)
     assert abs(acc_n - acc_e) <= 0.003 + 1e-9, (acc_n, acc_e)
