@@ -92,10 +92,6 @@ DTF_API int dtf_conv2_bwd_data_x3_packed(const float* dpool2, const float* pool2
 DTF_API int dtf_conv2_fwd_x3(const float* x, const float* W, const float* bias, float* out, void* amax, int B, hipStream_t st);
 DTF_API int dtf_conv2_bwd_data_x3(const float* dpool2, const float* pool2, const void* amax2, const float* W,
                                   const float* pool1, float* dpool1, int B, hipStream_t st);
-DTF_API int dtf_conv_dw_duo_x3(const float* dpool2, const float* pool2, const void* amax2, const float* pool1, float* dW2,
-                               float* db2, int B, const float* images, const int* perm, const int* step_ptr, int spe,
-                               const float* dpool1, const void* amax1, float* dW1, float* db1, const struct OptimParams* adam,
-                               hipStream_t st);
 DTF_API int dtf_conv1_fwd_f32_pack3(const float* images, const int* perm, const int* step_ptr, int spe, int B, const float* Wt,
                                     const float* bias, float* out, void* amax, const float* Wc2, void* Wf3, void* Wb3,
                                     hipStream_t st);

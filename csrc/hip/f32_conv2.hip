@@ -750,9 +750,6 @@ DTF_API int dtf_conv_dw_duo_f32(const float* dpool2, const float* pool2, const v
   if (B <= 0 || (perm && spe <= 0)) return ERR_SHAPE;
   if (adam && (adam->n <= 0 || adam->n % 4 || adam->zero_from % 4 || !adam->step)) return ERR_SHAPE;
   if (!wsh_fields_ok(adam)) return ERR_SHAPE;
-  if (dtf_f32_emulation())
-    return dtf_conv_dw_duo_x3(dpool2, pool2, amax2, pool1, dW2, db2, B, images, perm, step_ptr, spe, dpool1, amax1, dW1, db1,
-                              adam, st);
   if (!g_f32_attr_set) {
     const int rc = dtf_conv2_f32_init();
     if (rc) return rc;

@@ -71,9 +71,9 @@ using DwAg3 = F32ColKSeg<128, 256, 32, true>;
 using DwBg3 = F32ColKSeg<64, 256, 32, false>;
 
 // one role of a launch: the exact-fp32 body or its bf16x6 form (BK = the loaders' slab depth)
-template <bool X3, int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int KW = 1>
+template <bool X3, int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int KW = 1, int NSET = 2>
 __device__ __forceinline__ void gemm_role(const GemmParams& p, const int m0, const int n0, const int z, float* smem) {
-  if constexpr (X3) dtf_gemm32x3_body<BM, BN, BK, WM, WN, AL, BL, EP, KW>(p, m0, n0, z, reinterpret_cast<char*>(smem));
+  if constexpr (X3) dtf_gemm32x3_body<BM, BN, BK, WM, WN, AL, BL, EP, KW, NSET>(p, m0, n0, z, reinterpret_cast<char*>(smem));
   else dtf_gemm32_body<BM, BN, BK, WM, WN, AL, BL, EP, 2, KW>(p, m0, n0, z, smem);
 }
 template <bool X3, int BM, int BN, int BK, class AL, class BL>
@@ -81,6 +81,11 @@ constexpr int role_lds_floats() {
   if constexpr (X3) return dtf_gemm32x3_lds<BM, BN, BK, AL, BL>() / 4;
   else return dtf_gemm32_lds<BM, BN, AL, BL>();
 }
+
+// bf16x6 fc1 forward: register sets of staged slabs.  Measured: 7 sets (a workgroup's whole K chunk, 3136 / 14 splits = 7
+// slabs of 32, requested before the first slab is multiplied) 13.0 -> 15.6 us: the launch is bound by the 35 MB its 224
+// workgroups draw through L2 (X is re-read by all 16 column tiles), not by the latency of a slab.
+constexpr int FWD_NSET = 2;
 
 // the fc1 forward (112 x 64 tile, 8 waves) in both forms; SEL: W double-buffered by step parity; PUSH: a copy role in the z
 // planes behind the K splits (dtf_fc_fwd_f32_push)
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(512) void fc_fwd32_kernel(const GemmParams p) {
   if constexpr (SEL) {
     if (*p.bsel & 1) q.B = p.B_alt;  // (workgroup-uniform)
   }
-  gemm_role<X3, 112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store, 2>(q, blockIdx.x * 112, blockIdx.y * 64, blockIdx.z, smem);
+  gemm_role<X3, 112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store, 2, FWD_NSET>(q, blockIdx.x * 112, blockIdx.y * 64, blockIdx.z, smem);
 }
 template <bool X3, bool SEL>
 int launch_fc_fwd32(const GemmParams& p, int splits, hipStream_t st) {
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(512) void fc_fwd32_push_kernel(const GemmParams p, 
     shard_push_body(push, ((int)blockIdx.z - splits) * per + blockIdx.y * gridDim.x + blockIdx.x, PUSH_PLANES * per, 512);
     return;
   }
-  gemm_role<X3, 112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store, 2>(p, blockIdx.x * 112, blockIdx.y * 64, blockIdx.z, smem);
+  gemm_role<X3, 112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store, 2, FWD_NSET>(p, blockIdx.x * 112, blockIdx.y * 64, blockIdx.z, smem);
 }
 }  // namespace
 

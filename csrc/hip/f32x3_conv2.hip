@@ -15,8 +15,6 @@
 #include "common.h"
 #include "bf16x3.h"
 #include "conv2_pack3.h"
-#include "conv1_dw_body.h"
-#include "adam_body.h"
 #include "dtf_api.h"
 
 namespace {
@@ -250,13 +248,27 @@ __global__ __launch_bounds__(512) void conv2_bwd_data_x3_kernel(const float* __r
     tp[i] = *reinterpret_cast<const f32x4*>(pool2 + off);
     tav[i] = *reinterpret_cast<const uint32_t*>(amax2 + off);
   }
+  // Zeros only where the un-pool tasks below do not write (they cover every in-image pixel of the staged rows): the two
+  // halo columns on either side of every staged row, and the staged rows outside the image.  Disjoint from the tasks'
+  // addresses, so no barrier in between.
   {
-    const int n16 = (nrow0 + nrow1) * (D3_ROW / 16);
-    for (int c = tid; c < n16; c += 512)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(smem3 + p * D3_PLANE + c * 16) = make_uint4(0, 0, 0, 0);
+    const int nrow = nrow0 + nrow1;
+    for (int c = tid; c < nrow * 96; c += 512) {  // (row, plane, halo column 0 1 16 17, 16-byte chunk 0..7)
+      const int row = c / 96, rem = c - row * 96, p = rem >> 5, hc = (rem >> 3) & 3;
+      *reinterpret_cast<uint4*>(smem3 + p * D3_PLANE + row * D3_ROW + (hc + (hc >> 1) * 14) * D3_PIX + (rem & 7) * 16) =
+          make_uint4(0, 0, 0, 0);
+    }
+    // staged row -> halo row: slot 0 rows [0, nrow0) are halo rows ylo0 .., slot 1 rows are halo rows 0 ..; in-image = 2..15
+    for (int row = 0; row < nrow; ++row) {
+      const int hy = row < nrow0 ? ylo0 + row : row - nrow0;
+      if (hy >= 2 && hy <= 15) continue;  // (workgroup-uniform)
+      for (int c = tid; c < 3 * 14 * 8; c += 512) {
+        const int p = c / 112, rem = c - p * 112;
+        *reinterpret_cast<uint4*>(smem3 + p * D3_PLANE + row * D3_ROW + (2 + (rem >> 3)) * D3_PIX + (rem & 7) * 16) =
+            make_uint4(0, 0, 0, 0);
+      }
+    }
   }
-  __syncthreads();
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int task = tid + 512 * i;
@@ -367,244 +379,10 @@ __global__ __launch_bounds__(512) void conv2_bwd_data_x3_kernel(const float* __r
   }
 }
 
-// ------------------------------------------------------------------ filter gradient (+ bias gradient)
-// dW[tap][cin][cout] = sum over images and positions of X_halo[pos + tap][cin] * dY[pos][cout]: K runs over positions.
-//  * The k index is the pixel index of an 18-wide, 14-row grid (dY is zero in columns 14..17 and behind row 13): the A
-//    operand of tap (dy, dx) is then the staged image shifted by dx pixels, whatever the position -- no per-lane offset
-//    tables; 8 k-steps of 32 per image for 196 positions.  X is staged as it comes (pixel-major, three planes) and read with
-//    the transposing LDS load.
-//  * dY never exists un-pooled: LDS holds, per pooling window and output channel, the three planes of the masked pooled
-//    gradient and the argmax (8 bytes; 72 windows of an 8 x 9 window grid whose last row / two last columns are zero).  A
-//    lane's B fragment is 8 consecutive grid positions of its channel = four windows x the two positions of one window row:
-//    one ds_read_b64 per window, and a dword of the fragment is the window's plane value in the low or the high half, or
-//    zero, by the argmax.  18 KB instead of the 98 KB of three un-pooled plane images.
-// One workgroup = (4 images, half of the output channels, filter row dy) like the exact-fp32 kernel: 250 workgroups at batch
-// 100; 8 waves = (k group kq, input-channel tile mt, output-channel tile nt), accumulators [dx]; four k-steps per image and
-// wave (20 accumulator registers and one B tile per wave keep the launch at 128 VGPRs).  68 KB of LDS: two workgroups of the
-// launch fit on a CU, so the optimizer workgroups of the fused launch are resident from the start.
-namespace {
-constexpr int DW3_IPW = 4;
-constexpr int DW3_XPIX = 64, DW3_XN = 264;     // X plane: 14 staged rows x 18 pixels (+ 12: the largest shifted read) x 32 cin
-constexpr int DW3_XPLANE = DW3_XN * DW3_XPIX;  // 16 896 B
-constexpr int DW3_PW = 72 * 32 * 8;            // pooled dY of one channel half: [window 8 x 9][cout 32] x 8 B = 18 432 B
-constexpr int DW3_IMG = 3 * DW3_XPLANE + DW3_PW;        // 69 120 B
-constexpr int DW3_RED = 8 * 5 * 256 * 4;                // [wave][dx][lane][4] floats: 40 960 B
-constexpr int DW3_LDS = DW3_IMG + 128;                  // (the bias-gradient scratch sits behind the images)
-static_assert(DW3_RED <= DW3_IMG, "LDS carve-up");
-
-typedef short s16x4_x3 __attribute__((ext_vector_type(4)));
-typedef short s16x8_x3 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4_x3 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 tr8_x3(const char* p, const int pitch) {
-  const s16x4_x3 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_x3*)(p));
-  const s16x4_x3 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_x3*)(p + 4 * pitch));
-  const s16x8_x3 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, v8);
-}
-
-// id -> (image quad id / 10, output-channel half (id / 5) & 1, filter row id % 5); 512 threads
-__device__ __forceinline__ void conv2_dw_x3_body(char* __restrict__ smem, const int id, const float* __restrict__ pool1,
-                                                 const float* __restrict__ dpool2, const float* __restrict__ pool2,
-                                                 const uint8_t* __restrict__ amax2, float* __restrict__ dW,
-                                                 float* __restrict__ db2, const int B) {
-  char* xl = smem;
-  char* pw = smem + 3 * DW3_XPLANE;
-  float* bsum = reinterpret_cast<float*>(smem + DW3_IMG);
-  const int dy = id % 5, c = (id / 5) & 1, g = id / 10;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int kq = wave & 1, mt = (wave >> 1) & 1, nt = wave >> 2;
-  const int b0 = DW3_IPW * g;
-  const int nimg = min(DW3_IPW, B - b0);
-  const bool bias_role = db2 && dy == 0;
-
-  // zero both images once: the interiors are rewritten per image, halo pixels / padding windows stay zero
-  for (int i = tid; i < DW3_IMG / 16; i += 512) *reinterpret_cast<uint4*>(smem + i * 16) = make_uint4(0, 0, 0, 0);
-  if (tid < 32) bsum[tid] = 0.f;
-
-  // X: staged row sy (0..13) = image row sy + dy - 2; chunk = (sy, x 0..13, 4-channel part 0..7): 1568 chunks
-  f32x4 xv[4];
-  f32x4 tg, tp;
-  uint32_t tav;
-  // pooled-gradient task (threads < 392): window tid >> 3, 4-channel group tid & 7 of this half
-  const int twin = tid < 392 ? tid >> 3 : 0, tcg = tid & 7;
-  // (32-bit element offsets from the image's uniform base: 64-bit per-thread addresses held across the image loop spill)
-  int xoff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ch = tid + 512 * i;
-    const int pix = ch >> 3, sy = pix / 14, xx = pix - sy * 14;
-    const int y = sy + dy - 2;
-    xoff[i] = ch < 1568 && (unsigned)y < 14u ? (y * 14 + xx) * 32 + (ch & 7) * 4 : -1;
-  }
-  const int toff = twin * 64 + c * 32 + tcg * 4;
-  auto load = [&](const int b) {
-    const float* xb = pool1 + (long)b * 6272;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      xv[i] = *reinterpret_cast<const f32x4*>(xb + (xoff[i] >= 0 ? xoff[i] : 0));
-      if (xoff[i] < 0) xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    tg = *reinterpret_cast<const f32x4*>(dpool2 + (long)b * 3136 + toff);
-    tp = *reinterpret_cast<const f32x4*>(pool2 + (long)b * 3136 + toff);
-    tav = *reinterpret_cast<const uint32_t*>(amax2 + (long)b * 3136 + toff);
-  };
-  f32x4 gsum = {0.f, 0.f, 0.f, 0.f};
-  auto store = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ch = tid + 512 * i;
-      const int pix = ch >> 3, sy = pix / 14, xx = pix - sy * 14;
-      // (rows outside the image: their chunks were loaded as zeros)
-      if (ch < 1568) store_planes8(xl + (sy * 18 + xx + 2) * DW3_XPIX + (ch & 7) * 8, DW3_XPLANE, bf3_split4(xv[i]));
-    }
-    if (tid < 392) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) tg[j] = tp[j] > 0.f ? tg[j] : 0.f;
-      const Bf3Quad s = bf3_split4(tg);
-      const int py = twin / 7, px = twin - py * 7;
-      // entry j: [g0 | g1 << 16, g2 | argmax << 16]
-      const uint32_t p0[4] = {s.p0.x & 0xffffu, s.p0.x >> 16, s.p0.y & 0xffffu, s.p0.y >> 16};
-      const uint32_t p1[4] = {s.p1.x & 0xffffu, s.p1.x >> 16, s.p1.y & 0xffffu, s.p1.y >> 16};
-      const uint32_t p2[4] = {s.p2.x & 0xffffu, s.p2.x >> 16, s.p2.y & 0xffffu, s.p2.y >> 16};
-      u32x4_x3 e0, e1;
-      e0[0] = p0[0] | (p1[0] << 16); e0[1] = p2[0] | (((tav >> 0) & 0xffu) << 16);
-      e0[2] = p0[1] | (p1[1] << 16); e0[3] = p2[1] | (((tav >> 8) & 0xffu) << 16);
-      e1[0] = p0[2] | (p1[2] << 16); e1[1] = p2[2] | (((tav >> 16) & 0xffu) << 16);
-      e1[2] = p0[3] | (p1[3] << 16); e1[3] = p2[3] | (((tav >> 24) & 0xffu) << 16);
-      char* dst = pw + ((py * 9 + px) * 32 + tcg * 4) * 8;
-      *reinterpret_cast<u32x4_x3*>(dst) = e0;
-      *reinterpret_cast<u32x4_x3*>(dst + 16) = e1;
-      if (bias_role) { gsum[0] += tg[0]; gsum[1] += tg[1]; gsum[2] += tg[2]; gsum[3] += tg[3]; }
-    }
-  };
-
-  f32x4 acc[5];
-#pragma unroll
-  for (int dx = 0; dx < 5; ++dx) acc[dx] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // lane part of the transposing reads of X: k-row 8 q + (r >> 2) of the step, columns 4 (r & 3) .. + 3 of the cin tile
-  const char* xa = xl + (8 * q + (r >> 2)) * DW3_XPIX + (mt * 16 + 4 * (r & 3)) * 2;
-  // the lane's four windows of each of its k-steps (grid positions 32 s + 8 q + 2 j, s = kq + 2 h): LDS offset of the entry
-  // of its cout (16 bits each, two per register), and the parity of the grid row (one bit each)
-  uint32_t woff[4][2], wpar = 0;
-#pragma unroll
-  for (int h = 0; h < 4; ++h)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int pos = 32 * (kq + 2 * h) + 8 * q + 2 * j;
-      const int y = pos / 18, xx = pos - y * 18;
-      const uint32_t o = (((y >> 1) * 9 + (xx >> 1)) * 32 + nt * 16 + r) * 8;
-      if (j & 1) woff[h][j >> 1] |= o << 16; else woff[h][j >> 1] = o;
-      wpar |= (uint32_t)(y & 1) << (4 * h + j);
-    }
-
-  if (nimg > 0) load(b0);
-  for (int im = 0; im < nimg; ++im) {
-    __syncthreads();  // the previous image has been consumed (first pass: the zero fill is done)
-    store();
-    __syncthreads();
-    if (im + 1 < nimg) load(b0 + im + 1);
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      const int s = kq + 2 * h;  // k-step: grid positions 32 s .. 32 s + 31
-      // the B fragment of this wave's cout tile, built from the pooled entries
-      uint2 ent[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) ent[j] = *reinterpret_cast<const uint2*>(pw + ((woff[h][j >> 1] >> (16 * (j & 1))) & 0xffffu));
-      u32x4_x3 f0, f1, f2;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t m = (ent[j].y >> 16) - 2u * ((wpar >> (4 * h + j)) & 1u);  // 0: first position, 1: second, else none
-        const uint32_t g0 = ent[j].x & 0xffffu, g1 = ent[j].x >> 16, g2 = ent[j].y & 0xffffu;
-        f0[j] = m == 0u ? g0 : (m == 1u ? g0 << 16 : 0u);
-        f1[j] = m == 0u ? g1 : (m == 1u ? g1 << 16 : 0u);
-        f2[j] = m == 0u ? g2 : (m == 1u ? g2 << 16 : 0u);
-      }
-      const bf16x8 bfr[3] = {__builtin_bit_cast(bf16x8, f0), __builtin_bit_cast(bf16x8, f1), __builtin_bit_cast(bf16x8, f2)};
-      // A: per plane ONE 12-position run per lane (three transposing reads); the fragment of tap dx is positions dx .. dx + 7
-      // of it -- even dx: registers as they are, odd dx: four funnel shifts (nine reads per plane if every tap read its own)
-      bf16x8 a[5];
-#define DW3_LDA(P) do {                                                                                             \
-        const char* ap = xa + (P) * DW3_XPLANE + 32 * s * DW3_XPIX;                                                  \
-        const s16x4_x3 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_x3*)(ap));                      \
-        const s16x4_x3 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_x3*)(ap + 4 * DW3_XPIX));       \
-        const s16x4_x3 t2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_x3*)(ap + 8 * DW3_XPIX));       \
-        const uint2 u0 = __builtin_bit_cast(uint2, t0), u1 = __builtin_bit_cast(uint2, t1), u2 = __builtin_bit_cast(uint2, t2);              \
-        const uint32_t L[6] = {u0.x, u0.y, u1.x, u1.y, u2.x, u2.y};                                                  \
-        uint32_t S[5];                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < 5; ++i) S[i] = __builtin_amdgcn_alignbit(L[i + 1], L[i], 16);          \
-        a[0] = __builtin_bit_cast(bf16x8, (u32x4_x3){L[0], L[1], L[2], L[3]});                                       \
-        a[1] = __builtin_bit_cast(bf16x8, (u32x4_x3){S[0], S[1], S[2], S[3]});                                       \
-        a[2] = __builtin_bit_cast(bf16x8, (u32x4_x3){L[1], L[2], L[3], L[4]});                                       \
-        a[3] = __builtin_bit_cast(bf16x8, (u32x4_x3){S[1], S[2], S[3], S[4]});                                       \
-        a[4] = __builtin_bit_cast(bf16x8, (u32x4_x3){L[2], L[3], L[4], L[5]});                                       \
-      } while (0);
-#define DW3_PROD(PB) _Pragma("unroll") for (int dx = 0; dx < 5; ++dx) acc[dx] = mfma16bf(a[dx], bfr[PB], acc[dx]);
-      DW3_LDA(2) DW3_PROD(0)
-      DW3_LDA(1) DW3_PROD(1) DW3_PROD(0)
-      DW3_LDA(0) DW3_PROD(2) DW3_PROD(1) DW3_PROD(0)
-#undef DW3_LDA
-#undef DW3_PROD
-      __builtin_amdgcn_sched_barrier(0);  // (the next step's reads stay behind this step's products: register room)
-    }
-  }
-  // bias gradient: LDS atomics of the task threads, then one 32-lane atomic per workgroup
-  if (bias_role && tid < 392) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) atomicAdd(&bsum[tcg * 4 + j], gsum[j]);
-  }
-  __syncthreads();
-  if (bias_role && tid < 32) atomicAdd(&db2[c * 32 + tid], bsum[tid]);
-  __syncthreads();
-  // combine the two k groups' partial sums (the images are dead), then one atomic per element and workgroup
-  float* red = reinterpret_cast<float*>(smem);
-  if (kq == 1) {
-#pragma unroll
-    for (int dx = 0; dx < 5; ++dx) *reinterpret_cast<f32x4*>(red + ((wave * 5 + dx) * 64 + lane) * 4) = acc[dx];
-  }
-  __syncthreads();
-  if (kq == 0) {
-#pragma unroll
-    for (int dx = 0; dx < 5; ++dx) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(red + (((wave + 1) * 5 + dx) * 64 + lane) * 4);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int cin = mt * 16 + 4 * q + i, cout = c * 32 + nt * 16 + r;
-        atomicAdd(&dW[((long)(dy * 5 + dx) * 32 + cin) * 64 + cout], acc[dx][i] + v[i]);
-      }
-    }
-  }
-}
-
-// conv2 dW (workgroups [0, n2)), conv1 dW/db (the next n1) and optionally trailing optimizer workgroups in one launch (the
-// roles of conv_dw_duo_f32_kernel, f32_conv2.hip)
-struct ConvDwDuoX3 {
-  const float* pool1; const float* dpool2; const float* pool2; const uint8_t* amax2; float* dW2; float* db2;
-  int B, n2;
-  const float* images; const int* perm; const int* step_ptr; int spe;
-  const float* dpool1; const uint8_t* amax1; float* dW1; float* db1;
-  int n1;
-  OptimParams adam;  // adam.n == 0: no optimizer workgroups
-  int nadam;
-};
-constexpr int DUOX3_LDS = DW3_LDS > CONV1_DW_LDS_FLOATS * 4 ? DW3_LDS : CONV1_DW_LDS_FLOATS * 4;
-static_assert(DUOX3_LDS <= 81920, "two workgroups per CU");
-}  // namespace
-
-__global__ __launch_bounds__(512, 4) void conv_dw_duo_x3_kernel(const ConvDwDuoX3 a) {
-  extern __shared__ __attribute__((aligned(16))) char smem3[];
-  const int id = blockIdx.x;
-  if (id < a.n2)
-    conv2_dw_x3_body(smem3, id, a.pool1, a.dpool2, a.pool2, a.amax2, a.dW2, a.db2, a.B);
-  else if (id >= a.n2 + a.n1) {
-    if (a.adam.wsh_world > 0)  // (launch-uniform) "wshard": this rank's slice only, stored into every rank's next-parity buffer
-      adam_tf_body<false, true>(a.adam, id - a.n2 - a.n1, a.nadam, 512);
-    else
-      adam_tf_body(a.adam, id - a.n2 - a.n1, a.nadam, 512);
-  } else
-    conv1_dw_body(reinterpret_cast<float*>(smem3), id - a.n2, a.n1, a.images, a.perm, a.step_ptr, a.spe, a.B, a.dpool1,
-                  a.amax1, a.dW1, a.db1);
-}
+// (The filter gradient stays on the exact-fp32 MFMA, f32_conv2.hip: a bf16x6 form -- pooled dY entries in LDS, transposing
+// reads, one 12-position run + funnel shifts for the five shifted A fragments -- was correct but no faster, 29.3 against
+// 28.5 us for the role alone: that launch is bound by its per-image staging chain under the hosted optimizer's memory
+// traffic, not by the matrix pipe.  docs/DESIGN.md 2d.)
 
 __global__ __launch_bounds__(256) void conv2_pack3_kernel(const float* __restrict__ W, char* __restrict__ Wf3, char* __restrict__ Wb3) {
   conv2_pack3_body(W, Wf3, Wb3, blockIdx.x, gridDim.x);
@@ -626,37 +404,7 @@ static int x3_init() {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_bwd_data_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           D3_LDS);
   if (e != hipSuccess) return (int)e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dw_duo_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          DUOX3_LDS);
-  if (e != hipSuccess) return (int)e;
   g_x3_attr_set = true;
-  return 0;
-}
-
-// Both filter gradients of the conv stack (+ the hosted optimizer range) in one launch: the arguments of dtf_conv_dw_duo_f32,
-// which validates them and forwards here when the emulation switch is on.
-DTF_API int dtf_conv_dw_duo_x3(const float* dpool2, const float* pool2, const void* amax2, const float* pool1, float* dW2,
-                               float* db2, int B, const float* images, const int* perm, const int* step_ptr, int spe,
-                               const float* dpool1, const void* amax1, float* dW1, float* db1, const OptimParams* adam,
-                               hipStream_t st) {
-  if (B <= 0 || (perm && spe <= 0)) return ERR_SHAPE;
-  const int rc = x3_init();
-  if (rc) return rc;
-  ConvDwDuoX3 a;
-  a.pool1 = pool1; a.dpool2 = dpool2; a.pool2 = pool2; a.amax2 = (const uint8_t*)amax2; a.dW2 = dW2; a.db2 = db2;
-  a.B = B; a.n2 = dtf_cdiv(B, DW3_IPW) * 10;
-  a.images = images; a.perm = perm; a.step_ptr = step_ptr; a.spe = spe;
-  a.dpool1 = dpool1; a.amax1 = (const uint8_t*)amax1; a.dW1 = dW1; a.db1 = db1;
-  a.n1 = dW1 ? (B < 128 ? B : 128) : 0;
-  a.adam = OptimParams{};
-  a.nadam = 0;
-  if (adam) {
-    a.adam = *adam;
-    a.adam.ticket = nullptr;  // (the step is advanced by the optimizer launch that covers the rest of the arena)
-    a.nadam = 512 - (a.n2 + a.n1) > 64 ? 512 - (a.n2 + a.n1) : 64;  // (fill the resident slots: two workgroups per CU)
-  }
-  hipLaunchKernelGGL(conv_dw_duo_x3_kernel, dim3(a.n2 + a.n1 + a.nadam), dim3(512), DUOX3_LDS, st, a);
-  DTF_CHECK_LAUNCH();
   return 0;
 }
 

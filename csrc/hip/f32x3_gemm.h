@@ -11,7 +11,7 @@
 //   ColK (source row-contiguous): plane [BK][R] bf16 AS IT COMES, pitch 2 R + 64 B (four consecutive k-rows on distinct
 //     banks); fragments with the transposing read ds_read_b64_tr_b16, two per 8 k
 // One LDS image of a slab (two barriers per slab; the double image of the exact-fp32 body would need 2 x 45-49 KB), slabs
-// i + 1 and i + 2 in flight in registers.  KW = 2: the two wave sets split the six plane products, three each.
+// i + 1 .. in flight in registers.  KW = 2: the two wave sets split the six plane products, three each.
 #pragma once
 #include "bf16x3.h"
 #include "f32_gemm.h"
@@ -62,7 +62,9 @@ constexpr int dtf_gemm32x3_lds() {
                                                                        : BM * (BN + 4) * 4;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int KW = 1>
+// NSET register sets of staged slabs: slabs i + 1 .. i + NSET - 1 are in flight while slab i is multiplied (a launch whose
+// workgroups walk few slabs, like the fc1 forward with 7, takes them all at once and pays the memory latency once).
+template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int KW = 1, int NSET = 2>
 __device__ __forceinline__ void dtf_gemm32x3_body(const GemmParams& p, const int m0, const int n0, const int z,
                                                   char* __restrict__ smem) {
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16, NT = 64 * WM * WN * KW;
@@ -86,10 +88,10 @@ __device__ __forceinline__ void dtf_gemm32x3_body(const GemmParams& p, const int
 
   char* As = smem;
   char* Bs = smem + AX::BYTES;
-  AL al[2];
-  BL bl[2];
+  AL al[NSET];
+  BL bl[NSET];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < NSET; ++s) {
     al[s].init(p, m0, tid);
     bl[s].init(p, n0, tid);
     if (s == 0 || kbeg + s * BK < kend) {
@@ -97,16 +99,16 @@ __device__ __forceinline__ void dtf_gemm32x3_body(const GemmParams& p, const int
       bl[s].load(kbeg + s * BK, kend, tid);
     }
   }
-  for (int k = kbeg; k < kend; k += 2 * BK) {
+  for (int k = kbeg; k < kend; k += NSET * BK) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < NSET; ++s) {
       if (s > 0 && k + s * BK >= kend) break;  // (workgroup-uniform)
       if (k + s * BK > kbeg) __syncthreads();  // the previous slab has been multiplied
       AX::store(al[s], As, tid, NT);
       BX::store(bl[s], Bs, tid, NT);
-      if (k + (s + 2) * BK < kend) {
-        al[s].load(k + (s + 2) * BK, kend, tid);
-        bl[s].load(k + (s + 2) * BK, kend, tid);
+      if (k + (s + NSET) * BK < kend) {
+        al[s].load(k + (s + NSET) * BK, kend, tid);
+        bl[s].load(k + (s + NSET) * BK, kend, tid);
       }
       __syncthreads();
 #pragma unroll
