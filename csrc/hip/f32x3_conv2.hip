@@ -17,6 +17,22 @@
 #include "conv2_pack3.h"
 #include "dtf_api.h"
 
+// -DDTF_CONV_STAMPS (diagnostic builds only, scripts/dbg/x3_conv_stamps.py): thread 0 of every workgroup records (shader clock,
+// 100 MHz real-time clock) pairs at phase boundaries into g_x3_stamps[workgroup][16][2]
+#ifdef DTF_CONV_STAMPS
+__device__ unsigned long long* g_x3_stamps;
+DTF_API int dtf_dbg_set_x3_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_x3_stamps), &p, sizeof(p)); }
+#define X3STAMP(i) do { if (threadIdx.x == 0 && g_x3_stamps) { g_x3_stamps[blockIdx.x * 32 + 2 * (i)] = __builtin_amdgcn_s_memtime(); \
+  g_x3_stamps[blockIdx.x * 32 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+// per-wave: loop-end clock at [workgroup][16 + wave], HW_ID at [workgroup][24 + wave]
+#define X3STAMP_WAVE() do { if ((threadIdx.x & 63) == 0 && g_x3_stamps) { \
+  g_x3_stamps[blockIdx.x * 32 + 16 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime(); \
+  g_x3_stamps[blockIdx.x * 32 + 24 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); } } while (0)
+#else
+#define X3STAMP(i) do { } while (0)
+#define X3STAMP_WAVE() do { } while (0)
+#endif
+
 namespace {
 constexpr int ERR_SHAPE = -22;
 
@@ -44,12 +60,18 @@ __device__ __forceinline__ void store_planes8(char* dst, const int plane_bytes, 
 }
 
 // the six plane products of 5 x 2 tiles, plane pair outermost: ten independent MFMAs between two that share an accumulator
-#define X3_PROD(PA, PB)                                                                  \
+#define X3_PROD(A, Bq, PA, PB)                                                           \
   _Pragma("unroll") for (int mt = 0; mt < 5; ++mt) {                                     \
-    acc[mt][0] = mfma16bf(a[mt][PA], bcur[PB][0], acc[mt][0]);                           \
-    acc[mt][1] = mfma16bf(a[mt][PA], bcur[PB][1], acc[mt][1]);                           \
+    acc[mt][0] = mfma16bf(A[mt][PA], Bq[PB][0], acc[mt][0]);                             \
+    acc[mt][1] = mfma16bf(A[mt][PA], Bq[PB][1], acc[mt][1]);                             \
   }
-#define X3_ALL_PRODUCTS() do { X3_PROD(2, 0) X3_PROD(0, 2) X3_PROD(1, 1) X3_PROD(1, 0) X3_PROD(0, 1) X3_PROD(0, 0) } while (0)
+// (pinned between scheduling barriers: left to itself the compiler sinks the prefetches issued in front of a k-unit's
+// products to a few MFMAs before their use)
+#define X3_ALL_PRODUCTS(A, Bq) do {                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    X3_PROD(A, Bq, 2, 0) X3_PROD(A, Bq, 0, 2) X3_PROD(A, Bq, 1, 1) X3_PROD(A, Bq, 1, 0) X3_PROD(A, Bq, 0, 1) X3_PROD(A, Bq, 0, 0) \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+  } while (0)
 }  // namespace
 
 // ------------------------------------------------------------------ forward + bias + ReLU + 2x2 max-pool
@@ -77,6 +99,7 @@ __global__ __launch_bounds__(512) void conv2_fwd_x3_kernel(const float* __restri
   const int hlo0 = 2 * pylo0;
   const int nrow0 = 2 * (pyhi0 - pylo0) + 6;
   const int nrow1 = two ? 2 * ((glast - (b0 + 1) * 49) / 7) + 6 : 0;
+  X3STAMP(0);
 
   // B fragments of tap t: plane p, tile nt: Wf3[p][t][32 nh + 16 nt + r][8 q .. 8 q + 7]
   const char* wb = Wf3 + ((long)(32 * nh + r) * 32 + 8 * q) * 2;
@@ -124,21 +147,17 @@ __global__ __launch_bounds__(512) void conv2_fwd_x3_kernel(const float* __restri
   for (int mt = 0; mt < F3_MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  X3STAMP(1);
   __syncthreads();
+  X3STAMP(2);
 
-  const int ntap = kq == 0 ? 7 : 6;
-#pragma unroll 1
-  for (int i = 0; i < ntap; ++i) {
-    const int t = kq + 4 * i;
-    const int tn = t + 4 < 25 ? t + 4 : t;  // (the last prefetch is a harmless repeat)
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-        bnxt[p][nt] = *reinterpret_cast<const bf16x8*>(wb + p * CONV2_W3_PLANE + ((long)tn * 64 + 16 * nt) * 64);
+  // k loop: the fragments of the NEXT k-unit (15 LDS reads, 6 filter loads from L2) are requested before the 60 MFMAs of the
+  // current one, in two register sets used in turn.  Phase stamps showed why: with "oldest wave first" issue the older wave
+  // of a SIMD runs ahead and the younger one ends up alone for a third of the loop, where a wave that reads, waits and
+  // multiplies in turn keeps the pipe 60 % busy; a wave that always has its operands keeps it full on its own.
+  auto load_a = [&](bf16x8 (&a)[F3_MT][3], const int t) {
     const int dy = t / 5, dx = t - dy * 5;
     const char* ab = smem3 + dy * F3_ROW + dx * F3_PIX;
-    bf16x8 a[F3_MT][3];
     // (plane 2 first: the products that need it come first, and LDS returns in order)
 #pragma unroll
     for (int mt = 0; mt < F3_MT; ++mt) a[mt][2] = *reinterpret_cast<const bf16x8*>(ab + abase[mt] + 2 * F3_PLANE);
@@ -146,20 +165,35 @@ __global__ __launch_bounds__(512) void conv2_fwd_x3_kernel(const float* __restri
     for (int mt = 0; mt < F3_MT; ++mt) a[mt][0] = *reinterpret_cast<const bf16x8*>(ab + abase[mt]);
 #pragma unroll
     for (int mt = 0; mt < F3_MT; ++mt) a[mt][1] = *reinterpret_cast<const bf16x8*>(ab + abase[mt] + F3_PLANE);
-    // (pinned: left to itself the compiler sinks the filter prefetch to a few MFMAs before its use and reads the A fragments
-    // two at a time just in time, so every unit starts with a chain of exposed round trips)
-    __builtin_amdgcn_sched_barrier(0);
-    X3_ALL_PRODUCTS();
-    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto load_b = [&](bf16x8 (&b)[3][2], const int t) {
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) bcur[p][nt] = bnxt[p][nt];
+      for (int nt = 0; nt < 2; ++nt)
+        b[p][nt] = *reinterpret_cast<const bf16x8*>(wb + p * CONV2_W3_PLANE + ((long)t * 64 + 16 * nt) * 64);
+  };
+  bf16x8 acur[F3_MT][3], anxt[F3_MT][3];
+  load_a(acur, kq);
+#pragma unroll 1
+  for (int j = 0; j < 3; ++j) {  // taps kq + 8 j and kq + 8 j + 4
+    const int t = kq + 8 * j;
+    load_b(bnxt, t + 4);
+    load_a(anxt, t + 4);
+    X3_ALL_PRODUCTS(acur, bcur);
+    const int t2 = t + 8 < 25 ? t + 8 : 24;  // (kq = 0: its seventh tap, 24; the other waves' last prefetch is a harmless read)
+    load_b(bcur, t2);
+    load_a(acur, t2);
+    X3_ALL_PRODUCTS(anxt, bnxt);
   }
+  if (kq == 0) X3_ALL_PRODUCTS(acur, bcur);  // tap 24 (wave-uniform)
 
   // ---- combine the four K slices of each channel half through LDS (the image is dead), then bias + ReLU + pool on register
   // quads; tile id = (nh * F3_MT + mt) * 2 + nt, finalised by wave (id % 8)
+  X3STAMP_WAVE();
+  X3STAMP(3);
   __syncthreads();
+  X3STAMP(4);
   float* red = reinterpret_cast<float*>(smem3);
   constexpr int TPW = F3_MT * 2;  // tiles per wave
 #pragma unroll
@@ -168,6 +202,7 @@ __global__ __launch_bounds__(512) void conv2_fwd_x3_kernel(const float* __restri
     for (int nt = 0; nt < 2; ++nt)
       *reinterpret_cast<f32x4*>(red + ((wave * TPW + mt * 2 + nt) * 64 + lane) * 4) = acc[mt][nt];
   __syncthreads();
+  X3STAMP(5);
   for (int id = wave; id < 2 * TPW; id += 8) {
     const int h = id / TPW, t = id - h * TPW;
     f32x4 s = *reinterpret_cast<const f32x4*>(red + (((4 * h) * TPW + t) * 64 + lane) * 4);
@@ -189,6 +224,7 @@ __global__ __launch_bounds__(512) void conv2_fwd_x3_kernel(const float* __restri
       if (amax) amax[o] = (uint8_t)arg;
     }
   }
+  X3STAMP(6);
 }
 
 // ------------------------------------------------------------------ data gradient + un-pool + ReLU mask
@@ -321,33 +357,39 @@ __global__ __launch_bounds__(512) void conv2_bwd_data_x3_kernel(const float* __r
     for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
-  const int nunit = wave < 2 ? 7 : 6;
-#pragma unroll 1
-  for (int i = 0; i < nunit; ++i) {
-    const int u = wave + 8 * i;
-    const int un = u + 8 < 50 ? u + 8 : u;
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) bnxt[p][nt] = bfrag(p, nt, un);
+  // k loop: two register sets of fragments used in turn, the next unit's requested before the current one's MFMAs (see
+  // conv2_fwd_x3_kernel); wave w takes units w, w + 8, ... (7 for waves 0 and 1, 6 for the others)
+  auto load_a = [&](bf16x8 (&a)[D3_MT][3], const int u) {
     const int tap = u >> 1;
     const int dy = tap / 5, dx = tap - dy * 5;
     const char* ab = smem3 + dy * D3_ROW + dx * D3_PIX + (u & 1) * 64;
-    bf16x8 a[D3_MT][3];
 #pragma unroll
     for (int mt = 0; mt < D3_MT; ++mt) a[mt][2] = *reinterpret_cast<const bf16x8*>(ab + abase[mt] + 2 * D3_PLANE);
 #pragma unroll
     for (int mt = 0; mt < D3_MT; ++mt) a[mt][0] = *reinterpret_cast<const bf16x8*>(ab + abase[mt]);
 #pragma unroll
     for (int mt = 0; mt < D3_MT; ++mt) a[mt][1] = *reinterpret_cast<const bf16x8*>(ab + abase[mt] + D3_PLANE);
-    __builtin_amdgcn_sched_barrier(0);
-    X3_ALL_PRODUCTS();
-    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto load_b = [&](bf16x8 (&b)[3][2], const int u) {
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) bcur[p][nt] = bnxt[p][nt];
+      for (int nt = 0; nt < 2; ++nt) b[p][nt] = bfrag(p, nt, u);
+  };
+  bf16x8 acur[D3_MT][3], anxt[D3_MT][3];
+  load_a(acur, wave);
+#pragma unroll 1
+  for (int j = 0; j < 3; ++j) {  // units wave + 16 j and wave + 16 j + 8
+    const int u = wave + 16 * j;
+    load_b(bnxt, u + 8);
+    load_a(anxt, u + 8);
+    X3_ALL_PRODUCTS(acur, bcur);
+    const int u2 = u + 16 < 50 ? u + 16 : 49;  // (waves 0 and 1: their seventh unit; the others' last prefetch is a harmless read)
+    load_b(bcur, u2);
+    load_a(acur, u2);
+    X3_ALL_PRODUCTS(anxt, bnxt);
   }
+  if (wave < 2) X3_ALL_PRODUCTS(acur, bcur);  // units 48, 49 (wave-uniform)
 
   // ---- combine the eight K slices through LDS (the staged rows are dead); tile id = mt * 2 + nt, finalised by wave id % 8
   __syncthreads();

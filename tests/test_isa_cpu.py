@@ -49,7 +49,7 @@ def test_bf16x6_kernels_run_on_the_bf16_matrix_cores_without_scratch():
     for key in ("conv2_fwd_x3_kernel", "conv2_bwd_data_x3_kernel"):
         body = [b for n, b in conv.items() if key in n]
         assert len(body) == 1, (key, list(conv))
-        assert body[0].count("v_mfma_f32_16x16x32_bf16") == 60, key   # 5 x 2 tiles x 6 plane products per k-unit
+        assert body[0].count("v_mfma_f32_16x16x32_bf16") == 180, key  # 5 x 2 tiles x 6 plane products per k-unit; two units per loop pass + the odd one
         assert "v_mfma_f32_16x16x4_f32" not in body[0] and "scratch_" not in body[0], key
         assert "v_cvt_pk_bf16_f32" in body[0], key                     # the split happens where the operand is staged
     fc = _kernel_bodies("f32_fc.hip")
