@@ -171,7 +171,11 @@ __global__ __launch_bounds__(512) void conv2_fwd_x3_kernel(const float* __restri
     for (int p = 0; p < 3; ++p)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
+#ifdef DTF_X3_EXP_BHOT  // (timing experiment only, wrong sums: every tap reads tap 0's filter rows -> L1 hits, no L2 stream)
+        b[p][nt] = *reinterpret_cast<const bf16x8*>(wb + p * CONV2_W3_PLANE + ((long)(t & 0) * 64 + 16 * nt) * 64);
+#else
         b[p][nt] = *reinterpret_cast<const bf16x8*>(wb + p * CONV2_W3_PLANE + ((long)t * 64 + 16 * nt) * 64);
+#endif
   };
   bf16x8 acur[F3_MT][3], anxt[F3_MT][3];
   load_a(acur, kq);
@@ -179,11 +183,16 @@ __global__ __launch_bounds__(512) void conv2_fwd_x3_kernel(const float* __restri
   for (int j = 0; j < 3; ++j) {  // taps kq + 8 j and kq + 8 j + 4
     const int t = kq + 8 * j;
     load_b(bnxt, t + 4);
+#ifdef DTF_X3_EXP_NOLDS  // (timing experiment only, wrong sums: no fragment reads inside the loop)
+    if (j == 0)
+#endif
     load_a(anxt, t + 4);
     X3_ALL_PRODUCTS(acur, bcur);
     const int t2 = t + 8 < 25 ? t + 8 : 24;  // (kq = 0: its seventh tap, 24; the other waves' last prefetch is a harmless read)
     load_b(bcur, t2);
+#ifndef DTF_X3_EXP_NOLDS
     load_a(acur, t2);
+#endif
     X3_ALL_PRODUCTS(anxt, bnxt);
   }
   if (kq == 0) X3_ALL_PRODUCTS(acur, bcur);  // tap 24 (wave-uniform)
