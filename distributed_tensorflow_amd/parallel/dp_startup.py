@@ -242,12 +242,24 @@ class StartupMixin:
                     return bad
 
                 def time_steps(self):
-                    trainer.train_steps(7)
-                    e.stream.synchronize()
+                    """Warm + timed steps -> us per step; inf (agreed across ranks) as soon as an in-kernel wait has
+                    expired: a schedule whose waits run into their 2 s bound would otherwise hold the start-up for
+                    minutes (seen with four ranks time-sharing one GPU: 64 steps took 85 s)."""
+                    for n in (2, 5):
+                        trainer.train_steps(n)
+                        e.stream.synchronize()
+                        if self.wait_expired():
+                            return math.inf
                     dist.barrier(group=trainer.group)
                     t0 = time.perf_counter()
-                    trainer.train_steps(steps)
-                    e.stream.synchronize()
+                    done = 0
+                    while done < steps:
+                        n = min(16, steps - done)
+                        trainer.train_steps(n)
+                        e.stream.synchronize()
+                        done += n
+                        if self.wait_expired():
+                            return math.inf
                     return (time.perf_counter() - t0) / steps * 1e6
 
                 def restore(self):
@@ -283,6 +295,12 @@ class StartupMixin:
             self.schedule_deviation = {c: float("%.3g" % v) for c, v in zip(cands, off)}
             set_timeouts(op_timeout)
             cands = [sel.choose(cands, times, off, broken, forced)]
+            # the dropped candidates' expired waits are in the log and the state is the snapshot again: the chosen schedule
+            # starts with a clean count (ensure_healthy() / check_transport() act on ANY expiry since then)
+            if broken:
+                for comm in (self.ipc, self.ipc_act, self.ipc_w):
+                    if comm is not None:
+                        comm.reset_errors()
         use(cands[0])
         if self.rank == 0:
             print("data-parallel step schedule: %s %s gradient deviation from the staged all-reduce %s" % (

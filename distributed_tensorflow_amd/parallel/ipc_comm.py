@@ -211,6 +211,15 @@ class IpcAllReduce:
         """Number of waits that timed out so far (synchronises)."""
         return int(self._words[1].item())
 
+    def reset_errors(self) -> None:
+        """Forget the expired waits counted so far (synchronises).  For the end of the start-up trials: a candidate schedule
+        whose waits expired was dropped and the training state restored, so its expiries must not make `ensure_healthy()`
+        abandon the schedule that was chosen."""
+        if self.comm is not None:
+            torch.cuda.synchronize(self.device)
+            self._words[1:2].zero_()
+            torch.cuda.synchronize(self.device)
+
     def self_test(self, n: int = 0, rounds: int = 3) -> bool:
         """Reduce random data ``rounds`` times and compare with the process group's own all-reduce; all ranks get the
         same verdict."""

@@ -97,7 +97,11 @@ def run_trials(cands: Sequence[str], ops: TrialOps, *, forced: str = "auto", tim
             drop(c, "an in-kernel wait expired (2 s bound): not eligible", restore=True)
             continue
         if timed:
-            times.append(ops.time_steps())
+            t_us = ops.time_steps()
+            if math.isinf(t_us):  # (agreed across ranks: TrialOps.time_steps stops at the first expired wait)
+                drop(c, "an in-kernel wait expired during the timed steps (2 s bound): not eligible", restore=True)
+                continue
+            times.append(t_us)
         else:
             times.append(float(len(times)))  # untimed: keep the order of preference
         note("%s: %s us/step, trial took %.2f s" % (c, ("%.1f" % times[-1]) if timed else "untimed", clock() - t_c))

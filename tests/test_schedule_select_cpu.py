@@ -150,3 +150,15 @@ def test_untimed_trials_keep_the_order_of_preference():
     ops = FakeOps({})
     times, off, broken = _run(ops, cands, timed=False)
     assert times == [0.0, 1.0, 2.0, 3.0] and sel.choose(cands, times, off, broken) == "ipc-shard"
+
+
+def test_wait_expiring_during_the_timed_steps_drops_the_candidate():
+    """TrialOps.time_steps returns inf (agreed across ranks) at the first expired wait instead of running 64 steps of 2 s
+    waits: the candidate is dropped, the snapshot restored, and the remaining candidates are still tried."""
+    cands = sel.candidates(**ALL)
+    ops = FakeOps(dict(US8, **{"ipc-shard": math.inf}))
+    times, off, broken = _run(ops, cands)
+    assert "ipc-shard" in broken and math.isinf(times[cands.index("ipc-shard")])
+    assert len(times) == len(off) == len(cands) and ops.used == cands and ops.restored == len(cands)
+    assert sel.choose(cands, times, off, broken) == "ipc-gather"
+    assert any("ipc-shard" in l and "timed steps" in l for l in ops.log)
