@@ -70,15 +70,23 @@ using DwBn3 = F32ColK<16, 256, 32, false>;
 using DwAg3 = F32ColKSeg<128, 256, 32, true>;
 using DwBg3 = F32ColKSeg<64, 256, 32, false>;
 
+// The bf16x6 fc1 forward is wave-specialised (f32x3_gemm.h: dtf_gemm32x3_ws_body): 4 multiplying waves + 4 FWD_SMUL staging
+// waves.  Measured per slab by the stamps: staging 3 100 / 2 400 cycles with 4 / 8 staging waves against ~1 400 of multiplying
+// (kernel 13.9 / 11.4 us).  The exact-fp32 form has 512 threads.
+constexpr int FWD_SMUL = 3;
+using FwdAs = F32RowK<112, 256 * FWD_SMUL, 32, true>;
+using FwdBs = F32ColK<64, 256 * FWD_SMUL, 32, false>;
+
 // one role of a launch: the exact-fp32 body or its bf16x6 form (BK = the loaders' slab depth)
-template <bool X3, int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int KW = 1, int NSET = 2>
+template <bool X3, int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int KW = 1, int NSET = 2, int STAGES = 1>
 __device__ __forceinline__ void gemm_role(const GemmParams& p, const int m0, const int n0, const int z, float* smem) {
-  if constexpr (X3) dtf_gemm32x3_body<BM, BN, BK, WM, WN, AL, BL, EP, KW, NSET>(p, m0, n0, z, reinterpret_cast<char*>(smem));
+  if constexpr (X3)
+    dtf_gemm32x3_body<BM, BN, BK, WM, WN, AL, BL, EP, KW, NSET, STAGES>(p, m0, n0, z, reinterpret_cast<char*>(smem));
   else dtf_gemm32_body<BM, BN, BK, WM, WN, AL, BL, EP, 2, KW>(p, m0, n0, z, smem);
 }
-template <bool X3, int BM, int BN, int BK, class AL, class BL>
+template <bool X3, int BM, int BN, int BK, class AL, class BL, int STAGES = 1>
 constexpr int role_lds_floats() {
-  if constexpr (X3) return dtf_gemm32x3_lds<BM, BN, BK, AL, BL>() / 4;
+  if constexpr (X3) return dtf_gemm32x3_lds<BM, BN, BK, AL, BL, STAGES>() / 4;
   else return dtf_gemm32_lds<BM, BN, AL, BL>();
 }
 
@@ -89,19 +97,40 @@ constexpr int FWD_NSET = 2;
 
 // the fc1 forward (112 x 64 tile, 8 waves) in both forms; SEL: W double-buffered by step parity; PUSH: a copy role in the z
 // planes behind the K splits (dtf_fc_fwd_f32_push)
+// (one workgroup per CU: the bf16x6 form keeps two LDS images of a slab, 2 x 45 KB of dynamic shared memory)
+constexpr int FWD_STAGES = 2;
+template <bool X3>
+constexpr int fwd_lds_bytes() { return 4 * role_lds_floats<X3, 112, 64, 32, FwdA, FwdB, X3 ? FWD_STAGES : 1>(); }
+template <bool X3>
+__device__ __forceinline__ void fwd_role(const GemmParams& p, float* smem) {
+  if constexpr (X3)
+    // (7: fc1's 3136 / 14 splits = 7 slabs of 32 take the unrolled path)
+    dtf_gemm32x3_ws_body<112, 64, 32, 1, 4, FwdAs, FwdBs, Ep32Store, 7, FWD_SMUL>(p, blockIdx.x * 112, blockIdx.y * 64, blockIdx.z,
+                                                                       reinterpret_cast<char*>(smem));
+  else
+    dtf_gemm32_body<112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store, 2, 2>(p, blockIdx.x * 112, blockIdx.y * 64, blockIdx.z, smem);
+}
+template <bool X3>
+constexpr int fwd_threads() { return X3 ? 256 * (1 + FWD_SMUL) : 512; }
 template <bool X3, bool SEL>
-__global__ __launch_bounds__(512) void fc_fwd32_kernel(const GemmParams p) {
-  __shared__ __attribute__((aligned(16))) float smem[role_lds_floats<X3, 112, 64, 32, FwdA, FwdB>()];
+__global__ __launch_bounds__(fwd_threads<X3>()) void fc_fwd32_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   GemmParams q = p;
   if constexpr (SEL) {
     if (*p.bsel & 1) q.B = p.B_alt;  // (workgroup-uniform)
   }
-  gemm_role<X3, 112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store, 2, FWD_NSET>(q, blockIdx.x * 112, blockIdx.y * 64, blockIdx.z, smem);
+  fwd_role<X3>(q, smem);
+}
+template <class K>
+int allow_lds(K kernel, int bytes) {  // (dynamic shared memory above 64 KB has to be granted per kernel, once)
+  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 template <bool X3, bool SEL>
 int launch_fc_fwd32(const GemmParams& p, int splits, hipStream_t st) {
+  static int granted = allow_lds(fc_fwd32_kernel<X3, SEL>, fwd_lds_bytes<X3>());
+  if (granted != 0) return granted;
   dim3 grid(dtf_cdiv(p.M, 112), dtf_cdiv(p.N, 64), splits);
-  hipLaunchKernelGGL((fc_fwd32_kernel<X3, SEL>), grid, dim3(512), 0, st, p);
+  hipLaunchKernelGGL((fc_fwd32_kernel<X3, SEL>), grid, dim3(fwd_threads<X3>()), fwd_lds_bytes<X3>(), st, p);
   DTF_CHECK_LAUNCH();
   return 0;
 }
@@ -137,14 +166,15 @@ DTF_API int dtf_fc_fwd_f32_sel(const float* X, const float* W0, const float* W1,
 namespace {
 constexpr int PUSH_PLANES = 2;
 template <bool X3>
-__global__ __launch_bounds__(512) void fc_fwd32_push_kernel(const GemmParams p, const int splits, const ShardPush push) {
-  __shared__ __attribute__((aligned(16))) float smem[role_lds_floats<X3, 112, 64, 32, FwdA, FwdB>()];
+__global__ __launch_bounds__(fwd_threads<X3>()) void fc_fwd32_push_kernel(const GemmParams p, const int splits, const ShardPush push) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((int)blockIdx.z >= splits) {  // (workgroup-uniform)
     const int per = gridDim.x * gridDim.y;
-    shard_push_body(push, ((int)blockIdx.z - splits) * per + blockIdx.y * gridDim.x + blockIdx.x, PUSH_PLANES * per, 512);
+    shard_push_body(push, ((int)blockIdx.z - splits) * per + blockIdx.y * gridDim.x + blockIdx.x, PUSH_PLANES * per,
+                    fwd_threads<X3>());
     return;
   }
-  gemm_role<X3, 112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store, 2, FWD_NSET>(p, blockIdx.x * 112, blockIdx.y * 64, blockIdx.z, smem);
+  fwd_role<X3>(p, smem);
 }
 }  // namespace
 
@@ -158,8 +188,15 @@ DTF_API int dtf_fc_fwd_f32_push(const float* X, const float* W, float* out, int 
   GemmParams p = base_params32(X, W, out, M, N, K, K, N, N, splits, 32);
   const int s = eff_splits32(p);
   dim3 grid(dtf_cdiv(p.M, 112), dtf_cdiv(p.N, 64), s + PUSH_PLANES);
-  if (dtf_f32_emulation()) hipLaunchKernelGGL((fc_fwd32_push_kernel<true>), grid, dim3(512), 0, st, p, s, *push);
-  else hipLaunchKernelGGL((fc_fwd32_push_kernel<false>), grid, dim3(512), 0, st, p, s, *push);
+  if (dtf_f32_emulation()) {
+    static int granted = allow_lds(fc_fwd32_push_kernel<true>, fwd_lds_bytes<true>());
+    if (granted != 0) return granted;
+    hipLaunchKernelGGL((fc_fwd32_push_kernel<true>), grid, dim3(fwd_threads<true>()), fwd_lds_bytes<true>(), st, p, s, *push);
+  } else {
+    static int granted = allow_lds(fc_fwd32_push_kernel<false>, fwd_lds_bytes<false>());
+    if (granted != 0) return granted;
+    hipLaunchKernelGGL((fc_fwd32_push_kernel<false>), grid, dim3(512), fwd_lds_bytes<false>(), st, p, s, *push);
+  }
   DTF_CHECK_LAUNCH();
   return 0;
 }
@@ -169,6 +206,7 @@ DTF_API int dtf_fc_fwd_f32_stamps(const float* X, const float* W, float* out, in
                                   hipStream_t st) {
   GemmParams p = base_params32(X, W, out, M, N, K, K, N, N, splits, 32);
   p.aux_out = stamps;
+  if (dtf_f32_emulation()) return launch_fc_fwd32<true, false>(p, eff_splits32(p), st);
   return dtf_launch_gemm32<112, 64, 32, 1, 4, FwdA, FwdB, Ep32Store, 2, 2>(p, eff_splits32(p), st);
 }
 #endif

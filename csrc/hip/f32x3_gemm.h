@@ -56,15 +56,19 @@ struct X3Op {
 };
 
 // LDS bytes a workgroup of the body below needs
-template <int BM, int BN, int BK, class AL, class BL>
+template <int BM, int BN, int BK, class AL, class BL, int STAGES = 1>
 constexpr int dtf_gemm32x3_lds() {
-  return X3Op<AL, BK>::BYTES + X3Op<BL, BK>::BYTES > BM * (BN + 4) * 4 ? X3Op<AL, BK>::BYTES + X3Op<BL, BK>::BYTES
-                                                                       : BM * (BN + 4) * 4;
+  return STAGES * (X3Op<AL, BK>::BYTES + X3Op<BL, BK>::BYTES) > BM * (BN + 4) * 4
+             ? STAGES * (X3Op<AL, BK>::BYTES + X3Op<BL, BK>::BYTES) : BM * (BN + 4) * 4;
 }
 
 // NSET register sets of staged slabs: slabs i + 1 .. i + NSET - 1 are in flight while slab i is multiplied (a launch whose
 // workgroups walk few slabs, like the fc1 forward with 7, takes them all at once and pays the memory latency once).
-template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int KW = 1, int NSET = 2>
+// STAGES = 2 (with NSET = 2): two LDS images of a slab, like the exact-fp32 body -- slab i + 1 is split and stored while slab
+// i is multiplied, ONE barrier per slab.  Phase stamps of the fc1 forward with one image (scripts/dbg/fc_fwd_stamps.py): per
+// slab ~1400 cycles of split + store + barrier, then ~1500 cycles of fragment reads + 21 MFMAs per wave, strictly in turn.
+// 2 x 45 KB of LDS: for launches of one workgroup per CU (dynamic shared memory above 64 KB).
+template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int KW = 1, int NSET = 2, int STAGES = 1>
 __device__ __forceinline__ void dtf_gemm32x3_body(const GemmParams& p, const int m0, const int n0, const int z,
                                                   char* __restrict__ smem) {
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16, NT = 64 * WM * WN * KW;
@@ -79,6 +83,13 @@ __device__ __forceinline__ void dtf_gemm32x3_body(const GemmParams& p, const int
   const int r = lane & 15, q = lane >> 4;
   const int kbeg = z * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
+
+#ifdef DTF_GEMM32_STAMPS  // (diagnostic builds: see dtf_gemm32_body)
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(p.aux_out) +
+                               ((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 64;
+  int si = 0;
+#endif
+  DTF_STAMP(si++);
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -99,18 +110,48 @@ __device__ __forceinline__ void dtf_gemm32x3_body(const GemmParams& p, const int
       bl[s].load(kbeg + s * BK, kend, tid);
     }
   }
+  static_assert(STAGES == 1 || (STAGES == 2 && NSET == 2), "two images go with two register sets");
+  constexpr int STAGE = AX::BYTES + BX::BYTES;
+  if constexpr (STAGES == 2) {
+    AX::store(al[0], As, tid, NT);
+    BX::store(bl[0], Bs, tid, NT);
+    if (kbeg + 2 * BK < kend) {
+      al[0].load(kbeg + 2 * BK, kend, tid);
+      bl[0].load(kbeg + 2 * BK, kend, tid);
+    }
+    __syncthreads();
+  }
   for (int k = kbeg; k < kend; k += NSET * BK) {
 #pragma unroll
     for (int s = 0; s < NSET; ++s) {
       if (s > 0 && k + s * BK >= kend) break;  // (workgroup-uniform)
-      if (k + s * BK > kbeg) __syncthreads();  // the previous slab has been multiplied
-      AX::store(al[s], As, tid, NT);
-      BX::store(bl[s], Bs, tid, NT);
-      if (k + (s + NSET) * BK < kend) {
-        al[s].load(k + (s + NSET) * BK, kend, tid);
-        bl[s].load(k + (s + NSET) * BK, kend, tid);
+      if constexpr (STAGES == 2) {
+        // slab (k + s BK) is in image s; the next one goes from register set 1 - s into image 1 - s (last read before the
+        // barrier that ended the previous slab), and that register set is refilled with the slab after the next two
+        As = smem + s * STAGE;
+        Bs = As + AX::BYTES;
+        DTF_STAMP(si++);
+        if (k + (s + 1) * BK < kend) {
+          AX::store(al[1 - s], smem + (1 - s) * STAGE, tid, NT);
+          BX::store(bl[1 - s], smem + (1 - s) * STAGE + AX::BYTES, tid, NT);
+          if (k + (s + 3) * BK < kend) {
+            al[1 - s].load(k + (s + 3) * BK, kend, tid);
+            bl[1 - s].load(k + (s + 3) * BK, kend, tid);
+          }
+        }
+        DTF_STAMP(si++);
+      } else {
+        if (k + s * BK > kbeg) __syncthreads();  // the previous slab has been multiplied
+        DTF_STAMP(si++);
+        AX::store(al[s], As, tid, NT);
+        BX::store(bl[s], Bs, tid, NT);
+        if (k + (s + NSET) * BK < kend) {
+          al[s].load(k + (s + NSET) * BK, kend, tid);
+          bl[s].load(k + (s + NSET) * BK, kend, tid);
+        }
+        __syncthreads();
+        DTF_STAMP(si++);
       }
-      __syncthreads();
 #pragma unroll
       for (int g = 0; g < BK / 32; ++g) {
         // One A plane and two B planes live at a time (all nine would not fit next to the staged slabs' registers in the
@@ -141,8 +182,10 @@ __device__ __forceinline__ void dtf_gemm32x3_body(const GemmParams& p, const int
         }
 #undef X3G_PROD
       }
+      if constexpr (STAGES == 2) __syncthreads();  // slab multiplied, next image stored
     }
   }
+  DTF_STAMP(si++);
   // ---- assemble the output image in LDS (the staged slab is dead): set KW-1 stores, the others add in descending order
   float* Cs = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -162,6 +205,160 @@ __device__ __forceinline__ void dtf_gemm32x3_body(const GemmParams& p, const int
   }
   __syncthreads();
   EP::template tile<BM, BN>(p, Cs, m0, n0, z, tid, NT);
+  DTF_STAMP(si++);
+}
+
+// ------------------------------------------------------------------ wave-specialised form (one workgroup per CU)
+// Workgroup = (1 + SMUL) x WM x WN waves: the first WM x WN MULTIPLY (every plane product of their tiles), the others STAGE (load,
+// split, store into the other LDS image).  Why: phase stamps of the fc1 forward (scripts/dbg/fc_fwd_stamps.py) show a wave of
+// the plain body spending ~1 250 cycles per slab splitting and storing and ~1 500 reading fragments and multiplying, one
+// after the other, with or without a second LDS image -- every wave does both jobs and the barrier keeps all of them on the
+// same one.  With the jobs on different waves of a SIMD the split's VALU work runs under the other wave's MFMAs.
+// AL / BL are instantiated for the 64 x WM x WN x SMUL staging threads.  smem: 2 x (A + B images) bytes.
+template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int NSLAB = 0, int SMUL = 1>
+__device__ __forceinline__ void dtf_gemm32x3_ws_body(const GemmParams& p, const int m0, const int n0, const int z,
+                                                     char* __restrict__ smem) {
+  // NC multiplying threads, NS = SMUL x NC staging threads (the split is the larger job: ~500 cycles per 4-value chunk and
+  // wave by the stamps, 6 144 values per slab of the fc1 forward)
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16, NC = 64 * WM * WN, NS = SMUL * NC, NT = NC + NS;
+  using AX = X3Op<AL, BK>;
+  using BX = X3Op<BL, BK>;
+  static_assert(TM >= 1 && TN >= 1 && BM % (WM * 16) == 0 && BN % (WN * 16) == 0, "tile");
+  static_assert(AX::R == BM && BX::R == BN, "loader tile");
+  constexpr int STAGE = AX::BYTES + BX::BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool stager = wave >= WM * WN;  // (wave-uniform)
+  const int ptid = tid - NC;
+  const int wm = (wave % (WM * WN)) / WN, wn = wave % WN;
+  const int r = lane & 15, q = lane >> 4;
+  const int kbeg = z * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+#ifdef DTF_GEMM32_STAMPS
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(p.aux_out) +
+                               ((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 64;
+  int si = 0, sj = 0;
+#endif
+  DTF_STAMP(si++);
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  AL al[2];
+  BL bl[2];
+  if (stager) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      al[s].init(p, m0, ptid);
+      bl[s].init(p, n0, ptid);
+      // (unconditional: past kend the loaders read address 0 and zero-fill, and a run-time condition here would cost the
+      // counted waits of everything that follows)
+      al[s].load(kbeg + s * BK, kend, ptid);
+      bl[s].load(kbeg + s * BK, kend, ptid);
+    }
+    AX::store(al[0], smem, ptid, NS);
+    BX::store(bl[0], smem + AX::BYTES, ptid, NS);
+    al[0].load(kbeg + 2 * BK, kend, ptid);
+    bl[0].load(kbeg + 2 * BK, kend, ptid);
+  }
+  __syncthreads();
+  DTF_STAMP(si++);
+  // One slab step of either side; S = the LDS image being multiplied = the register set that is NOT stored now; HAS1 /
+  // HAS3: slabs i + 1 / i + 3 exist.  Each side runs its own loop over the slabs (same number of barriers on both).
+  // Why two loops and not one loop with an if: the waits for the staged registers are counted (s_waitcnt vmcnt(N): "all
+  // but the N youngest loads have landed"), and the compiler can only count along straight-line code.  Where the two
+  // sides' paths join after every slab, or a loop's back edge or a run-time "is there a next slab" sits in between, it
+  // falls back to waiting for EVERY load in flight before each store, i.e. for the refill issued one slab ago: a full
+  // memory round trip per slab (3 200 cycles by the stamps, for 1 400 cycles of multiplying).  Hence also the fully
+  // unrolled path for the launch's usual slab count NSLAB.
+#ifdef DTF_GEMM32_STAMPS
+#define X3W_STAGER_STAMP() do { if (ptid == 0 && sj < 30) stamps[32 + sj++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define X3W_STAGER_STAMP() do { } while (0)
+#endif
+#define X3W_PROD(PA, PB)                                                          \
+  _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_)                               \
+      _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = mfma16bf(a[i_][PA], b[j_][PB], acc[i_][j_]);
+#define X3W_STAGE(S, HAS1, HAS3, KK)                                                                             \
+  do {                                                                                                           \
+    if (HAS1) {                                                                                                  \
+      AX::store(al[1 - (S)], smem + (1 - (S)) * STAGE, ptid, NS);                                                \
+      BX::store(bl[1 - (S)], smem + (1 - (S)) * STAGE + AX::BYTES, ptid, NS);                                    \
+      if (HAS3) {                                                                                                \
+        al[1 - (S)].load((KK) + 3 * BK, kend, ptid);                                                             \
+        bl[1 - (S)].load((KK) + 3 * BK, kend, ptid);                                                             \
+      }                                                                                                          \
+    }                                                                                                            \
+    X3W_STAGER_STAMP();                                                                                          \
+    __syncthreads(); /* next image stored (and the current one multiplied, on the other side) */                 \
+  } while (0)
+#define X3W_MULTIPLY(S)                                                                                          \
+  do {                                                                                                           \
+    const char* As = smem + (S) * STAGE;                                                                         \
+    const char* Bs = As + AX::BYTES;                                                                             \
+    _Pragma("unroll") for (int g = 0; g < BK / 32; ++g) {                                                        \
+      bf16x8 a[TM][3], b[TN][3];                                                                                 \
+      _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                                         \
+        const int pp = pl == 0 ? 2 : pl - 1; /* (plane 2 first: its product comes first) */                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_)                                                        \
+          a[i_][pp] = AX::frag(As + pp * AX::PLANE, wm * (BM / WM) + i_ * 16, r, q, g);                          \
+        _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                                        \
+          b[j_][pp] = BX::frag(Bs + pp * BX::PLANE, wn * (BN / WN) + j_ * 16, r, q, g);                          \
+      }                                                                                                          \
+      X3W_PROD(2, 0) X3W_PROD(0, 2) X3W_PROD(1, 1) X3W_PROD(1, 0) X3W_PROD(0, 1) X3W_PROD(0, 0)                  \
+    }                                                                                                            \
+    DTF_STAMP(si++); /* (products issued) */                                                                     \
+    __syncthreads();                                                                                             \
+    DTF_STAMP(si++);                                                                                             \
+  } while (0)
+  const bool usual = NSLAB > 0 && kend - kbeg == NSLAB * BK;  // (workgroup-uniform)
+  if (stager) {
+    if (usual) {
+#pragma unroll
+      for (int i = 0; i < (NSLAB > 0 ? NSLAB : 1); ++i) X3W_STAGE(i & 1, i + 1 < NSLAB, i + 3 < NSLAB, kbeg + i * BK);
+    } else {
+      for (int k = kbeg; k < kend; k += 2 * BK) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (s > 0 && k + s * BK >= kend) break;
+          X3W_STAGE(s, k + (s + 1) * BK < kend, k + (s + 3) * BK < kend, k + s * BK);
+        }
+      }
+    }
+  } else {
+    if (usual) {
+#pragma unroll
+      for (int i = 0; i < (NSLAB > 0 ? NSLAB : 1); ++i) X3W_MULTIPLY(i & 1);
+    } else {
+      for (int k = kbeg; k < kend; k += 2 * BK) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (s > 0 && k + s * BK >= kend) break;
+          X3W_MULTIPLY(s);
+        }
+      }
+    }
+  }
+#undef X3W_STAGE
+#undef X3W_MULTIPLY
+#undef X3W_PROD
+#undef X3W_STAGER_STAMP
+  // ---- the output image in LDS (the staged slabs are dead), written out by the whole workgroup
+  float* Cs = reinterpret_cast<float*>(smem);
+  if (!stager) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          Cs[(wm * (BM / WM) + a * 16 + 4 * q + i) * (BN + 4) + wn * (BN / WN) + b * 16 + r] = acc[a][b][i];
+  }
+  __syncthreads();
+  EP::template tile<BM, BN>(p, Cs, m0, n0, z, tid, NT);
+  DTF_STAMP(si++);
 }
 
 template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int KW = 1>

@@ -30,3 +30,12 @@ print("deltas:", np.diff(np.median(rel, axis=0)).astype(int))
 print("entry: min %d max %d; end: min %d max %d" % (rel[:, 0].min(), rel[:, 0].max(), rel[:, n - 1].min(), rel[:, n - 1].max()))
 err = float((out.sum(0) - x @ w).abs().max())
 print("max abs err vs torch", err)
+# wave-specialised bf16x6 form: the staging side's end-of-slab clocks at [32 ..] (0 when not present)
+if (t[:, 32] != 0).any():
+    ns = int((t[0, 32:] != 0).sum())
+    srel = t[:, 32:32 + ns] - t[:, 0:1]
+    mrel = t[:, :n] - t[:, 0:1]
+    print("multiplying wave 0, cycles since its entry (entry, staged, [products issued, barrier passed] x slabs, end):")
+    print(np.median(mrel, axis=0).astype(int))
+    print("staging wave, end of each slab's split + store (cycles since workgroup entry):")
+    print(np.median(srel, axis=0).astype(int))
