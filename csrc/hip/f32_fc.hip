@@ -78,14 +78,14 @@ using FwdAs = F32RowK<112, 256 * FWD_SMUL, 32, true>;
 using FwdBs = F32ColK<64, 256 * FWD_SMUL, 32, false>;
 
 // one role of a launch: the exact-fp32 body or its bf16x6 form (BK = the loaders' slab depth)
-template <bool X3, int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int KW = 1, int NSET = 2, int STAGES = 1>
+template <bool X3, int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int KW = 1, int NSET = 2, int NSLAB = 0>
 __device__ __forceinline__ void gemm_role(const GemmParams& p, const int m0, const int n0, const int z, float* smem) {
   if constexpr (X3)
-    dtf_gemm32x3_body<BM, BN, BK, WM, WN, AL, BL, EP, KW, NSET, STAGES>(p, m0, n0, z, reinterpret_cast<char*>(smem));
+    dtf_gemm32x3_body<BM, BN, BK, WM, WN, AL, BL, EP, KW, NSET, NSLAB>(p, m0, n0, z, reinterpret_cast<char*>(smem));
   else dtf_gemm32_body<BM, BN, BK, WM, WN, AL, BL, EP, 2, KW>(p, m0, n0, z, smem);
 }
 template <bool X3, int BM, int BN, int BK, class AL, class BL, int STAGES = 1>
-constexpr int role_lds_floats() {
+constexpr int role_lds_floats() {  // (STAGES: LDS images of a slab, bf16x6 only)
   if constexpr (X3) return dtf_gemm32x3_lds<BM, BN, BK, AL, BL, STAGES>() / 4;
   else return dtf_gemm32_lds<BM, BN, AL, BL>();
 }
@@ -264,6 +264,12 @@ struct GemmTrio32 {
   const float* gB[8];
   int ksets;  // shard modes: K sets of problem 0 (see the kernel)
 };
+// Slab counts for the straight-line path of the bf16x6 body (f32x3_gemm.h; 0 = rolled loop).  Measured with the usual
+// counts (6 for the fc1 data gradient, 4 for the filter gradients): straight-line code keeps both register sets' loads in
+// flight over more of the program, 226 VGPRs instead of 168 -> two workgroups per CU instead of three, launch 19.2 -> 25.4 us
+// (at the 168 cap it spills 280 bytes per lane).  Three resident workgroups hide a slab's round trip better than one
+// workgroup's counted waits do.
+constexpr int TRIO_Q_NSLAB = 0, TRIO_D_NSLAB = 0;
 template <bool X3>
 constexpr int trio32_lds() {
   return role_lds_floats<X3, 112, 64, 32, BdA, BdB>() > role_lds_floats<X3, 128, 64, X3 ? 32 : 20, DwA, DwB>()
@@ -293,11 +299,11 @@ __global__ __launch_bounds__(256, 3) void fc_bwd_trio_f32_kernel(const GemmTrio3
       if (g.q.bsel) {  // "wshard": W_fc1 double-buffered by step parity (workgroup-uniform choice)
         GemmParams q = g.q;
         if (*g.q.bsel & 1) q.B = g.q.B_alt;
-        gemm_role<X3, 112, 64, 32, 1, 4, BdA, BdB, Ep32Atomic>(q, mt * 112, (r % g.q_nt) * 64, r / g.q_nt, smem);
+        gemm_role<X3, 112, 64, 32, 1, 4, BdA, BdB, Ep32Atomic, 1, 2, TRIO_Q_NSLAB>(q, mt * 112, (r % g.q_nt) * 64, r / g.q_nt, smem);
         return;
       }
     }
-    gemm_role<X3, 112, 64, 32, 1, 4, BdA, BdB, Ep32Atomic>(g.q, mt * 112, (r % g.q_nt) * 64, r / g.q_nt, smem);
+    gemm_role<X3, 112, 64, 32, 1, 4, BdA, BdB, Ep32Atomic, 1, 2, TRIO_Q_NSLAB>(g.q, mt * 112, (r % g.q_nt) * 64, r / g.q_nt, smem);
   } else if (id < g.nblk_q + g.nblk0) {
     const int k = id - g.nblk_q;
     if constexpr (MODE == 2 || MODE == 3) {
@@ -316,10 +322,10 @@ __global__ __launch_bounds__(256, 3) void fc_bwd_trio_f32_kernel(const GemmTrio3
       d.B = g.gB;
       gemm_role<X3, 128, 64, DBK, 4, 1, TAg, TBg, Ep32Store>(d, (k % g.mt0) * 128, (k / g.mt0) * 64, 0, smem);
     } else
-      gemm_role<X3, 128, 64, DBK, 4, 1, TA, TB, Ep32Store>(g.d0, (k % g.mt0) * 128, (k / g.mt0) * 64, 0, smem);
+      gemm_role<X3, 128, 64, DBK, 4, 1, TA, TB, Ep32Store, 1, 2, TRIO_D_NSLAB>(g.d0, (k % g.mt0) * 128, (k / g.mt0) * 64, 0, smem);
   } else {
     const int k = id - g.nblk_q - g.nblk0;
-    gemm_role<X3, 128, 16, DBK, 4, 1, TA, TBn, Ep32Store>(g.d1, (k % g.mt1) * 128, (k / g.mt1) * 16, 0, smem);
+    gemm_role<X3, 128, 16, DBK, 4, 1, TA, TBn, Ep32Store, 1, 2, TRIO_D_NSLAB>(g.d1, (k % g.mt1) * 128, (k / g.mt1) * 16, 0, smem);
   }
 }
 

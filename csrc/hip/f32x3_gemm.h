@@ -64,11 +64,11 @@ constexpr int dtf_gemm32x3_lds() {
 
 // NSET register sets of staged slabs: slabs i + 1 .. i + NSET - 1 are in flight while slab i is multiplied (a launch whose
 // workgroups walk few slabs, like the fc1 forward with 7, takes them all at once and pays the memory latency once).
-// STAGES = 2 (with NSET = 2): two LDS images of a slab, like the exact-fp32 body -- slab i + 1 is split and stored while slab
-// i is multiplied, ONE barrier per slab.  Phase stamps of the fc1 forward with one image (scripts/dbg/fc_fwd_stamps.py): per
-// slab ~1400 cycles of split + store + barrier, then ~1500 cycles of fragment reads + 21 MFMAs per wave, strictly in turn.
-// 2 x 45 KB of LDS: for launches of one workgroup per CU (dynamic shared memory above 64 KB).
-template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int KW = 1, int NSET = 2, int STAGES = 1>
+// NSLAB > 0: a K chunk of exactly NSLAB slabs (the launch's usual shape) runs as straight-line code, so that the waits for
+// the staged registers are counted ("all but the N youngest loads"); in the rolled loop the compiler drains EVERY load in
+// flight before each store (see dtf_gemm32x3_ws_body), which turns the two-slab lead of the loads into none.
+// (A second LDS image was measured on the fc1 forward and changed nothing: every wave still splits, then multiplies.)
+template <int BM, int BN, int BK, int WM, int WN, class AL, class BL, class EP, int KW = 1, int NSET = 2, int NSLAB = 0>
 __device__ __forceinline__ void dtf_gemm32x3_body(const GemmParams& p, const int m0, const int n0, const int z,
                                                   char* __restrict__ smem) {
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16, NT = 64 * WM * WN * KW;
@@ -105,86 +105,62 @@ __device__ __forceinline__ void dtf_gemm32x3_body(const GemmParams& p, const int
   for (int s = 0; s < NSET; ++s) {
     al[s].init(p, m0, tid);
     bl[s].init(p, n0, tid);
-    if (s == 0 || kbeg + s * BK < kend) {
-      al[s].load(kbeg + s * BK, kend, tid);
-      bl[s].load(kbeg + s * BK, kend, tid);
-    }
+    // (unconditional: past kend the loaders read address 0 and zero-fill; a run-time condition would cost the counted waits)
+    al[s].load(kbeg + s * BK, kend, tid);
+    bl[s].load(kbeg + s * BK, kend, tid);
   }
-  static_assert(STAGES == 1 || (STAGES == 2 && NSET == 2), "two images go with two register sets");
-  constexpr int STAGE = AX::BYTES + BX::BYTES;
-  if constexpr (STAGES == 2) {
-    AX::store(al[0], As, tid, NT);
-    BX::store(bl[0], Bs, tid, NT);
-    if (kbeg + 2 * BK < kend) {
-      al[0].load(kbeg + 2 * BK, kend, tid);
-      bl[0].load(kbeg + 2 * BK, kend, tid);
-    }
-    __syncthreads();
-  }
-  for (int k = kbeg; k < kend; k += NSET * BK) {
-#pragma unroll
-    for (int s = 0; s < NSET; ++s) {
-      if (s > 0 && k + s * BK >= kend) break;  // (workgroup-uniform)
-      if constexpr (STAGES == 2) {
-        // slab (k + s BK) is in image s; the next one goes from register set 1 - s into image 1 - s (last read before the
-        // barrier that ended the previous slab), and that register set is refilled with the slab after the next two
-        As = smem + s * STAGE;
-        Bs = As + AX::BYTES;
-        DTF_STAMP(si++);
-        if (k + (s + 1) * BK < kend) {
-          AX::store(al[1 - s], smem + (1 - s) * STAGE, tid, NT);
-          BX::store(bl[1 - s], smem + (1 - s) * STAGE + AX::BYTES, tid, NT);
-          if (k + (s + 3) * BK < kend) {
-            al[1 - s].load(k + (s + 3) * BK, kend, tid);
-            bl[1 - s].load(k + (s + 3) * BK, kend, tid);
-          }
-        }
-        DTF_STAMP(si++);
-      } else {
-        if (k + s * BK > kbeg) __syncthreads();  // the previous slab has been multiplied
-        DTF_STAMP(si++);
-        AX::store(al[s], As, tid, NT);
-        BX::store(bl[s], Bs, tid, NT);
-        if (k + (s + NSET) * BK < kend) {
-          al[s].load(k + (s + NSET) * BK, kend, tid);
-          bl[s].load(k + (s + NSET) * BK, kend, tid);
-        }
-        __syncthreads();
-        DTF_STAMP(si++);
-      }
-#pragma unroll
-      for (int g = 0; g < BK / 32; ++g) {
-        // One A plane and two B planes live at a time (all nine would not fit next to the staged slabs' registers in the
-        // 3-workgroups-per-CU launches): (a2 b0) (a0 b2) (a0 b0) | (a0 b1) (a1 b1) (a1 b0); two wave sets take a half each.
-        bf16x8 a[TM], b0[TN], bx[TN];
-        auto lda = [&](const int pl) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i) a[i] = AX::frag(As + pl * AX::PLANE, wm * (BM / WM) + i * 16, r, q, g);
-        };
-        auto ldb = [&](bf16x8 (&b)[TN], const int pl) {
-#pragma unroll
-          for (int j = 0; j < TN; ++j) b[j] = BX::frag(Bs + pl * BX::PLANE, wn * (BN / WN) + j * 16, r, q, g);
-        };
+  // one slab: register set S holds it; HASN: slab i + NSET exists (its loads go into the set that has just been stored)
 #define X3G_PROD(BV)                                                              \
-  _Pragma("unroll") for (int i = 0; i < TM; ++i)                                  \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = mfma16bf(a[i], BV[j], acc[i][j]);
-        if (KW == 1 || ks == 0) {
-          lda(2); ldb(b0, 0); X3G_PROD(b0)
-          lda(0); ldb(bx, 2); X3G_PROD(bx) X3G_PROD(b0)
-        }
-        if (KW == 1) {
-          __builtin_amdgcn_sched_barrier(0);  // (keeps the second half's fragment reads from being hoisted: register room)
-          ldb(bx, 1); X3G_PROD(bx)
-          lda(1); X3G_PROD(bx) X3G_PROD(b0)
-        } else if (ks == 1) {
-          lda(0); ldb(bx, 1); X3G_PROD(bx)
-          lda(1); ldb(b0, 0); X3G_PROD(bx) X3G_PROD(b0)
-        }
-#undef X3G_PROD
+  _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_)                               \
+      _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] = mfma16bf(a[i_], BV[j_], acc[i_][j_]);
+#define X3G_LDA(PL) _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) a[i_] = AX::frag(As + (PL) * AX::PLANE, wm * (BM / WM) + i_ * 16, r, q, g);
+#define X3G_LDB(BV, PL) _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) BV[j_] = BX::frag(Bs + (PL) * BX::PLANE, wn * (BN / WN) + j_ * 16, r, q, g);
+#define X3G_SLAB(S, FIRST, HASN, KK)                                                                             \
+  do {                                                                                                           \
+    if (!(FIRST)) __syncthreads(); /* the previous slab has been multiplied */                                   \
+    DTF_STAMP(si++);                                                                                             \
+    AX::store(al[S], As, tid, NT);                                                                               \
+    BX::store(bl[S], Bs, tid, NT);                                                                               \
+    if (HASN) {                                                                                                  \
+      al[S].load((KK) + NSET * BK, kend, tid);                                                                   \
+      bl[S].load((KK) + NSET * BK, kend, tid);                                                                   \
+    }                                                                                                            \
+    __syncthreads();                                                                                             \
+    DTF_STAMP(si++);                                                                                             \
+    _Pragma("unroll") for (int g = 0; g < BK / 32; ++g) {                                                        \
+      /* One A plane and two B planes live at a time (all nine would not fit next to the staged slabs' registers in the */ \
+      /* 3-workgroups-per-CU launches): (a2 b0) (a0 b2) (a0 b0) | (a0 b1) (a1 b1) (a1 b0); two wave sets take a half each. */ \
+      bf16x8 a[TM], b0[TN], bx[TN];                                                                              \
+      if (KW == 1 || ks == 0) {                                                                                  \
+        X3G_LDA(2) X3G_LDB(b0, 0) X3G_PROD(b0)                                                                   \
+        X3G_LDA(0) X3G_LDB(bx, 2) X3G_PROD(bx) X3G_PROD(b0)                                                      \
+      }                                                                                                          \
+      if (KW == 1) {                                                                                             \
+        __builtin_amdgcn_sched_barrier(0); /* (keeps the second half's fragment reads from being hoisted: register room) */ \
+        X3G_LDB(bx, 1) X3G_PROD(bx)                                                                              \
+        X3G_LDA(1) X3G_PROD(bx) X3G_PROD(b0)                                                                     \
+      } else if (ks == 1) {                                                                                      \
+        X3G_LDA(0) X3G_LDB(bx, 1) X3G_PROD(bx)                                                                   \
+        X3G_LDA(1) X3G_LDB(b0, 0) X3G_PROD(bx) X3G_PROD(b0)                                                      \
+      }                                                                                                          \
+    }                                                                                                            \
+  } while (0)
+  if (NSLAB > 0 && kend - kbeg > (NSLAB - 1) * BK && kend - kbeg <= NSLAB * BK) {  // (workgroup-uniform)
+#pragma unroll
+    for (int i = 0; i < (NSLAB > 0 ? NSLAB : 1); ++i) X3G_SLAB(i % NSET, i == 0, i + NSET < NSLAB, kbeg + i * BK);
+  } else {
+    for (int k = kbeg; k < kend; k += NSET * BK) {
+#pragma unroll
+      for (int s = 0; s < NSET; ++s) {
+        if (s > 0 && k + s * BK >= kend) break;  // (workgroup-uniform)
+        X3G_SLAB(s, k + s * BK == kbeg, k + (s + NSET) * BK < kend, k + s * BK);
       }
-      if constexpr (STAGES == 2) __syncthreads();  // slab multiplied, next image stored
     }
   }
+#undef X3G_SLAB
+#undef X3G_LDA
+#undef X3G_LDB
+#undef X3G_PROD
   DTF_STAMP(si++);
   // ---- assemble the output image in LDS (the staged slab is dead): set KW-1 stores, the others add in descending order
   float* Cs = reinterpret_cast<float*>(smem);
