@@ -17,14 +17,20 @@ __device__ __forceinline__ f32x4 mfma16bf(bf16x8 a, bf16x8 b, f32x4 c) {
 
 struct Bf3Pair { uint32_t p0, p1, p2; };  // (lo, hi) of two values, per plane
 
+// (two values per v_cvt_pk_bf16_f32 and per v_pk_add_f32: 10 VALU operations per pair; converting the values one by one and
+// OR-ing the halves together, as pack_bf2 compiles, takes 15)
+typedef __bf16 bf16x2_x3 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf3_pack2(const f32x2 v) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_x3));
+}
 __device__ __forceinline__ Bf3Pair bf3_split2(float lo, float hi) {
   Bf3Pair o;
-  o.p0 = pack_bf2(lo, hi);
-  float rl = lo - __uint_as_float(o.p0 << 16), rh = hi - __uint_as_float(o.p0 & 0xffff0000u);
-  o.p1 = pack_bf2(rl, rh);
-  rl -= __uint_as_float(o.p1 << 16);
-  rh -= __uint_as_float(o.p1 & 0xffff0000u);
-  o.p2 = pack_bf2(rl, rh);
+  f32x2 r = {lo, hi};
+  o.p0 = bf3_pack2(r);
+  r = r - f32x2{__uint_as_float(o.p0 << 16), __uint_as_float(o.p0 & 0xffff0000u)};
+  o.p1 = bf3_pack2(r);
+  r = r - f32x2{__uint_as_float(o.p1 << 16), __uint_as_float(o.p1 & 0xffff0000u)};
+  o.p2 = bf3_pack2(r);
   return o;
 }
 
