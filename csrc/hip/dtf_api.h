@@ -114,6 +114,7 @@ DTF_API int dtf_ipc_sync_gather_pushed(const void* comm, void* dst, long bytes, 
 DTF_API int dtf_ipc_push_desc(const void* comm, float* src, long n_floats, struct ShardPush* push);
 DTF_API int dtf_fc_fwd_f32_push(const float* X, const float* W, float* out, int M, int N, int K, int splits,
                                 const struct ShardPush* push, hipStream_t st);
+DTF_API int dtf_ipc_reset_errors(const void* comm);
 DTF_API int dtf_ipc_sync_gather_slice(const void* comm, void* dst, long bytes, int rows, int pitch4, int lo4, int w4,
                                       long tail_off4, long tail_n4, int blocks_per_peer, hipStream_t st);
 DTF_API int dtf_ipc_shard_desc(const void* comm, long lo_floats, long n_floats, float* src, int zero_src,

@@ -442,6 +442,19 @@ DTF_API void* dtf_ipc_result_ptr(void* base, long n_max) {
   return reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(base) + HDR_BYTES) + n_max;
 }
 
+// Forget the expired waits counted so far: this rank's count, the copy it published to the peers and the total it has acted
+// on.  Collective in effect: every rank calls it (device idle) and the callers meet at a barrier before the next exchange,
+// otherwise a rank would see a total that differs from the one it acted on and skip a step.
+DTF_API int dtf_ipc_reset_errors(const void* comm) {
+  const IpcComm& c = *reinterpret_cast<const IpcComm*>(comm);
+  if (c.world < 1 || c.world > MAX_RANKS || c.rank < 0 || c.rank >= c.world || c.error != c.epoch + 1) return -22;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemset(c.error, 0, 4) != hipSuccess || hipMemset(c.epoch + 3, 0, 4) != hipSuccess ||
+      hipMemset(c.base[c.rank] + 128, 0, 4) != hipSuccess)  // (err_pub of this rank's header)
+    return -1;
+  return hipDeviceSynchronize() == hipSuccess ? 0 : -1;
+}
+
 // Barrier over the ranks of `comm` on the stream (one wave): bumps the epoch, tells every peer, waits for every peer.
 // What it orders is up to the caller: here, "my fc1 operands for this step are in my stage buffer" (their producers
 // write them there directly, stream-ordered before this kernel).

@@ -290,17 +290,27 @@ class StartupMixin:
                     return t.cpu().tolist()
 
             set_timeouts(2.0)  # a schedule that cannot make progress on this machine must cost seconds, not minutes
-            times, off, broken = sel.run_trials(cands, Ops(), forced=forced, timed=timed, note=self._note, budget_s=budget)
+            ops = Ops()
+            times, off, broken = sel.run_trials(cands, ops, forced=forced, timed=timed, note=self._note, budget_s=budget)
             self.schedule_us = {c: round(v, 1) for c, v in zip(cands, times)} if timed else None
             self.schedule_deviation = {c: float("%.3g" % v) for c, v in zip(cands, off)}
             set_timeouts(op_timeout)
-            cands = [sel.choose(cands, times, off, broken, forced)]
+            try:
+                cands = [sel.choose(cands, times, off, broken, forced)]
+            except RuntimeError as err:  # (with what the trials saw on this rank)
+                # (what the trials saw on this rank: norms of the first-step gradients, the exchanges' device words)
+                seen = ["%s |g| %.4g" % (c, float(g.norm())) for c, g in zip(cands, getattr(ops, "grads", [])) if g is not None]
+                words = [c._words.tolist() for c in (self.ipc, self.ipc_act, self.ipc_w) if c is not None]
+                raise RuntimeError("%s; rank %d: first-step gradients %s; [epoch, errors, ticket, seen, tag, ..] of the "
+                                   "exchanges %s; start-up log: %s" % (err, self.rank, ", ".join(seen), words,
+                                                                       " | ".join(self.startup_log))) from None
             # the dropped candidates' expired waits are in the log and the state is the snapshot again: the chosen schedule
             # starts with a clean count (ensure_healthy() / check_transport() act on ANY expiry since then)
             if broken:
                 for comm in (self.ipc, self.ipc_act, self.ipc_w):
                     if comm is not None:
                         comm.reset_errors()
+                dist.barrier(group=self.group)
         use(cands[0])
         if self.rank == 0:
             print("data-parallel step schedule: %s %s gradient deviation from the staged all-reduce %s" % (

@@ -37,6 +37,7 @@ def _signatures(lib) -> None:
     lib.dtf_ipc_allreduce.argtypes, lib.dtf_ipc_allreduce.restype = [P, P, P, L, I, P], I
     lib.dtf_ipc_allreduce_zc.argtypes, lib.dtf_ipc_allreduce_zc.restype = [P, P, L, L, L, I, P], I
     lib.dtf_ipc_sync.argtypes, lib.dtf_ipc_sync.restype = [P, P], I
+    lib.dtf_ipc_reset_errors.argtypes, lib.dtf_ipc_reset_errors.restype = [P], I
     lib.dtf_ipc_all_gather.argtypes, lib.dtf_ipc_all_gather.restype = [P, P, P, L, I, P], I
     lib.dtf_ipc_broadcast.argtypes, lib.dtf_ipc_broadcast.restype = [P, P, L, I, I, P], I
     lib.dtf_ipc_allreduce_oneshot.argtypes, lib.dtf_ipc_allreduce_oneshot.restype = [P, P, P, L, I, P], I
@@ -208,17 +209,21 @@ class IpcAllReduce:
             self.comm.timeout_ticks = int(timeout_s * 100e6)
 
     def errors(self) -> int:
-        """Number of waits that timed out so far (synchronises)."""
+        """Number of waits that timed out so far.  Synchronises the DEVICE: the count is written by kernels on the engine's
+        stream, and reading it from another stream while a step is still spinning in a wait returns the old count (seen
+        with three ranks sharing a GPU: the reference schedule's first trial step ran into the 2 s bound after the count
+        had been read, the step was skipped, and its zero "gradient" became the reference)."""
+        torch.cuda.synchronize(self.device)
         return int(self._words[1].item())
 
     def reset_errors(self) -> None:
         """Forget the expired waits counted so far (synchronises).  For the end of the start-up trials: a candidate schedule
         whose waits expired was dropped and the training state restored, so its expiries must not make `ensure_healthy()`
-        abandon the schedule that was chosen."""
+        abandon the schedule that was chosen.  Clears this rank's count, the copy the peers read and the total this rank
+        has acted on; every rank calls it, and the caller puts a barrier of the process group behind it (a rank that ran
+        ahead would see a total different from the one it acted on, and skip a step)."""
         if self.comm is not None:
-            torch.cuda.synchronize(self.device)
-            self._words[1:2].zero_()
-            torch.cuda.synchronize(self.device)
+            native.check(self.lib.dtf_ipc_reset_errors(C.byref(self.comm)), "ipc_reset_errors")
 
     def self_test(self, n: int = 0, rounds: int = 3) -> bool:
         """Reduce random data ``rounds`` times and compare with the process group's own all-reduce; all ranks get the

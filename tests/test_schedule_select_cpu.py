@@ -12,8 +12,9 @@ from distributed_tensorflow_amd.parallel import schedule_select as sel
 class FakeOps(sel.TrialOps):
     """A machine described by a table: us/step per schedule, which captures fail, whose waits expire, whose gradient is off."""
 
-    def __init__(self, us, capture_fail=(), expire=(), wrong=(), budget_after=None, ranks_disagree=None):
+    def __init__(self, us, capture_fail=(), expire=(), wrong=(), budget_after=None, ranks_disagree=None, expire_once=()):
         self.us, self.capture_fail, self.expire, self.wrong = us, set(capture_fail), set(expire), set(wrong)
+        self.expire_once = set(expire_once)   # a wait expires in the first try only (ranks time-sharing a GPU)
         self.budget_after = budget_after      # over budget once this many candidates have been used
         self.ranks_disagree = ranks_disagree  # {name: us on the slowest rank}: the max over ranks decides
         self.cur, self.used, self.restored, self.log = None, [], 0, []
@@ -26,9 +27,14 @@ class FakeOps(sel.TrialOps):
         return self.cur not in self.capture_fail
 
     def first_step(self):
+        if self.cur in self.expire_once:
+            return 0.0                        # (the step was skipped: no gradient)
         return 2.0 if self.cur in self.wrong else 1.0
 
     def wait_expired(self):
+        if self.cur in self.expire_once:
+            self.expire_once.discard(self.cur)
+            return True
         return self.cur in self.expire
 
     def time_steps(self):
@@ -162,3 +168,20 @@ def test_wait_expiring_during_the_timed_steps_drops_the_candidate():
     assert len(times) == len(off) == len(cands) and ops.used == cands and ops.restored == len(cands)
     assert sel.choose(cands, times, off, broken) == "ipc-gather"
     assert any("ipc-shard" in l and "timed steps" in l for l in ops.log)
+
+
+def test_reference_whose_wait_expired_once_is_tried_again():
+    """Seen with three ranks time-sharing one GPU: the reference schedule's first trial step ran into the 2 s bound, the step
+    was skipped, and its zero gradient made every candidate look wrong.  The reference gets one more try from the snapshot;
+    any other candidate is simply dropped."""
+    cands = sel.candidates(**ALL)
+    ops = FakeOps(US8, expire_once={"ipc-inline", "ipc-gather"})
+    times, off, broken = _run(ops, cands)
+    assert broken == {"ipc-gather"} and off[cands.index("ipc-inline")] == 0.0 and off[0] == 0.0
+    assert sel.choose(cands, times, off, broken) == "ipc-shard"
+    assert ops.restored == len(cands) + 1 and any("trying once more" in m for m in ops.log)
+    # forced schedule, reference hiccups once: still validated and chosen
+    cands = sel.trial_list(sel.candidates(**dict(ALL, forced="ipc-shard")))
+    ops = FakeOps(US8, expire_once={"ipc-inline"})
+    times, off, broken = _run(ops, cands, forced="ipc-shard", timed=False)
+    assert not broken and sel.choose(cands, times, off, broken, forced="ipc-shard") == "ipc-shard"
