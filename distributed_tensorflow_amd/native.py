@@ -220,10 +220,12 @@ def f32_emulation_note() -> Optional[str]:
         return None
     return ("bf16x6: " + ", ".join(F32_EMULATED_KERNELS) + " take each fp32 operand as three bf16 planes and each product as "
             "six v_mfma_f32_16x16x32_bf16 (fp32 accumulate); same float64-oracle tolerances as the exact-fp32 MFMA kernels "
-            "(tests/test_f32_gpu.py, 1e-5 per kernel, 1e-4 step gradients); everything else is plain fp32")
+            "(tests/test_f32_gpu.py, 1e-5 per kernel, 1e-4 step gradients); conv1, the conv filter gradients, the loss head and "
+            "Adam are plain fp32")
 
 
-F32_EMULATED_KERNELS = ("conv2 forward", "conv2 data gradient")
+F32_EMULATED_KERNELS = ("conv2 forward", "conv2 data gradient", "fc1 forward", "fc1 data gradient",
+                        "fc1 / fc2 filter gradients")
 
 
 # signatures of optional kernels (Inception pools / image ops / stats / retrain head) registered by

@@ -35,7 +35,7 @@ def _kernel_bodies(src):
             name, buf = line.split(":")[0], []
         elif name is not None:
             buf.append(line)
-            if "s_endpgm" in line:
+            if line.startswith(".Lfunc_end"):  # (not the first s_endpgm: a wave-specialised kernel has one per role)
                 out[name] = "\n".join(buf)
                 name = None
     return out
