@@ -116,9 +116,18 @@ out = {"rank": rank, "skipped": eng.skipped_steps(), "unchanged": bool(torch.equ
        "step_before": step0, "step_after": int(eng.step_t.item()), "errors": tr.transport_errors(),
        "grad_discarded": float(eng.G[eng.layout["b_fc1"][0]:].abs().max().item()) == 0.0}
 dist.barrier()
+if os.environ.get("DTF_TEST_AFTER") == "reset":
+    # what the start-up does after dropping a candidate schedule whose wait expired: forget the expiry on every rank
+    for c in (tr.ipc, tr.ipc_act, tr.ipc_w):
+        if c is not None:
+            c.reset_errors()
+    dist.barrier()
 out["healthy"] = tr.ensure_healthy()            # collective: agrees on the failure, falls back, re-broadcasts the state
 out["transport_after"] = tr.comm
 tr.train_steps(5)
+tr.sync_params()
+torch.cuda.synchronize()
+out["skipped_after"], out["errors_after"] = eng.skipped_steps(), tr.transport_errors()
 out["in_sync"] = tr.replicas_in_sync()
 out["host_step"], out["device_step"] = eng.global_step, int(eng.step_t.item())
 json.dump(out, open(os.path.join(sys.argv[2], "r%d.json" % rank), "w"))  # (two ranks' stdout lines can interleave)
@@ -148,6 +157,30 @@ def test_expired_ipc_wait_skips_the_optimizer_on_every_rank(tmp_path, schedule):
         assert o["healthy"] is False and o["transport_after"] == "rccl" and o["in_sync"] is True, o
         assert o["host_step"] == o["device_step"] == o["step_before"] + 5, o
     assert max(o["errors"] for o in res) >= 1 and min(o["errors"] for o in res) == 0, res
+
+
+def test_cleared_expiry_count_lets_the_ipc_schedule_continue_without_a_spurious_skip(tmp_path):
+    """``IpcAllReduce.reset_errors()`` (start-up, after a candidate schedule with an expired wait was dropped): this rank's
+    count, the copy the peers read and the total each rank has acted on are cleared together, so the steps that follow are
+    applied on every rank (a stale published count would differ from the total acted on and skip one more step on one
+    rank), the trainer stays on the IPC transport and the replicas stay in sync."""
+    script = tmp_path / "stalled_peer.py"
+    script.write_text(_STALLED_PEER)
+    env = dict(os.environ, MASTER_PORT="29644", HSA_ENABLE_IPC_MODE_LEGACY="0", DTF_DP_SCHEDULE="ipc-inline",
+               DTF_IPC_TIMEOUT_S="0.4", DTF_TEST_AFTER="reset")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29644", str(script), REPO, str(tmp_path)]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    res = [json.load(open(str(tmp_path / ("r%d.json" % k)))) for k in range(2)]
+    assert max(o["errors"] for o in res) >= 1, res   # (the stalled step did expire somewhere)
+    for o in res:
+        assert o["skipped"] == 1 and o["unchanged"], o
+        assert o["healthy"] is True and o["transport_after"] == "ipc", o
+        assert o["skipped_after"] == 1 and o["errors_after"] == 0 and o["in_sync"] is True, o
+        # (the host's count includes the skipped step; the start-up restores it with the snapshot, `ensure_healthy()` on its
+        # fallback path re-reads it from the device)
+        assert o["device_step"] == o["step_before"] + 5 and o["host_step"] == o["device_step"] + 1, o
 
 
 _CHECKED = r"""
