@@ -251,16 +251,17 @@ class StartupMixin:
                         if self.wait_expired():
                             return math.inf
                     dist.barrier(group=trainer.group)
-                    t0 = time.perf_counter()
-                    done = 0
+                    done, spent = 0, 0.0
                     while done < steps:
                         n = min(16, steps - done)
+                        t0 = time.perf_counter()
                         trainer.train_steps(n)
                         e.stream.synchronize()
+                        spent += time.perf_counter() - t0
                         done += n
-                        if self.wait_expired():
+                        if self.wait_expired():  # (also the barrier in front of the next chunk; not part of the timing)
                             return math.inf
-                    return (time.perf_counter() - t0) / steps * 1e6
+                    return spent / steps * 1e6
 
                 def restore(self):
                     with trainer._ctx():
