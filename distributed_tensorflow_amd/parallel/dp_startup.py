@@ -5,6 +5,7 @@ Reference behaviour being replaced: a fixed star of gRPC channels to the paramet
 (``/root/reference/demo2/train.py:13-29``); there is nothing to choose."""
 from __future__ import annotations
 
+import math
 import os
 
 import torch
