@@ -66,6 +66,17 @@ DTF_API int dtf_fc_fwd_f32(const float* X, const float* W, float* out, int M, in
 DTF_API int dtf_fc_bwd_data_f32(const float* dY, const float* W, float* dX, int M, int N, int K, int splits, hipStream_t st);
 DTF_API int dtf_fc_dw_f32(const float* X, int ldx, const float* dY, int ldy, float* dW, int M, int N, int K, int splits,
                           hipStream_t st);
+DTF_API int dtf_fc_bwd_trio_f32_bias(const float* X0, const float* dY0, float* dW0, int M0, int N0, const float* X1,
+                                     const float* dY1, int ldy1, float* dW1, int M1, int N1, int K, const float* dYq,
+                                     const float* Wq, float* dXq, int Mq, int Nq, int Kq, int splits, const void* const* gA,
+                                     const void* const* gB, int granks, float* db0, float* db1, float* metrics,
+                                     int metrics_ring, const int* step_ptr, hipStream_t st);
+DTF_API int dtf_fc_bwd_trio_f32_shard_bias(const float* X1, const float* dY1, int ldy1, float* dW1, int M1, int N1, int K,
+                                           const float* dYq, const float* Wq, float* dXq, int Mq, int Nq, int Kq, int splits,
+                                           const void* const* gA, const void* const* gB, int granks, int ranks_per_set,
+                                           int lda0, float* dW0_slice, int M0_slice, int N0, const float* Wq_alt,
+                                           const int* wq_sel, float* db0, float* db1, float* metrics, int metrics_ring,
+                                           const int* step_ptr, hipStream_t st);
 DTF_API int dtf_fc_bwd_trio_f32(const float* X0, const float* dY0, float* dW0, int M0, int N0, const float* X1,
                                 const float* dY1, int ldy1, float* dW1, int M1, int N1, int K, const float* dYq,
                                 const float* Wq, float* dXq, int Mq, int Nq, int Kq, int splits, const void* const* gA,

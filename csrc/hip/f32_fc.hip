@@ -263,6 +263,17 @@ struct GemmTrio32 {
   const float* gA[8];
   const float* gB[8];
   int ksets;  // shard modes: K sets of problem 0 (see the kernel)
+  // optional bias gradients as column sums, in row order (stores, no atomics): db0[j] = sum_m dYq[m][j] (fc1), db1[j] = sum_k
+  // dY1[k][j] (fc2); a few workgroups behind problem 1.  The loss head then adds nothing to them (its 100 workgroups' atomics
+  // on the same 65 cache lines cost 2.4 us of its 10.3).
+  float* db0;
+  float* db1;
+  int nblk1;
+  // optional, with the above: columns 12 / 13 of dY1 (pitch 16) hold the rows' loss and hit count (head_kernel): their sums
+  // are added to the step's metrics slot
+  float* metrics;
+  const int* step_ptr;
+  int ring;
 };
 // Slab counts for the straight-line path of the bf16x6 body (f32x3_gemm.h; 0 = rolled loop).  Measured with the usual
 // counts (6 for the fc1 data gradient, 4 for the filter gradients): straight-line code keeps both register sets' loads in
@@ -323,9 +334,34 @@ __global__ __launch_bounds__(256, 3) void fc_bwd_trio_f32_kernel(const GemmTrio3
       gemm_role<X3, 128, 64, DBK, 4, 1, TAg, TBg, Ep32Store>(d, (k % g.mt0) * 128, (k / g.mt0) * 64, 0, smem);
     } else
       gemm_role<X3, 128, 64, DBK, 4, 1, TA, TB, Ep32Store, 1, 2, TRIO_D_NSLAB>(g.d0, (k % g.mt0) * 128, (k / g.mt0) * 64, 0, smem);
-  } else {
+  } else if (id < g.nblk_q + g.nblk0 + g.nblk1) {
     const int k = id - g.nblk_q - g.nblk0;
     gemm_role<X3, 128, 16, DBK, 4, 1, TA, TBn, Ep32Store, 1, 2, TRIO_D_NSLAB>(g.d1, (k % g.mt1) * 128, (k / g.mt1) * 16, 0, smem);
+  } else {
+    // bias gradients: one column per thread, rows summed in order (deterministic; every load is independent of the sum)
+    const int w = id - g.nblk_q - g.nblk0 - g.nblk1, tid = threadIdx.x;
+    const int nb0 = (g.q.K + 255) / 256;
+    if (w < nb0) {
+      const int j = w * 256 + tid;
+      if (j < g.q.K) {
+        const float* __restrict__ src = reinterpret_cast<const float*>(g.q.A) + j;
+        float s = 0.f;
+#pragma unroll 10
+        for (int m = 0; m < g.q.M; ++m) s += src[(long)m * g.q.lda];
+        g.db0[j] = s;
+      }
+    } else if (tid < g.d1.N || (g.metrics && (tid == 12 || tid == 13))) {
+      const float* __restrict__ src = reinterpret_cast<const float*>(g.d1.B) + tid;
+      float s = 0.f;
+#pragma unroll 10
+      for (int k = 0; k < g.d1.K; ++k) s += src[(long)k * g.d1.ldb];
+      if (tid < g.d1.N) {
+        g.db1[tid] = s;
+      } else {  // (the only writer of the slot in a training step: the head left the per-row values to this launch)
+        const int step = g.step_ptr ? *g.step_ptr : 0;
+        g.metrics[(g.ring > 0 ? 2 * (step % g.ring) : 0) + tid - 12] += s;
+      }
+    }
   }
 }
 
@@ -347,10 +383,13 @@ DTF_API void dtf_dbg_set_trio_stamps(void* p) { g_trio_stamps = p; }
 // dX[Mq][Nq] += dYq[Mq][Kq] * Wq[Nq][Kq]^T (split over K, dX pre-zeroed) in one launch.  K = batch.
 // With granks > 0, dW0 = sum over r < granks of gA[r]^T gB[r] instead (operand pairs of the shapes of X0 / dY0, e.g. the
 // ranks' exchanged activations; X0 / dY0 themselves are then unused); K must be a multiple of 20 then.
-DTF_API int dtf_fc_bwd_trio_f32(const float* X0, const float* dY0, float* dW0, int M0, int N0, const float* X1,
-                                const float* dY1, int ldy1, float* dW1, int M1, int N1, int K, const float* dYq,
-                                const float* Wq, float* dXq, int Mq, int Nq, int Kq, int splits, const void* const* gA,
-                                const void* const* gB, int granks, hipStream_t st) {
+// db0 / db1 (both or neither): also the bias gradients db0[Kq] = column sums of dYq, db1[N1] = column sums of dY1 (stored).
+DTF_API int dtf_fc_bwd_trio_f32_bias(const float* X0, const float* dY0, float* dW0, int M0, int N0, const float* X1,
+                                     const float* dY1, int ldy1, float* dW1, int M1, int N1, int K, const float* dYq,
+                                     const float* Wq, float* dXq, int Mq, int Nq, int Kq, int splits, const void* const* gA,
+                                     const void* const* gB, int granks, float* db0, float* db1, float* metrics,
+                                     int metrics_ring, const int* step_ptr, hipStream_t st) {
+  if ((db0 != nullptr) != (db1 != nullptr) || (metrics && (!db0 || ldy1 < 16 || N1 > 12))) return ERR_SHAPE;
   if (M0 <= 0 || N0 <= 0 || M1 <= 0 || N1 <= 0 || K <= 0 || M0 % 4 || N0 % 4 || M1 % 4 || N1 > 16 || ldy1 % 4 || ldy1 < N1)
     return ERR_SHAPE;
   if (Mq <= 0 || Nq <= 0 || Kq <= 0 || Kq % 4 || splits < 2) return ERR_SHAPE;
@@ -372,7 +411,13 @@ DTF_API int dtf_fc_bwd_trio_f32(const float* X0, const float* dY0, float* dW0, i
   g.mt0 = dtf_cdiv(M0, 128);
   g.mt1 = dtf_cdiv(M1, 128);
   g.nblk0 = g.mt0 * dtf_cdiv(N0, 64);
-  const int nblk1 = g.mt1 * dtf_cdiv(N1, 16);
+  g.nblk1 = g.mt1 * dtf_cdiv(N1, 16);
+  g.db0 = db0;
+  g.db1 = db1;
+  g.metrics = metrics;
+  g.ring = metrics_ring;
+  g.step_ptr = step_ptr;
+  const int nblk1 = g.nblk1 + (db0 ? dtf_cdiv(Kq, 256) + 1 : 0);
   g.q = base_params32(dYq, Wq, dXq, Mq, Nq, Kq, Kq, Kq, Nq, splits, 32);
   const int s = eff_splits32(g.q);
   if (s < 2) return ERR_SHAPE;  // the atomic epilogue is the only one instantiated here
@@ -384,6 +429,13 @@ DTF_API int dtf_fc_bwd_trio_f32(const float* X0, const float* dY0, float* dW0, i
 #endif
   return granks > 0 ? launch_trio32<1>(g, g.nblk_q + g.nblk0 + nblk1, st) : launch_trio32<0>(g, g.nblk_q + g.nblk0 + nblk1, st);
 }
+DTF_API int dtf_fc_bwd_trio_f32(const float* X0, const float* dY0, float* dW0, int M0, int N0, const float* X1,
+                                const float* dY1, int ldy1, float* dW1, int M1, int N1, int K, const float* dYq,
+                                const float* Wq, float* dXq, int Mq, int Nq, int Kq, int splits, const void* const* gA,
+                                const void* const* gB, int granks, hipStream_t st) {
+  return dtf_fc_bwd_trio_f32_bias(X0, dY0, dW0, M0, N0, X1, dY1, ldy1, dW1, M1, N1, K, dYq, Wq, dXq, Mq, Nq, Kq, splits, gA, gB,
+                                  granks, nullptr, nullptr, nullptr, 0, nullptr, st);
+}
 
 // The same launch for the "shard" data-parallel schedule (shard_body.h):
 //   dW0_slice[M0_slice][N0] += sum over r < granks of gA[r]^T gB[r]
@@ -391,11 +443,13 @@ DTF_API int dtf_fc_bwd_trio_f32(const float* X0, const float* dY0, float* dW0, i
 // gB[r]: rank r's [K][N0] block.  K (a multiple of 20) is split into sets of ranks_per_set source ranks: with more than one
 // set the sets accumulate with atomics and dW0_slice must be zero on entry (the push that follows re-zeroes it); one set
 // stores.  Problems 1 and q as in dtf_fc_bwd_trio_f32; Wq_alt / wq_sel (both or neither): Wq_alt replaces Wq when *wq_sel is odd.
-DTF_API int dtf_fc_bwd_trio_f32_shard(const float* X1, const float* dY1, int ldy1, float* dW1, int M1, int N1, int K,
-                                      const float* dYq, const float* Wq, float* dXq, int Mq, int Nq, int Kq, int splits,
-                                      const void* const* gA, const void* const* gB, int granks, int ranks_per_set, int lda0,
-                                      float* dW0_slice, int M0_slice, int N0, const float* Wq_alt, const int* wq_sel,
-                                      hipStream_t st) {
+DTF_API int dtf_fc_bwd_trio_f32_shard_bias(const float* X1, const float* dY1, int ldy1, float* dW1, int M1, int N1, int K,
+                                           const float* dYq, const float* Wq, float* dXq, int Mq, int Nq, int Kq, int splits,
+                                           const void* const* gA, const void* const* gB, int granks, int ranks_per_set,
+                                           int lda0, float* dW0_slice, int M0_slice, int N0, const float* Wq_alt,
+                                           const int* wq_sel, float* db0, float* db1, float* metrics, int metrics_ring,
+                                           const int* step_ptr, hipStream_t st) {
+  if ((db0 != nullptr) != (db1 != nullptr) || (metrics && (!db0 || ldy1 < 16 || N1 > 12))) return ERR_SHAPE;
   if ((Wq_alt != nullptr) != (wq_sel != nullptr) || (Wq_alt && !aligned16(Wq_alt))) return ERR_SHAPE;
   if (M0_slice <= 0 || N0 <= 0 || M1 <= 0 || N1 <= 0 || K <= 0 || M0_slice % 4 || N0 % 4 || M1 % 4 || N1 > 16 || ldy1 % 4 ||
       ldy1 < N1 || lda0 % 4 || lda0 < M0_slice)
@@ -420,7 +474,13 @@ DTF_API int dtf_fc_bwd_trio_f32_shard(const float* X1, const float* dY1, int ldy
   g.mt0 = dtf_cdiv(M0_slice, 128);
   g.mt1 = dtf_cdiv(M1, 128);
   g.nblk0 = g.mt0 * dtf_cdiv(N0, 64) * g.ksets;
-  const int nblk1 = g.mt1 * dtf_cdiv(N1, 16);
+  g.nblk1 = g.mt1 * dtf_cdiv(N1, 16);
+  g.db0 = db0;
+  g.db1 = db1;
+  g.metrics = metrics;
+  g.ring = metrics_ring;
+  g.step_ptr = step_ptr;
+  const int nblk1 = g.nblk1 + (db0 ? dtf_cdiv(Kq, 256) + 1 : 0);
   g.q = base_params32(dYq, Wq, dXq, Mq, Nq, Kq, Kq, Kq, Nq, splits, 32);
   g.q.bsel = wq_sel;  // (optional: Wq double-buffered by the parity of *wq_sel)
   g.q.B_alt = Wq_alt;
@@ -433,4 +493,13 @@ DTF_API int dtf_fc_bwd_trio_f32_shard(const float* X1, const float* dY1, int ldy
   g.q.aux_out = g.d0.aux_out = g.d1.aux_out = g_trio_stamps;
 #endif
   return g.ksets > 1 ? launch_trio32<2>(g, g.nblk_q + g.nblk0 + nblk1, st) : launch_trio32<3>(g, g.nblk_q + g.nblk0 + nblk1, st);
+}
+DTF_API int dtf_fc_bwd_trio_f32_shard(const float* X1, const float* dY1, int ldy1, float* dW1, int M1, int N1, int K,
+                                      const float* dYq, const float* Wq, float* dXq, int Mq, int Nq, int Kq, int splits,
+                                      const void* const* gA, const void* const* gB, int granks, int ranks_per_set, int lda0,
+                                      float* dW0_slice, int M0_slice, int N0, const float* Wq_alt, const int* wq_sel,
+                                      hipStream_t st) {
+  return dtf_fc_bwd_trio_f32_shard_bias(X1, dY1, ldy1, dW1, M1, N1, K, dYq, Wq, dXq, Mq, Nq, Kq, splits, gA, gB, granks,
+                                        ranks_per_set, lda0, dW0_slice, M0_slice, N0, Wq_alt, wq_sel, nullptr, nullptr, nullptr, 0,
+                                        nullptr, st);
 }

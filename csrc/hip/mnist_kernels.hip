@@ -287,6 +287,8 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
   int it = 0;
   for (int row = blockIdx.x; row < p.B; row += gridDim.x, ++it) {
     float4 h = b1;
+    // the row's label: two dependent loads (permutation, label) that would otherwise start behind the barrier below
+    const int y = p.labels_all[sample_index(p.perm, p.step_ptr, p.spe, p.B, row)];
     // all split-K slabs of this row in flight at once (clamped index + select: one L2 round trip instead of nslab/4)
     for (int s0 = 0; s0 < p.nslab; s0 += 16) {
       f32x4 v[16];
@@ -349,7 +351,6 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
       pr[j] *= pinv;
       if (pr[j] > pbest) { pbest = pr[j]; arg = j; }
     }
-    const int y = p.labels_all[sample_index(p.perm, p.step_ptr, p.spe, p.B, row)];
     float dzv[NC];
     float loss;
     if (p.double_softmax) {
@@ -410,17 +411,21 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
           if (F32) reinterpret_cast<float*>(p.dz)[(long)row * 16 + j] = dzv[j];
           else p.dz[(long)row * NC + j] = f2bf(dzv[j]);
         }
+      // fp32 with the bias gradients taken by the fused fc backward launch: that launch also adds up the rows' loss and
+      // hit count, left in two padding columns of dz (no operand chunk of the fc2 filter gradient reaches columns 12..15)
+      if (F32 && !p.db_fc1 && (tid == 12 || tid == 13))
+        reinterpret_cast<float*>(p.dz)[(long)row * 16 + tid] = tid == 12 ? loss : ((arg == y) ? 1.f : 0.f);
 #pragma unroll
       for (int j = 0; j < NC; ++j) accb2[j] += dzv[j];
     }
   }
   // One atomic *instruction* per destination line: every workgroup adds to the same two cache lines, and the L2
   // serialises same-line requests (12 single-lane atomics per workgroup cost ~3 us of a 17 us kernel at 50 workgroups).
-  if (tid < 2) {
+  if (tid < 2 && !(F32 && p.training && !p.db_fc1)) {
     float* m = p.metrics + (p.metrics_ring > 0 ? 2 * (step % p.metrics_ring) : 0);
     atomicAdd(&m[tid], tid == 0 ? loss_sum : correct);
   }
-  if (p.training) {
+  if (p.training && p.db_fc1) {  // (null: the fused fc backward launch takes the bias gradients as column sums)
     float mine = 0.f;
 #pragma unroll
     for (int j = 0; j < NC; ++j) mine = tid == j ? accb2[j] : mine;
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadParams p) {
 
 DTF_API int dtf_head(const HeadParams* hp, int blocks, hipStream_t st) {
   if (hp->B <= 0 || hp->nslab < 1 || blocks < 1 || hp->keep_prob <= 0.f) return ERR_SHAPE;
-  if (hp->training && (!hp->h_drop || !hp->dh || !hp->dz || !hp->db_fc1 || !hp->db_fc2)) return ERR_SHAPE;
+  if (hp->training && (!hp->h_drop || !hp->dh || !hp->dz || (hp->db_fc1 == nullptr) != (hp->db_fc2 == nullptr))) return ERR_SHAPE;
   if (blocks > hp->B) blocks = hp->B;
   if (hp->f32)
     hipLaunchKernelGGL(head_kernel<true>, dim3(blocks), dim3(256), 0, st, *hp);

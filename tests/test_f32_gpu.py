@@ -103,6 +103,29 @@ def test_fc_backward_trio_f32(granks):
     assert relerr(dW0, ref0) < 2e-6
     assert relerr(dW1, hdrop.double().t() @ dz[:, :10].double()) < 2e-6
     assert relerr(dX, dhs[0].double() @ w.double().t()) < 1e-5
+    # the same launch with the bias gradients as column sums of dYq / dY1 (what the engine uses: the loss head then adds none)
+    lib.dtf_fc_bwd_trio_f32_bias.argtypes = [P, P, P, I, I, P, P, I, P, I, I, I, P, P, P, I, I, I, I, P, P, I, P, P, P, I, P, P]
+    lib.dtf_fc_bwd_trio_f32_bias.restype = I
+    db0 = torch.full((1024,), float("nan"), device=dev())
+    db1 = torch.full((10,), float("nan"), device=dev())
+    dz[:, 12:14] = torch.rand(B, 2, device=dev())   # (per-row loss / hit count, as the loss head leaves them)
+    ring = torch.zeros(8, 2, device=dev())
+    ring[3] = torch.tensor([0.5, 2.0])
+    step = torch.tensor([11], dtype=torch.int32, device=dev())   # slot 11 % 8 = 3
+    dW0.fill_(float("nan")); dW1.fill_(float("nan")); dX.zero_()
+    torch.cuda.synchronize()
+    rc = lib.dtf_fc_bwd_trio_f32_bias(xs[0].data_ptr(), dhs[0].data_ptr(), dW0.data_ptr(), 3136, 1024, hdrop.data_ptr(),
+                                      dz.data_ptr(), 16, dW1.data_ptr(), 1024, 10, B, dhs[0].data_ptr(), w.data_ptr(),
+                                      dX.data_ptr(), B, 3136, 1024, 8, ga if granks else None, gb if granks else None, granks,
+                                      db0.data_ptr(), db1.data_ptr(), ring.data_ptr(), 8, step.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert relerr(db0, dhs[0].double().sum(0)) < 1e-6 and relerr(db1, dz[:, :10].double().sum(0)) < 1e-6
+    want = torch.zeros(8, 2, dtype=torch.float64, device=dev())
+    want[3] = torch.tensor([0.5, 2.0], dtype=torch.float64, device=dev()) + dz[:, 12:14].double().sum(0)
+    assert relerr(ring, want) < 1e-6 and float(ring[[0, 1, 2, 4, 5, 6, 7]].abs().max()) == 0.0
+    assert relerr(dW0, ref0) < 2e-6 and relerr(dX, dhs[0].double() @ w.double().t()) < 1e-5
+    assert relerr(dW1, hdrop.double().t() @ dz[:, :10].double()) < 2e-6
     # a batch whose K slabs would straddle two ranks' blocks is refused, not mis-summed
     if granks:
         assert lib.dtf_fc_bwd_trio_f32(xs[0].data_ptr(), dhs[0].data_ptr(), dW0.data_ptr(), 3136, 1024, hdrop.data_ptr(),
