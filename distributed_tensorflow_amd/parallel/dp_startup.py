@@ -240,6 +240,9 @@ class StartupMixin:
                     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=trainer.group)
                     bad = float(t.item()) > self.errs_seen
                     self.errs_seen = max(self.errs_seen, float(t.item()))
+                    # (fault injection for tests/test_rccl_gpu.py: the reference schedule's waits "expire", every time)
+                    if os.environ.get("DTF_DP_FAULT_INJECT") == "reference-expires" and trainer.schedule == sel.REFERENCE:
+                        bad = True
                     return bad
 
                 def time_steps(self):

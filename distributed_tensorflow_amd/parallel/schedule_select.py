@@ -118,6 +118,19 @@ def run_trials(cands: Sequence[str], ops: TrialOps, *, forced: str = "auto", tim
     # the step): a candidate that is far from the reference schedule is broken on this machine
     ops.grads = grads  # (for the caller's error report)
     ref = grads[list(cands).index(REFERENCE)] if REFERENCE in cands else None
+    if REFERENCE in broken and math.isinf(times[list(cands).index(REFERENCE)]) and any(c not in broken for c in cands):
+        # The reference's own exchange ran into the bound (seen with three processes time-sharing one GPU, twice in a row),
+        # so its "gradient" is that of a skipped step.  The process group's all-reduce of the same local gradients is the
+        # same sum: take the reference from there rather than refuse every candidate.
+        ref = None
+        if "rccl" in cands and "rccl" not in broken:
+            ref = grads[list(cands).index("rccl")]
+        else:
+            note("%s: not usable as the reference; taking the reference gradient through the process group" % REFERENCE)
+            ops.use("rccl")
+            if ops.capture_ok():
+                ref = ops.first_step()
+                ops.restore()
     off = [math.inf if (g is None or ref is None) else ops.deviation(g, ref) for g in grads]
     both = ops.reduce_max(list(times) + off)
     return both[:len(times)], both[len(times):], broken

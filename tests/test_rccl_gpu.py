@@ -159,6 +159,25 @@ def test_expired_ipc_wait_skips_the_optimizer_on_every_rank(tmp_path, schedule):
     assert max(o["errors"] for o in res) >= 1 and min(o["errors"] for o in res) == 0, res
 
 
+def test_reference_schedule_that_keeps_expiring_is_replaced_by_the_process_group(tmp_path):
+    """Fault injection (``DTF_DP_FAULT_INJECT=reference-expires``): the reference schedule's trial step "expires" twice, as
+    seen with three processes time-sharing one GPU.  The forced schedule is then validated against the process group's
+    all-reduce of the same gradients instead of being refused, and training runs on it with the replicas in sync."""
+    script = tmp_path / "sharded_state.py"
+    script.write_text(_SHARDED_STATE)
+    env = dict(os.environ, MASTER_PORT="29657", HSA_ENABLE_IPC_MODE_LEGACY="0", DTF_DP_SCHEDULE="ipc-shard", DTF_TEST_TAG="a",
+               DTF_DP_FAULT_INJECT="reference-expires")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29657", str(script), REPO, str(tmp_path)]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "taking the reference gradient through the process group" in r.stdout, r.stdout[-3000:]
+    res = [json.load(open(str(tmp_path / ("a_r%d.json" % q)))) for q in range(2)]
+    for o in res:
+        assert o["schedule"] == "ipc-shard" and o["in_sync"] and o["errors"] == 0 and o["live_step"] == 37, o
+        assert o["live"] == res[0]["live"], o
+
+
 def test_cleared_expiry_count_lets_the_ipc_schedule_continue_without_a_spurious_skip(tmp_path):
     """``IpcAllReduce.reset_errors()`` (start-up, after a candidate schedule with an expired wait was dropped): this rank's
     count, the copy the peers read and the total each rank has acted on are cleared together, so the steps that follow are

@@ -185,3 +185,25 @@ def test_reference_whose_wait_expired_once_is_tried_again():
     ops = FakeOps(US8, expire_once={"ipc-inline"})
     times, off, broken = _run(ops, cands, forced="ipc-shard", timed=False)
     assert not broken and sel.choose(cands, times, off, broken, forced="ipc-shard") == "ipc-shard"
+
+
+def test_reference_that_keeps_expiring_is_replaced_by_the_process_group():
+    """The reference schedule's exchange expired twice (three processes time-sharing one GPU): its gradient is that of a
+    skipped step.  The reference gradient is then taken through the process group's all-reduce, the candidates are judged
+    against it, and the reference schedule itself stays not eligible."""
+    cands = sel.trial_list(sel.candidates(**dict(ALL, forced="ipc-shard")))
+    ops = FakeOps(US8, expire={"ipc-inline"})
+    times, off, broken = _run(ops, cands, forced="ipc-shard", timed=False)
+    assert broken == {"ipc-inline"} and ops.used == ["ipc-shard", "ipc-inline", "rccl"] and off[0] == 0.0
+    assert sel.choose(cands, times, off, broken, forced="ipc-shard") == "ipc-shard"
+    assert any("process group" in m for m in ops.log)
+    # a candidate with a wrong gradient is still caught against that reference
+    ops = FakeOps(US8, expire={"ipc-inline"}, wrong={"ipc-shard"})
+    times, off, broken = _run(ops, cands, forced="ipc-shard", timed=False)
+    with pytest.raises(RuntimeError):
+        sel.choose(cands, times, off, broken, forced="ipc-shard")
+    # automatic selection with RCCL among the candidates: its trial gradient is the reference, no extra trial
+    cands = sel.candidates(**ALL)
+    ops = FakeOps(US8, expire={"ipc-inline"})
+    times, off, broken = _run(ops, cands)
+    assert ops.used == cands and sel.choose(cands, times, off, broken) == "ipc-shard"
